@@ -1,0 +1,75 @@
+"""Pins oracle/affnet_oracle.py against the UNMODIFIED reference, bit for bit.
+
+Runs only where /root/reference exists (the authoring container).  Exit code 0 = every
+compared tensor is bit-identical.  Usage: python oracle/check_restatement.py [--fast]
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import affnet_oracle as orc  # noqa: E402
+import ref_harness as rh  # noqa: E402
+
+
+def same(name, a, b):
+    a, b = np.asarray(a), np.asarray(b)
+    ok = a.shape == b.shape and np.array_equal(a, b)
+    md = float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max()) if a.shape == b.shape and a.size else -1
+    print("%-34s %s  shape=%s maxdiff=%g" % (name, "IDENTICAL" if ok else "DIFFERS", a.shape, md))
+    return ok
+
+
+def run(fast=False):
+    ns = rh.import_reference()
+    from PIL import Image
+    torch.manual_seed(0)
+    aff_sd, ori_sd = rh.load_state_dict("AffNet.pth"), rh.load_state_dict("OriNet.pth")
+    hard_sd = orc.synthetic_hardnet_state(0)
+    A = ns.architectures.AffNetFast(PS=32); A.load_state_dict(aff_sd); A.eval()
+    O = ns.architectures.OriNetFast(PS=32); O.load_state_dict(ori_sd); O.eval()
+    Hn = ns.HardNet.HardNet(); Hn.load_state_dict(hard_sd); Hn.eval()
+    cases = [("synthetic 240x320", orc.synthetic_image(240, 320, 1), 300)]
+    if not fast:
+        img = np.mean(np.array(Image.open(os.path.join(rh.REF_ROOT, "test-graf/img1.png")).convert("RGB")), axis=2)
+        cases.append(("graf img1", torch.from_numpy(img.astype(np.float32)).view(1, 1, *img.shape), 2000))
+    ok = True
+    for name, x, n in cases:
+        print("== %s, N=%d" % (name, n))
+        det = ns.SparseImgRepresenter.ScaleSpaceAffinePatchExtractor(
+            mrSize=5.192, num_features=n, border=5, num_Baum_iters=1, AffNet=A, OriNet=O)
+        with torch.no_grad(), rh.quiet():
+            L, r = det(x, do_ori=True)
+            P = det.extract_patches_from_pyr(L, PS=32)
+            D = Hn(P)
+        o = orc.OracleExtractor(mrSize=5.192, num_features=n, border=5, num_Baum_iters=1,
+                                affnet_sd=aff_sd, orinet_sd=ori_sd)
+        L2, r2, P2, D2 = orc.describe(x, o, hard_sd, do_ori=True, ps=32)
+        for oi in range(len(det.scale_pyr)):
+            for li in range(len(det.scale_pyr[oi])):
+                ok &= np.array_equal(det.scale_pyr[oi][li].numpy(), o.scale_pyr[oi][li].numpy())
+        print("pyramid identical so far:", ok)
+        ok &= same("sigmas", np.array(det.sigmas), np.array(o.sigmas))
+        ok &= same("LAFs", L.numpy(), L2.numpy())
+        ok &= same("responses", r.numpy(), r2.numpy())
+        ok &= same("patches", P.numpy(), P2.numpy())
+        ok &= same("descriptors", D.numpy(), D2.numpy())
+        # threshold mode (hesaffnet.py as shipped: th = -1 -> num = -1)
+        if name.startswith("synthetic"):
+            det = ns.SparseImgRepresenter.ScaleSpaceAffinePatchExtractor(
+                mrSize=5.192, num_features=n, border=5, num_Baum_iters=1, th=-1, AffNet=A)
+            with torch.no_grad(), rh.quiet():
+                L, r = det(x)
+            o = orc.OracleExtractor(mrSize=5.192, num_features=n, border=5, num_Baum_iters=1, th=-1, affnet_sd=aff_sd)
+            L2, r2 = o(x)
+            ok &= same("th=-1 LAFs", L.numpy(), L2.numpy())
+            ok &= same("th=-1 responses", r.numpy(), r2.numpy())
+            ok &= same("LAFs2ell", ns.LAF.LAFs2ell(L.numpy()), orc.lafs_to_ellipses(L2.numpy()))
+    print("ALL IDENTICAL" if ok else "MISMATCH")
+    return ok
+
+
+if __name__ == "__main__":
+    sys.exit(0 if run("--fast" in sys.argv) else 1)

@@ -1,0 +1,96 @@
+"""CPU: pins oracle/affnet_oracle.py against golden vectors produced by the UNMODIFIED
+reference (tests/golden/make_golden.py).  Tolerances: the vectors were generated on the
+authoring host; the same ATen kernels on another x86 host may differ in the last ulp of a
+convolution, so floating outputs are compared at 1e-4 relative (bit-identity is asserted by
+oracle/check_restatement.py wherever the reference itself is present)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import affnet_oracle as orc
+from conftest import load_gray
+
+
+def _close(a, b, atol, what):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, what
+    d = np.abs(a.astype(np.float64) - b.astype(np.float64)).max() if a.size else 0.0
+    assert d <= atol, "%s: max abs diff %g > %g" % (what, d, atol)
+
+
+def _full(x, n, weights, do_ori=True):
+    ex = orc.OracleExtractor(mrSize=5.192, num_features=n, border=5, num_Baum_iters=1,
+                             affnet_sd=weights["AffNet"], orinet_sd=weights["OriNet"])
+    return ex, orc.describe(x, ex, weights["HardNet"], do_ori=do_ori, ps=32)
+
+
+def test_synthetic_full_path(golden_dir, weights):
+    g = np.load(os.path.join(golden_dir, "synth_240x320_s1_n300.npz"))
+    x = orc.synthetic_image(240, 320, 1)
+    ex, (L, r, P, D) = _full(x, 300, weights)
+    sums = np.array([lv[0, 0].numpy().astype(np.float64).sum() for o in ex.scale_pyr for lv in o])
+    np.testing.assert_allclose(sums, g["pyr_sums"], rtol=1e-9)
+    _close(np.array(ex.sigmas), g["sigmas"], 0, "sigmas")
+    _close(L.numpy(), g["LAFs"], 2e-4, "LAFs px")
+    _close(r.numpy(), g["resp"], 1e-3, "responses")
+    _close(P[:16].numpy(), g["patches_head"], 1e-3, "patches")
+    _close(D.numpy(), g["desc"], 1e-5, "descriptors")
+    assert ex.keys.shape == (300, 3)
+
+
+def test_graf_img1(golden_dir, weights):
+    g = np.load(os.path.join(golden_dir, "graf_img1_n500.npz"))
+    x = load_gray(os.path.join(golden_dir, "graf_img1.png"))
+    ex, (L, r, P, D) = _full(x, 500, weights)
+    assert len(ex.scale_pyr) == 6 and tuple(ex.scale_pyr[0][0].shape[2:]) == (640, 800)
+    _close(L.numpy(), g["LAFs"], 5e-4, "LAFs px")
+    _close(r.numpy(), g["resp"], 1e-2, "responses")
+    _close(D.numpy(), g["desc"], 1e-5, "descriptors")
+
+
+def test_threshold_mode_and_ellipses(golden_dir, weights):
+    g = np.load(os.path.join(golden_dir, "synth_240x320_s1_thmode.npz"))
+    x = orc.synthetic_image(240, 320, 1)
+    ex = orc.OracleExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=1, th=-1,
+                             affnet_sd=weights["AffNet"])
+    L, r = ex(x)
+    assert ex.num == -1
+    _close(L.numpy(), g["LAFs"], 2e-4, "LAFs")
+    _close(r.numpy(), g["resp"], 1e-3, "resp")
+    np.testing.assert_allclose(orc.lafs_to_ellipses(L.numpy()), g["ells"], rtol=2e-3, atol=1e-7)
+
+
+def test_just_shape_column(golden_dir, weights):
+    g = np.load(os.path.join(golden_dir, "just_shape_column.npz"))
+    out = orc.detect_affine_shape(weights["AffNet"], g["column"])
+    _close(out, g["affine"], 1e-5, "a11 a12 a21 a22")
+    assert np.all(out[:, 1] == 0)
+
+
+def test_cnn_vectors(golden_dir, weights):
+    g = np.load(os.path.join(golden_dir, "cnn_random_patches.npz"))
+    p = torch.from_numpy(g["patches"])
+    with torch.no_grad():
+        _close(orc.affnet_forward(weights["AffNet"], p).numpy(), g["affnet"], 1e-5, "AffNet")
+        _close(orc.orinet_forward(weights["OriNet"], p).numpy(), g["orinet"], 1e-5, "OriNet")
+        _close(orc.hardnet_forward(weights["HardNet"], p).numpy(), g["hardnet"], 1e-5, "HardNet")
+
+
+def test_sampler_vectors(golden_dir):
+    g = np.load(os.path.join(golden_dir, "sampler_synth.npz"))
+    x = orc.synthetic_image(240, 320, 1)
+    lafs = torch.from_numpy(g["lafs"])
+    _close(orc.extract_patches(x, lafs, 32).numpy(), g["p32"], 1e-4, "PS=32")
+    _close(orc.extract_patches(x, lafs, 41).numpy(), g["p41"], 1e-4, "PS=41")
+
+
+def test_edge_cases():
+    # empty level handling (HandCraftedModules.py:252-254) and an image with no detections at all
+    flat = torch.zeros(1, 1, 64, 80)
+    with pytest.raises((RuntimeError, ValueError)):  # torch.cat([]) in the reference (SparseImgRepresenter.py:100)
+        orc.multi_scale_detector(flat, 100, mr_size=5.192)
+    plan = orc.pyramid_plan(768, 1024)
+    assert [(o["h"], o["w"]) for o in plan["octaves"]] == [(768, 1024), (384, 512), (192, 256), (96, 128), (48, 64), (24, 32)]
+    assert len(orc.pyramid_plan(2160, 3840)["octaves"]) == 8
