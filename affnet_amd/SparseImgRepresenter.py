@@ -1,0 +1,198 @@
+"""ScaleSpaceAffinePatchExtractor with the reference's constructor, forward() and
+extract_patches_from_pyr() (SparseImgRepresenter.py:14-209), executed on MI355X by
+libaffnet_hip.so.
+
+* native slots (affnet_amd.architectures.AffNetFast / OriNetFast, default HessianResp): ONE C call,
+  `affnet_extract_features`, runs pyramid -> detector -> AffNet -> filter -> OriNet ->
+  denormalise with no host synchronisation; the only read-back is the final row count;
+* foreign slots (any callable with the reference's slot signature): the same
+  stages are driven one by one through the C ABI and the slot is called on device tensors.
+
+Not built (SURVEY.md section 8f "next"): the hand-crafted default slot fillers AffineShapeEstimator /
+OrientationDetector and a custom RespNet; asking for them raises NotImplementedError.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib, engine
+from ._lib import lib, check, ptr
+from .architectures import _HipPatchNet
+
+
+class ScaleSpaceAffinePatchExtractor(nn.Module):
+    def __init__(self, border=16, num_features=500, patch_size=32, mrSize=3.0, nlevels=3, num_Baum_iters=0,
+                 init_sigma=1.6, th=None, RespNet=None, OriNet=None, AffNet=None):
+        super(ScaleSpaceAffinePatchExtractor, self).__init__()
+        self.mrSize, self.PS, self.b = mrSize, patch_size, border
+        self.num, self.nlevels = num_features, nlevels
+        self.num_Baum_iters, self.init_sigma = num_Baum_iters, init_sigma
+        self.th = th
+        if th is not None:        # SparseImgRepresenter.py:33-37: a threshold disables the feature budget
+            self.num = -1
+        else:
+            self.th = 0
+        if RespNet is not None:
+            raise NotImplementedError("custom RespNet slot: only the built-in HessianResp is implemented in HIP")
+        if nlevels != 3:
+            raise NotImplementedError("the HIP detector is specialised for nlevels=3 (5 levels per octave)")
+        if num_Baum_iters > 1:
+            raise NotImplementedError("num_Baum_iters > 1 (iterated AffNet with re-extraction) is not implemented")
+        if num_Baum_iters > 0 and AffNet is None:
+            raise NotImplementedError("default AffineShapeEstimator (Baumberg) slot is SURVEY section 8f 'next'; pass AffNet=")
+        self.OriNet = OriNet
+        self.AffNet = AffNet
+        self.scale_pyr = self.sigmas = self.pix_dists = None
+        self._ctx = None
+        self._ctx_key = None
+        self.last_ids = None       # (N,3) int32 (octave, level-1, pixel) of the detections returned last
+        self.max_keep = 16384      # row capacity in threshold mode (num = -1)
+
+    # ------------------------------------------------------------------------------------------
+    def _context(self, x):
+        engine.require_cuda(x, "image")
+        if x.dim() != 4 or x.size(0) != 1 or x.size(1) != 1:
+            raise ValueError("expected a (1,1,H,W) image; the detector is batch-size-1 like the reference "
+                             "(HandCraftedModules.py:283-284)")
+        pre = int(1.5 * self.num) if self.num_Baum_iters > 0 else self.num
+        key = (x.size(2), x.size(3), x.device, pre, self.num, float(self.th), self.mrSize, self.b, self.init_sigma, self.max_keep)
+        if self._ctx is None or self._ctx_key != key:
+            self._ctx = engine.Context(x.size(2), x.size(3), x.device, self.nlevels, self.init_sigma, self.b, self.mrSize,
+                                       float(self.th), self.num, pre, self.max_keep)
+            self._ctx_key = key
+        return self._ctx
+
+    def _publish_pyramid(self, ctx):
+        self.scale_pyr = ctx.pyramid_views()
+        self.sigmas = [list(s) for s in ctx.plan.sigmas]
+        self.pix_dists = [list(p) for p in ctx.plan.pix_dists]
+
+    @staticmethod
+    def _native(slot):
+        return slot is None or isinstance(slot, _HipPatchNet)
+
+    def run(self, x, do_ori=False, desc=None):
+        """Fused path.  Returns dict(LAFs px (N,2,3), responses (N,), ids (N,3), descriptors (N,128)|None).
+        `desc`: affnet_amd.HardNet.HardNet or None."""
+        ctx = self._context(x)
+        dev = x.device
+        if do_ori and self.OriNet is None:
+            raise NotImplementedError("default OrientationDetector slot is SURVEY section 8f 'next'; pass OriNet=")
+        img = x.contiguous().float()
+        F = ctx.cap_final
+        lafs = torch.empty(F, 2, 3, dtype=torch.float32, device=dev)
+        resp = torch.empty(F, dtype=torch.float32, device=dev)
+        ids = torch.empty(F, 3, dtype=torch.int32, device=dev)
+        count = torch.zeros(1, dtype=torch.int32, device=dev)
+        dsc = torch.empty(F, 128, dtype=torch.float32, device=dev) if desc is not None else None
+        nets = _lib.Nets()
+        nets.d_affnet = self.AffNet.packed_weights(dev).data_ptr() if self.num_Baum_iters > 0 else None
+        nets.d_orinet = self.OriNet.packed_weights(dev).data_ptr() if do_ori else None
+        nets.d_hardnet = desc.packed_weights(dev).data_ptr() if desc is not None else None
+        rc = lib.affnet_extract_features(ctx.handle, C.byref(nets), ptr(img), int(bool(do_ori)), ptr(lafs), ptr(resp), ptr(ids),
+                                         ptr(dsc), ptr(count), engine.stream_of(dev))
+        check(rc, ctx.handle, "affnet_extract_features")
+        self._publish_pyramid(ctx)
+        counts = ctx.read_counts()          # the one host read-back (also surfaces capacity overflow)
+        n = int(count.item())
+        if counts[0] == 0:
+            raise RuntimeError("no keypoints detected (the reference raises in torch.cat, SparseImgRepresenter.py:100)")
+        self.last_ids = ids[:n]
+        return {"LAFs": lafs[:n], "responses": resp[:n], "ids": ids[:n], "descriptors": None if dsc is None else dsc[:n]}
+
+    # ------------------------------------------------------------------------------------------
+    def _staged(self, x, do_ori):
+        """Stage-by-stage path for foreign AffNet / OriNet slots (same kernels, slot called on tensors)."""
+        ctx = self._context(x)
+        dev, st = x.device, engine.stream_of(x.device)
+        img = x.contiguous().float()
+        P, F = ctx.cap_pre, ctx.cap_final
+        check(lib.affnet_pyramid_build(ctx.handle, ptr(img), st), ctx.handle, "affnet_pyramid_build")
+        self._publish_pyramid(ctx)
+        resp = torch.empty(P, dtype=torch.float32, device=dev)
+        lafs = torch.empty(P, 2, 3, dtype=torch.float32, device=dev)
+        ids = torch.empty(P, 3, dtype=torch.int32, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        check(lib.affnet_detect(ctx.handle, ptr(resp), ptr(lafs), ptr(ids), ptr(cnt), st), ctx.handle, "affnet_detect")
+        n = int(cnt.item())
+        ctx.read_counts()
+        if n == 0:
+            raise RuntimeError("no keypoints detected (the reference raises in torch.cat, SparseImgRepresenter.py:100)")
+        if self.num_Baum_iters > 0:
+            PS = self.AffNet.PS
+            patches = torch.empty(n, 1, PS, PS, dtype=torch.float32, device=dev)
+            check(lib.affnet_pyr_grid_sample(ctx.handle, ptr(lafs), ptr(ids), ptr(cnt), n, PS, ptr(patches), st), ctx.handle,
+                  "affnet_pyr_grid_sample")
+            with torch.no_grad():
+                A = torch.cat([self.AffNet(patches[s:s + 256], {}) for s in range(0, n, 256)], 0)   # Utils.py:37-66
+            Afull = torch.zeros(P, 2, 2, dtype=torch.float32, device=dev)
+            Afull[:n] = A.to(dev, torch.float32)
+            r2 = torch.empty(F, dtype=torch.float32, device=dev)
+            l2 = torch.empty(F, 2, 3, dtype=torch.float32, device=dev)
+            i2 = torch.empty(F, 3, dtype=torch.int32, device=dev)
+            c2 = torch.zeros(1, dtype=torch.int32, device=dev)
+            check(lib.affnet_shape_filter_select(ctx.handle, ptr(resp), ptr(lafs), ptr(ids), ptr(Afull), ptr(cnt), ptr(r2), ptr(l2),
+                                                 ptr(i2), ptr(c2), st), ctx.handle, "affnet_shape_filter_select")
+            n = int(c2.item())
+            resp, lafs, ids, cnt = r2, l2, i2, c2
+        if do_ori:
+            PS = self.OriNet.PS
+            patches = torch.empty(n, 1, PS, PS, dtype=torch.float32, device=dev)
+            if n:
+                check(lib.affnet_pyr_grid_sample(ctx.handle, ptr(lafs), ptr(ids), ptr(cnt), n, PS, ptr(patches), st), ctx.handle,
+                      "affnet_pyr_grid_sample")
+            with torch.no_grad():
+                ang = self.OriNet(patches)
+            if ang.dim() <= 2:   # angles -> rotation matrices (LAF.py:306-311)
+                c, s = torch.cos(ang).view(-1, 1, 1), torch.sin(ang).view(-1, 1, 1)
+                ang = torch.cat([torch.cat([c, s], 2), torch.cat([-s, c], 2)], 1)
+            R = ang.to(dev, torch.float32).contiguous()
+            if n:
+                check(lib.affnet_apply_rotation(ctx.handle, ptr(lafs), ptr(R), ptr(cnt), n, st), ctx.handle, "affnet_apply_rotation")
+        out = torch.empty_like(lafs)
+        check(lib.affnet_scale_lafs(ctx.handle, ptr(lafs), ptr(out), ptr(cnt), lafs.size(0), x.size(3), x.size(2), 0, st), ctx.handle,
+              "affnet_scale_lafs")
+        self.last_ids = ids[:n]
+        return out[:n], resp[:n]
+
+    def forward(self, x, do_ori=False):
+        """x (1,1,H,W) fp32 0..255 on the GPU -> (LAFs in pixels (N,2,3), responses (N,))."""
+        aff_native = self.num_Baum_iters == 0 or self._native(self.AffNet)
+        ori_native = (not do_ori) or self._native(self.OriNet)
+        if aff_native and ori_native:
+            r = self.run(x, do_ori=do_ori)
+            return r["LAFs"], r["responses"]
+        return self._staged(x, do_ori)
+
+    def extract_patches_from_pyr(self, dLAFs, PS=41):
+        """Pixel LAFs (N,2,3) -> (N,1,PS,PS) sampled from the best pyramid level of the LAST forward()
+        (SparseImgRepresenter.py:181-188; level choice on the device instead of host scipy)."""
+        if self._ctx is None or self.scale_pyr is None:
+            raise RuntimeError("call forward() first: the pyramid of the last image is reused (stateful like the reference)")
+        ctx = self._ctx
+        engine.require_cuda(dLAFs, "dLAFs")
+        dev, st = dLAFs.device, engine.stream_of(dLAFs.device)
+        lafs = dLAFs.contiguous().float()
+        n = lafs.size(0)
+        out = torch.empty(n, 1, PS, PS, dtype=torch.float32, device=dev)
+        if n == 0:
+            return out
+        ids = torch.empty(n, 3, dtype=torch.int32, device=dev)
+        norm = torch.empty(n, 2, 3, dtype=torch.float32, device=dev)
+        check(lib.affnet_level_select(ctx.handle, ptr(lafs), None, n, PS, ptr(ids), ptr(norm), st), ctx.handle, "affnet_level_select")
+        check(lib.affnet_pyr_grid_sample(ctx.handle, ptr(norm), ptr(ids), None, n, PS, ptr(out), st), ctx.handle, "affnet_pyr_grid_sample")
+        self.last_level_ids = ids
+        return out
+
+
+def get_geometry_and_descriptors(img, det, desc, do_ori=True):
+    """train_OriNet_test_on_graffity.py:293-298.  With native nets this is one fused C call."""
+    from .HardNet import HardNet
+    if isinstance(desc, HardNet) and det._native(det.AffNet) and det._native(det.OriNet):
+        r = det.run(img, do_ori=do_ori, desc=desc)
+        return r["LAFs"], r["descriptors"]
+    with torch.no_grad():
+        LAFs, resp = det(img, do_ori=do_ori)
+        patches = det.extract_patches_from_pyr(LAFs, PS=32)
+        return LAFs, desc(patches)

@@ -1,0 +1,104 @@
+"""ctypes binding of libaffnet_hip.so (include/affnet_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol cannot be
+resolved, importing the binding raises.  Build it with `python -c "import __graft_entry__ as g;
+g.build()"` or `bash affnet_amd/csrc/build.sh`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaffnet_hip.so")
+
+MAX_OCTAVES, MAX_LEVELS, MAX_TAPS = 16, 8, 31
+NET_AFFNET, NET_ORINET, NET_HARDNET = 0, 1, 2
+OK, ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_EMPTY = 0, -1, -2, -3, -4
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("height", C.c_int32), ("width", C.c_int32), ("n_octaves", C.c_int32), ("levels_per_octave", C.c_int32),
+        ("oct_h", C.c_int32 * MAX_OCTAVES), ("oct_w", C.c_int32 * MAX_OCTAVES),
+        ("level_sigma", (C.c_float * MAX_LEVELS) * MAX_OCTAVES),
+        ("level_sigma4", (C.c_float * MAX_LEVELS) * MAX_OCTAVES),
+        ("level_sigma_px", (C.c_double * MAX_LEVELS) * MAX_OCTAVES),
+        ("first_blur_taps", C.c_int32), ("first_blur", C.c_float * (MAX_TAPS * MAX_TAPS)),
+        ("level_blur_taps", C.c_int32 * MAX_LEVELS),
+        ("level_blur", (C.c_float * (MAX_TAPS * MAX_TAPS)) * MAX_LEVELS),
+        ("mr_size", C.c_float), ("threshold", C.c_float),
+        ("num_features", C.c_int32), ("num_prefilter", C.c_int32),
+        ("max_raw_per_octave_div", C.c_int32), ("max_keep", C.c_int32),
+    ]
+
+
+class Nets(C.Structure):
+    _fields_ = [("d_affnet", C.c_void_p), ("d_orinet", C.c_void_p), ("d_hardnet", C.c_void_p)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/affnet_hip.h
+_P, _I, _SZ = C.c_void_p, C.c_int, C.c_size_t
+SYMBOLS = {
+    "affnet_ctx_create": (_I, [C.POINTER(_P), _I, C.POINTER(Config)]),
+    "affnet_ctx_destroy": (None, [_P]),
+    "affnet_last_error": (C.c_char_p, [_P]),
+    "affnet_version": (C.c_char_p, []),
+    "affnet_workspace_bytes": (_SZ, [_P]),
+    "affnet_bind_workspace": (_I, [_P, _P, _SZ]),
+    "affnet_pyramid_level_offset": (C.c_int64, [_P, _I, _I]),
+    "affnet_capacity_prefilter": (_I, [_P]),
+    "affnet_capacity_final": (_I, [_P]),
+    "affnet_gauss_blur": (_I, [_P, _P, _P, _I, _I, C.POINTER(C.c_float), _I, _P]),
+    "affnet_pyramid_build": (_I, [_P, _P, _P]),
+    "affnet_hessian_response": (_I, [_P, _P, _P, _I, _I, C.c_float, _P]),
+    "affnet_detect": (_I, [_P, _P, _P, _P, _P, _P]),
+    "affnet_laf_grid_sample": (_I, [_P, _P, _I, _I, _P, _I, _I, _P, _P]),
+    "affnet_pyr_grid_sample": (_I, [_P, _P, _P, _P, _I, _I, _P, _P]),
+    "affnet_cnn32_packed_floats": (_SZ, [_I]),
+    "affnet_cnn32_pack_weights": (_I, [_I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _P, _P, _P, _P]),
+    "affnet_cnn32_forward": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P]),
+    "affnet_cnn32_forward_pyr": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
+    "affnet_cnn32_debug_layer": (_I, [_P, _I, _P, _P, _I, _P, _P]),
+    "affnet_shape_filter_select": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "affnet_apply_rotation": (_I, [_P, _P, _P, _P, _I, _P]),
+    "affnet_scale_lafs": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "affnet_level_select": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
+    "affnet_extract_features": (_I, [_P, C.POINTER(Nets), _P, _I, _P, _P, _P, _P, _P, _P]),
+    "affnet_read_counts": (_I, [_P, C.POINTER(C.c_int32 * 4), _P]),
+    "affnet_host_base_grid": (_I, [_I, C.POINTER(C.c_float)]),
+    "affnet_selftest_mfma": (_I, [_P, _P, _P, _P]),
+}
+
+
+class AffnetHipError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.isfile(LIB_PATH):
+        raise ImportError(
+            "affnet_amd: %s is missing - the HIP extension is the only implementation of this path "
+            "(no CPU fallback). Build it: bash affnet_amd/csrc/build.sh" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # raises AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, ctx=None, what=""):
+    if rc != OK:
+        msg = lib.affnet_last_error(ctx).decode() if ctx else ""
+        raise AffnetHipError("%s failed (code %d): %s" % (what or "libaffnet_hip call", rc, msg))
+
+
+def ptr(t):
+    """Device (or host) pointer of a torch tensor as c_void_p; None -> NULL."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def current_stream(device):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,599 @@
+// 32x32-patch CNNs (AffNetFast / OriNetFast / HardNet) for gfx950 on the fp32 matrix cores.
+//
+// Replaces architectures.py:204-252 (AffNetFast), :33-82 (OriNetFast), HardNet.py:61-101
+// (HardNet) incl. input_norm, eval-mode BatchNorm (folded into weights + bias at pack time),
+// ReLU, the heads, rectifyAffineTransformationUpIsUp (LAF.py:285-291), get_rotation_matrix
+// (LAF.py:276-283) and L2Norm (HardNet.py:12-19).
+//
+// Design (one workgroup = 8 wavefronts = one patch, whole trunk resident on the CU):
+//   * the patch is sampled (or loaded), standardised (mean / unbiased std + 1e-7) and conv0
+//     (K = 9, VALU) writes its planes into ONE LDS activation buffer, planar [c][H+2][W+2] with a
+//     zero halo (so the 3x3 taps are plain address offsets and padding costs nothing);
+//   * conv1..conv5 are implicit GEMMs on v_mfma_f32_16x16x4_f32 (exact fp32, 32 cycles):
+//     M = output pixels (16 consecutive pixels per tile -> conflict-free ds_read_b32 A fragments:
+//     lane = (pixel, k) with k = 4 consecutive input channels one plane apart), N = 16 output
+//     channels per tile, K = (tap, cin).  B fragments stream from the packed weights in L2
+//     ([k][n], n fastest -> coalesced 64-byte segments).  The 8 waves split the M x N tile grid
+//     (TM x TN register blocking per wave);
+//   * a layer's complete output lives in the accumulators (<= 64 VGPR/lane) until every wave has
+//     finished reading the input; then bias + ReLU are applied and the planes are written back IN
+//     PLACE over the input.  One activation buffer (<= 148 KB of the 160 KB LDS), no HBM traffic
+//     between layers: per patch the kernel reads 4 KB (or samples the pyramid) + the L2-resident
+//     weights and writes 16 B (AffNet/OriNet) or the 32 KB conv5 tensor (HardNet);
+//   * AffNet / OriNet heads (K = 4096, N <= 3) run on the VALU in the same kernel; the HardNet
+//     head (8192 x 128, 4.2 MB of weights) is a separate GEMM over all patches so the weights are
+//     read once per 16 patches instead of once per patch, with BN + L2 normalisation fused.
+#include <math.h>
+
+#include "common.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define PST32 1157   // plane strides (floats) of the padded 34x34 / 18x18 / 10x10 planes, odd => the
+#define PST16 325    // 16 lanes of an epilogue store (16 channels, same pixel) hit 16 distinct banks
+#define PST8 101
+#define WP32 34
+#define WP16 18
+#define WP8 10
+#define CNN_THREADS 512
+#define HEAD_K 8192
+
+// ---- packed weight layout --------------------------------------------------------------------------
+struct NetLayout {
+    int cb;                 // base width: 16 (AffNet/OriNet) or 32 (HardNet)
+    int cin[6], cout[6];
+    size_t w_off[6], b_off[6];
+    size_t head_w, head_b;  // head weights / bias (HardNet: BN-folded [8192][128] + bias[128])
+    size_t total;
+};
+
+static NetLayout net_layout(int kind) {
+    NetLayout L;
+    L.cb = (kind == AFFNET_NET_HARDNET) ? 32 : 16;
+    const int ch[7] = {1, L.cb, L.cb, 2 * L.cb, 2 * L.cb, 4 * L.cb, 4 * L.cb};
+    size_t off = 0;
+    for (int i = 0; i < 6; ++i) {
+        L.cin[i] = ch[i]; L.cout[i] = ch[i + 1];
+        L.w_off[i] = off; off += (size_t)9 * ch[i] * ch[i + 1];
+        L.b_off[i] = off; off += ch[i + 1];
+        off = (off + 3) & ~(size_t)3;
+    }
+    L.head_w = off;
+    if (kind == AFFNET_NET_AFFNET) { off += 3 * 4096; L.head_b = off; off += 4; }
+    else if (kind == AFFNET_NET_ORINET) { off += 2 * 4096; L.head_b = off; off += 4; }
+    else { off += (size_t)HEAD_K * 128; L.head_b = off; off += 128; }
+    L.total = off;
+    return L;
+}
+
+extern "C" size_t affnet_cnn32_packed_floats(int net_kind) {
+    if (net_kind < 0 || net_kind > 2) return 0;
+    return net_layout(net_kind).total;
+}
+
+extern "C" int affnet_cnn32_pack_weights(int kind, const float* const* conv_w, const float* const* bn_mean, const float* const* bn_var,
+                                         const float* head_w, const float* head_b, const float* head_bn_mean, const float* head_bn_var,
+                                         float* out) {
+    if (kind < 0 || kind > 2 || !conv_w || !bn_mean || !bn_var || !head_w || !out) return AFFNET_ERR_INVALID;
+    const NetLayout L = net_layout(kind);
+    memset(out, 0, L.total * sizeof(float));
+    for (int i = 0; i < 6; ++i) {
+        const int ci = L.cin[i], co = L.cout[i];
+        for (int n = 0; n < co; ++n) {
+            const float s = 1.0f / sqrtf(bn_var[i][n] + 1e-5f);      // BatchNorm2d(affine=False), eps 1e-5, eval mode
+            out[L.b_off[i] + n] = -bn_mean[i][n] * s;
+            for (int c = 0; c < ci; ++c)
+                for (int t = 0; t < 9; ++t) {
+                    const float w = conv_w[i][((size_t)n * ci + c) * 9 + t] * s;
+                    if (i == 0) out[L.w_off[0] + (size_t)n * 9 + t] = w;                 // [n][tap]
+                    else out[L.w_off[i] + ((size_t)t * ci + c) * co + n] = w;           // [tap][cin][n]
+                }
+        }
+    }
+    if (kind == AFFNET_NET_HARDNET) {
+        if (!head_bn_mean || !head_bn_var) return AFFNET_ERR_INVALID;
+        for (int n = 0; n < 128; ++n) {
+            const float s = 1.0f / sqrtf(head_bn_var[n] + 1e-5f);
+            out[L.head_b + n] = -head_bn_mean[n] * s;
+            for (int k = 0; k < HEAD_K; ++k) out[L.head_w + (size_t)k * 128 + n] = head_w[(size_t)n * HEAD_K + k] * s;
+        }
+    } else {
+        const int no = kind == AFFNET_NET_AFFNET ? 3 : 2;
+        if (!head_b) return AFFNET_ERR_INVALID;
+        memcpy(out + L.head_w, head_w, (size_t)no * 4096 * sizeof(float));
+        memcpy(out + L.head_b, head_b, no * sizeof(float));
+    }
+    return AFFNET_OK;
+}
+
+struct NetOffsets {        // device-side copy of the offsets (by-value kernel argument)
+    int w[6], b[6], head_w, head_b;
+};
+
+static NetOffsets to_offsets(const NetLayout& L) {
+    NetOffsets o;
+    for (int i = 0; i < 6; ++i) { o.w[i] = (int)L.w_off[i]; o.b[i] = (int)L.b_off[i]; }
+    o.head_w = (int)L.head_w; o.head_b = (int)L.head_b;
+    return o;
+}
+
+// ---- device helpers ------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// Sum `v` over the 512 threads of the workgroup; red must hold >= 8 floats.  Two barriers.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+}
+
+// Zero the 1-pixel halo of `cout` planes of an (H+2)x(H+2) padded layout.
+template <int H, int PST>
+__device__ __forceinline__ void zero_halo(float* act, int cout) {
+    constexpr int WP = H + 2;
+    constexpr int CELLS = 4 * (H + 1);
+    for (int i = threadIdx.x; i < cout * CELLS; i += CNN_THREADS) {
+        const int c = i / CELLS, e = i - c * CELLS;
+        int y, x;
+        if (e < WP) { y = 0; x = e; }
+        else if (e < 2 * WP) { y = H + 1; x = e - WP; }
+        else { const int r = e - 2 * WP; y = 1 + (r >> 1); x = (r & 1) ? H + 1 : 0; }
+        act[c * PST + y * WP + x] = 0.0f;
+    }
+}
+
+// Implicit-GEMM 3x3 convolution (padding 1) of the planar LDS tensor `act` ([CIN][HIN+2][HIN+2],
+// plane stride PSI) with packed weights Wg [9*CIN][COUT]; leaves the TM x TN tiles of this wave in
+// `acc` (pre-activation, no bias).  HOUT = HIN / STRIDE.
+template <int CIN, int COUT, int HOUT, int STRIDE, int TM, int TN, int PSI, int WPI, int UNROLL>
+__device__ __forceinline__ void conv3x3_mfma(const float* act, const float* __restrict__ Wg, f32x4 (&acc)[TM][TN], int wave, int lane) {
+    constexpr int MT = HOUT * HOUT / 16, NT = COUT / 16;
+    constexpr int MG = MT / TM, NG = NT / TN;
+    static_assert(MG * NG == 8, "8 waves must tile the layer exactly");
+    static_assert(CIN % 4 == 0 && (CIN / 4) % UNROLL == 0, "bad unroll");
+    const int mg = wave % MG, ng = wave / MG;
+    const int m = lane & 15, kq = lane >> 4;
+    int a_base[TM], b_base[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int p = (mg * TM + i) * 16 + m;
+        const int oy = p / HOUT, ox = p - oy * HOUT;
+        a_base[i] = kq * PSI + (oy * STRIDE) * WPI + ox * STRIDE;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_base[j] = kq * COUT + (ng * TN + j) * 16 + m;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - 3 * ky;
+        const int a_tap = ky * WPI + kx;
+        const float* wt = Wg + (size_t)tap * CIN * COUT;
+#pragma unroll 1
+        for (int c0 = 0; c0 < CIN; c0 += 4 * UNROLL) {
+            float a[UNROLL][TM], b[UNROLL][TN];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) b[u][j] = wt[(c0 + 4 * u) * COUT + b_base[j]];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) a[u][i] = act[(c0 + 4 * u) * PSI + a_tap + a_base[i]];
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+        }
+    }
+}
+
+// Epilogue: bias + ReLU, write the wave's tiles into the padded planar LDS layout of the NEXT layer.
+template <int COUT, int HOUT, int TM, int TN, int PSO>
+__device__ __forceinline__ void store_tiles_lds(float* act, const float* __restrict__ bias, const f32x4 (&acc)[TM][TN], int wave, int lane) {
+    constexpr int MT = HOUT * HOUT / 16, MG = MT / TM;
+    constexpr int WPO = HOUT + 2;
+    const int mg = wave % MG, ng = wave / MG;
+    const int n = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int ch = (ng * TN + j) * 16 + n;
+        const float bv = bias[ch];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int p = (mg * TM + i) * 16 + 4 * g + r;
+                const int oy = p / HOUT, ox = p - oy * HOUT;
+                act[ch * PSO + (oy + 1) * WPO + ox + 1] = fmaxf(acc[i][j][r] + bv, 0.0f);
+            }
+        }
+    }
+}
+
+// Same for the last trunk layer of HardNet: [c][8][8] flattened = the head GEMM's K order.
+template <int COUT, int TM, int TN>
+__device__ __forceinline__ void store_tiles_global(float* __restrict__ dst, const float* __restrict__ bias, const f32x4 (&acc)[TM][TN],
+                                                   int wave, int lane) {
+    constexpr int MT = 4, MG = MT / TM;
+    const int mg = wave % MG, ng = wave / MG;
+    const int n = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int ch = (ng * TN + j) * 16 + n;
+        const float bv = bias[ch];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int p = (mg * TM + i) * 16 + 4 * g;
+            float4 v;
+            v.x = fmaxf(acc[i][j][0] + bv, 0.f); v.y = fmaxf(acc[i][j][1] + bv, 0.f);
+            v.z = fmaxf(acc[i][j][2] + bv, 0.f); v.w = fmaxf(acc[i][j][3] + bv, 0.f);
+            *reinterpret_cast<float4*>(dst + ch * 64 + p) = v;
+        }
+    }
+}
+
+struct PyrSrc {            // pyramid sampling source (fused sampler)
+    const float* lvl[AFFNET_MAX_OCTAVES][AFFNET_MAX_LEVELS];
+    int h[AFFNET_MAX_OCTAVES], w[AFFNET_MAX_OCTAVES];
+    int n_octaves, n_levels;
+    float base[32];        // affine_grid base coordinates for PS = 32
+};
+
+struct CnnArgs {
+    const float* packed;
+    NetOffsets off;
+    const float* patches;  // (n,32,32) or NULL -> sample from the pyramid
+    const float* lafs;     // normalised LAFs when sampling
+    const int32_t* ids;    // (octave, level, *) when sampling
+    const int32_t* count;
+    int n_max;
+    float* out;            // AffNet/OriNet: (n,2,2); HardNet: trunk output (n,8192)
+    int dbg_layer;         // >= 0: dump activations after this trunk layer of patch 0 and exit
+    float* dbg_out;
+};
+
+template <int CB>
+struct TrunkLds {
+    static constexpr int ACT = CB * PST32;
+    static constexpr int PATCH = WP32 * WP32;
+    static constexpr int TOTAL = ACT + PATCH + 64;
+};
+
+template <int C, int H, int PST>
+__device__ __forceinline__ void dump_planes(const float* act, float* dst) {
+    constexpr int WP = H + 2;
+    for (int i = threadIdx.x; i < C * H * H; i += CNN_THREADS) {
+        const int c = i / (H * H), r = i - c * H * H, y = r / H, x = r - y * H;
+        dst[i] = act[c * PST + (y + 1) * WP + x + 1];
+    }
+}
+
+// KIND: 0 AffNet, 1 OriNet, 2 HardNet.  CB = 16 for KIND 0/1, 32 for KIND 2.
+template <int KIND>
+__global__ __launch_bounds__(CNN_THREADS, (KIND == AFFNET_NET_HARDNET) ? 2 : 4) void cnn32_trunk_kernel(CnnArgs a, PyrSrc ps) {
+    constexpr int CB = (KIND == AFFNET_NET_HARDNET) ? 32 : 16;
+    __shared__ __attribute__((aligned(16))) float lds[TrunkLds<CB>::TOTAL];
+    float* act = lds;
+    float* patch = lds + TrunkLds<CB>::ACT;
+    float* red = patch + TrunkLds<CB>::PATCH;
+    const int pidx = blockIdx.x;
+    const int n = a.count ? min(*a.count, a.n_max) : a.n_max;
+    if (pidx >= n) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+
+    // ---- input: load or sample 1024 pixels (2 per thread), standardise, store padded --------------
+    float v0, v1;
+    if (a.patches) {
+        const float* src = a.patches + (size_t)pidx * 1024;
+        v0 = src[tid]; v1 = src[tid + 512];
+    } else {
+        int o = a.ids[3 * pidx], l = a.ids[3 * pidx + 1];
+        o = o < 0 ? 0 : (o >= ps.n_octaves ? ps.n_octaves - 1 : o);
+        l = l < 0 ? 0 : (l >= ps.n_levels ? ps.n_levels - 1 : l);
+        const float* img = ps.lvl[o][l];
+        const int h = ps.h[o], w = ps.w[o];
+        const float* L = a.lafs + 6 * (size_t)pidx;
+        const float m = (float)(h < w ? h : w);
+        const float t00 = L[0] * m, t01 = L[1] * m, t02 = L[2] * (float)w;
+        const float t10 = L[3] * m, t11 = L[4] * m, t12 = L[5] * (float)h;
+        v0 = aff_sample_bilinear(img, h, w, t00, t01, t02, t10, t11, t12, ps.base[tid & 31], ps.base[tid >> 5]);
+        v1 = aff_sample_bilinear(img, h, w, t00, t01, t02, t10, t11, t12, ps.base[tid & 31], ps.base[(tid >> 5) + 16]);
+    }
+    for (int i = tid; i < WP32 * WP32; i += CNN_THREADS) patch[i] = 0.0f;   // halo (interior overwritten below)
+    const float mean = block_sum(v0 + v1, red) * (1.0f / 1024.0f);
+    const float d0 = v0 - mean, d1 = v1 - mean;
+    const float var = block_sum(d0 * d0 + d1 * d1, red) * (1.0f / 1023.0f);    // torch.std: unbiased
+    const float sd = sqrtf(var) + 1e-7f;
+    patch[((tid >> 5) + 1) * WP32 + (tid & 31) + 1] = d0 / sd;
+    patch[((tid >> 5) + 17) * WP32 + (tid & 31) + 1] = d1 / sd;
+    zero_halo<32, PST32>(act, CB);
+    __syncthreads();
+
+    // ---- conv0: 1 -> CB, K = 9, VALU ---------------------------------------------------------------
+    {
+        const float* w0 = a.packed + a.off.w[0];
+        const float* b0 = a.packed + a.off.b[0];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int y = (tid >> 5) + 16 * half, x = tid & 31;
+            float q[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) q[t] = patch[(y + t / 3) * WP32 + x + t % 3];
+#pragma unroll 4
+            for (int c = 0; c < CB; ++c) {
+                float s = b0[c];
+#pragma unroll
+                for (int t = 0; t < 9; ++t) s = fmaf(q[t], w0[c * 9 + t], s);
+                act[c * PST32 + (y + 1) * WP32 + x + 1] = fmaxf(s, 0.0f);
+            }
+        }
+    }
+    __syncthreads();
+    if (a.dbg_layer == 0) { dump_planes<CB, 32, PST32>(act, a.dbg_out); return; }
+
+    // ---- conv1: CB -> CB @32x32 --------------------------------------------------------------------
+    {
+        constexpr int TN = CB / 16;
+        f32x4 acc[8][TN];
+        conv3x3_mfma<CB, CB, 32, 1, 8, TN, PST32, WP32, 4>(act, a.packed + a.off.w[1], acc, wave, lane);
+        __syncthreads();
+        store_tiles_lds<CB, 32, 8, TN, PST32>(act, a.packed + a.off.b[1], acc, wave, lane);   // halo already zero
+        __syncthreads();
+    }
+    if (a.dbg_layer == 1) { dump_planes<CB, 32, PST32>(act, a.dbg_out); return; }
+
+    // ---- conv2: CB -> 2CB, stride 2 @16x16 -----------------------------------------------------------
+    {
+        constexpr int TM = CB / 8, TN = 2;              // 16: 2x2 (MG 8, NG 1) ; 32: 4x2 (MG 4, NG 2)
+        f32x4 acc[TM][TN];
+        conv3x3_mfma<CB, 2 * CB, 16, 2, TM, TN, PST32, WP32, 4>(act, a.packed + a.off.w[2], acc, wave, lane);
+        __syncthreads();
+        zero_halo<16, PST16>(act, 2 * CB);
+        store_tiles_lds<2 * CB, 16, TM, TN, PST16>(act, a.packed + a.off.b[2], acc, wave, lane);
+        __syncthreads();
+    }
+    if (a.dbg_layer == 2) { dump_planes<2 * CB, 16, PST16>(act, a.dbg_out); return; }
+
+    // ---- conv3: 2CB -> 2CB @16x16 --------------------------------------------------------------------
+    {
+        constexpr int TM = CB / 8, TN = 2;
+        f32x4 acc[TM][TN];
+        conv3x3_mfma<2 * CB, 2 * CB, 16, 1, TM, TN, PST16, WP16, 8>(act, a.packed + a.off.w[3], acc, wave, lane);
+        __syncthreads();
+        store_tiles_lds<2 * CB, 16, TM, TN, PST16>(act, a.packed + a.off.b[3], acc, wave, lane);
+        __syncthreads();
+    }
+    if (a.dbg_layer == 3) { dump_planes<2 * CB, 16, PST16>(act, a.dbg_out); return; }
+
+    // ---- conv4: 2CB -> 4CB, stride 2 @8x8 --------------------------------------------------------------
+    {
+        constexpr int TM = CB / 8, TN = 1;              // 16: 2x1 (MG 2, NG 4) ; 32: 4x1 (MG 1, NG 8)
+        f32x4 acc[TM][TN];
+        conv3x3_mfma<2 * CB, 4 * CB, 8, 2, TM, TN, PST16, WP16, 8>(act, a.packed + a.off.w[4], acc, wave, lane);
+        __syncthreads();
+        zero_halo<8, PST8>(act, 4 * CB);
+        store_tiles_lds<4 * CB, 8, TM, TN, PST8>(act, a.packed + a.off.b[4], acc, wave, lane);
+        __syncthreads();
+    }
+    if (a.dbg_layer == 4) { dump_planes<4 * CB, 8, PST8>(act, a.dbg_out); return; }
+
+    // ---- conv5: 4CB -> 4CB @8x8 ------------------------------------------------------------------------
+    {
+        constexpr int TM = CB / 8, TN = 1;
+        f32x4 acc[TM][TN];
+        conv3x3_mfma<4 * CB, 4 * CB, 8, 1, TM, TN, PST8, WP8, 8>(act, a.packed + a.off.w[5], acc, wave, lane);
+        if (KIND == AFFNET_NET_HARDNET && a.dbg_layer < 0) {
+            store_tiles_global<4 * CB, TM, TN>(a.out + (size_t)pidx * HEAD_K, a.packed + a.off.b[5], acc, wave, lane);
+            return;
+        }
+        __syncthreads();
+        store_tiles_lds<4 * CB, 8, TM, TN, PST8>(act, a.packed + a.off.b[5], acc, wave, lane);
+        __syncthreads();
+    }
+    if (a.dbg_layer == 5) { dump_planes<4 * CB, 8, PST8>(act, a.dbg_out); return; }
+
+    // ---- heads (AffNet / OriNet), VALU -----------------------------------------------------------------
+    if (KIND == AFFNET_NET_AFFNET) {
+        // conv 64 -> 3, 8x8 valid, + bias -> tanh -> [[1+x0, 0],[x1, 1+x2]] -> up-is-up rectification
+        const float* hw = a.packed + a.off.head_w;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int e = tid; e < 4096; e += CNN_THREADS) {
+            const int c = e >> 6, y = (e >> 3) & 7, x = e & 7;
+            const float v = act[c * PST8 + (y + 1) * WP8 + x + 1];
+            s0 = fmaf(v, hw[e], s0); s1 = fmaf(v, hw[4096 + e], s1); s2 = fmaf(v, hw[8192 + e], s2);
+        }
+        s0 = block_sum(s0, red); s1 = block_sum(s1, red); s2 = block_sum(s2, red);
+        if (tid == 0) {
+            const float* hb = a.packed + a.off.head_b;
+            const float x0 = tanhf(s0 + hb[0]), x1 = tanhf(s1 + hb[1]), x2 = tanhf(s2 + hb[2]);
+            const float a00 = 1.0f + x0, a01 = 0.0f * x0, a10 = x1, a11 = 1.0f + x2;
+            // rectifyAffineTransformationUpIsUp (LAF.py:285-291)
+            const float det = sqrtf(fabsf(a00 * a11 - a10 * a01 + 1e-10f));
+            const float b2a2 = sqrtf(a01 * a01 + a00 * a00);
+            float* o = a.out + 4 * (size_t)pidx;
+            o[0] = b2a2 / det; o[1] = 0.0f * det;
+            o[2] = (a11 * a01 + a10 * a00) / (b2a2 * det); o[3] = det / b2a2;
+        }
+    } else if (KIND == AFFNET_NET_ORINET) {
+        // conv 64 -> 2, 8x8, padding 1 (= our zero halo) -> 3x3 -> tanh -> mean -> atan2 -> rotation
+        const float* hw = a.packed + a.off.head_w;
+        float s[2][9];
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int q = 0; q < 9; ++q) s[o][q] = 0.f;
+        for (int e = tid; e < 4096; e += CNN_THREADS) {
+            const int c = e >> 6, ky = (e >> 3) & 7, kx = e & 7;
+            const float w0 = hw[e], w1 = hw[4096 + e];
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                const float v = act[c * PST8 + (q / 3 + ky) * WP8 + (q % 3) + kx];
+                s[0][q] = fmaf(v, w0, s[0][q]); s[1][q] = fmaf(v, w1, s[1][q]);
+            }
+        }
+        float t0 = 0.f, t1 = 0.f;
+        const float* hb = a.packed + a.off.head_b;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const float r0 = block_sum(s[0][q], red), r1 = block_sum(s[1][q], red);
+            t0 += tanhf(r0 + hb[0]); t1 += tanhf(r1 + hb[1]);
+        }
+        if (tid == 0) {
+            const float yv = t0 / 9.0f, xv = t1 / 9.0f;                       // AdaptiveAvgPool2d(1)
+            const float ang = atan2f(yv + 1e-8f, xv + 1e-8f);                 // architectures.py:78
+            const float sn = sinf(ang), cs = cosf(ang);
+            float* o = a.out + 4 * (size_t)pidx;
+            o[0] = cs; o[1] = sn; o[2] = -sn; o[3] = cs;                      // LAF.py:276-283
+        }
+    }
+}
+
+// ---- HardNet head: (n x 8192) x (8192 x 128) GEMM + BN bias + L2 normalisation ----------------------
+// One workgroup = 256 threads = 16 patches x 128 outputs; wave w owns N-tiles 2w, 2w+1.  The A tile
+// (16 x KC) is staged through LDS with coalesced 16-byte loads; B streams from L2.
+#define HEAD_KC 256
+#define HEAD_AS (HEAD_KC + 1)
+__global__ __launch_bounds__(256) void hardnet_head_kernel(const float* __restrict__ trunk, const float* __restrict__ Bw,
+                                                           const float* __restrict__ bias, const int32_t* __restrict__ count, int n_max,
+                                                           float* __restrict__ out) {
+    __shared__ float As[16 * HEAD_AS];
+    __shared__ float nrm[4][16];
+    const int n = count ? min(*count, n_max) : n_max;
+    const int p0 = blockIdx.x * 16;
+    if (p0 >= n) return;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int m = lane & 15, kq = lane >> 4;
+    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+    for (int k0 = 0; k0 < HEAD_K; k0 += HEAD_KC) {
+        __syncthreads();
+        // stage 16 x 256 floats: 1024 float4, 4 per thread
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int f = tid + 256 * r;            // float4 index
+            const int row = f >> 6, c4 = f & 63;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p0 + row < n) v = *reinterpret_cast<const float4*>(trunk + (size_t)(p0 + row) * HEAD_K + k0 + 4 * c4);
+            float* d = &As[row * HEAD_AS + 4 * c4];
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+        const float* bptr = Bw + (size_t)(k0 + kq) * 128 + wave * 32 + m;
+#pragma unroll 8
+        for (int kk = 0; kk < HEAD_KC; kk += 4) {
+            const float av = As[m * HEAD_AS + kk + kq];
+            const float b0 = bptr[(size_t)kk * 128], b1 = bptr[(size_t)kk * 128 + 16];
+            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[0], 0, 0, 0);
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc[1], 0, 0, 0);
+        }
+    }
+    // acc[j][r]: patch row 4*(lane>>4)+r, channel wave*32 + 16*j + (lane&15)
+    const int g = lane >> 4;
+    const float bv0 = bias[wave * 32 + m], bv1 = bias[wave * 32 + 16 + m];
+    float val[2][4], ss[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        val[0][r] = acc[0][r] + bv0; val[1][r] = acc[1][r] + bv1;
+        ss[r] = val[0][r] * val[0][r] + val[1][r] * val[1][r];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) ss[r] += __shfl_xor(ss[r], o, 64);   // over the 16 lanes sharing g
+    }
+    if (m == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) nrm[wave][4 * g + r] = ss[r];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = 4 * g + r;
+        if (p0 + row >= n) continue;
+        const float tot = (nrm[0][row] + nrm[1][row]) + (nrm[2][row] + nrm[3][row]);
+        const float inv = sqrtf(tot + 1e-8f);                                  // L2Norm eps 1e-8 (HardNet.py:15-18)
+        float* o = out + (size_t)(p0 + row) * 128 + wave * 32 + m;
+        o[0] = val[0][r] / inv; o[16] = val[1][r] / inv;
+    }
+}
+
+// ---- host entry points -------------------------------------------------------------------------------
+void aff_fill_pyr_src(const affnet_ctx* ctx, PyrSrc* t) {
+    memset(t, 0, sizeof(*t));
+    if (ctx->ws) {
+        t->n_octaves = ctx->cfg.n_octaves; t->n_levels = ctx->cfg.levels_per_octave;
+        for (int o = 0; o < t->n_octaves; ++o) {
+            const OctaveGeom& g = ctx->oct[o];
+            t->h[o] = g.h; t->w[o] = g.w;
+            for (int l = 0; l < t->n_levels; ++l) t->lvl[o][l] = ctx->pyr + g.pyr_off + (size_t)l * g.h * g.w;
+        }
+    }
+    aff_base_grid(32, t->base);
+}
+
+static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const float* patches, const float* lafs, const int32_t* ids,
+                      const int32_t* count, int n_max, float* out, float* scratch, int dbg_layer, float* dbg_out, hipStream_t st) {
+    if (kind < 0 || kind > 2) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: unknown net kind %d", kind);
+    if (!packed || !out || n_max < 0 || (!patches && (!lafs || !ids))) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: null argument");
+    if (!patches && !ctx->ws) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: sampling from the pyramid needs a bound workspace");
+    if (kind == AFFNET_NET_HARDNET && dbg_layer < 0 && !scratch) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: HardNet needs d_scratch (n*8192 floats)");
+    if (n_max == 0) return AFFNET_OK;
+    const NetLayout L = net_layout(kind);
+    CnnArgs a;
+    a.packed = packed; a.off = to_offsets(L); a.patches = patches; a.lafs = lafs; a.ids = ids; a.count = count; a.n_max = n_max;
+    a.out = (kind == AFFNET_NET_HARDNET) ? scratch : out;
+    a.dbg_layer = dbg_layer; a.dbg_out = dbg_out;
+    PyrSrc ps;
+    aff_fill_pyr_src(ctx, &ps);
+    const dim3 grid(n_max), block(CNN_THREADS);
+    if (kind == AFFNET_NET_AFFNET) hipLaunchKernelGGL(cnn32_trunk_kernel<AFFNET_NET_AFFNET>, grid, block, 0, st, a, ps);
+    else if (kind == AFFNET_NET_ORINET) hipLaunchKernelGGL(cnn32_trunk_kernel<AFFNET_NET_ORINET>, grid, block, 0, st, a, ps);
+    else hipLaunchKernelGGL(cnn32_trunk_kernel<AFFNET_NET_HARDNET>, grid, block, 0, st, a, ps);
+    AFF_LAUNCH_CHECK(ctx);
+    if (kind == AFFNET_NET_HARDNET && dbg_layer < 0) {
+        hipLaunchKernelGGL(hardnet_head_kernel, dim3(aff_cdiv(n_max, 16)), dim3(256), 0, st, scratch, packed + L.head_w, packed + L.head_b,
+                           count, n_max, out);
+        AFF_LAUNCH_CHECK(ctx);
+    }
+    return AFFNET_OK;
+}
+
+extern "C" int affnet_cnn32_forward(affnet_ctx* ctx, int net_kind, const float* d_packed, const float* d_patches, const int32_t* d_count,
+                                    int n_max, float* d_out, float* d_scratch, void* stream) {
+    if (!ctx || !d_patches) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32_forward: null argument");
+    return cnn_launch(ctx, net_kind, d_packed, d_patches, nullptr, nullptr, d_count, n_max, d_out, d_scratch, -1, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int affnet_cnn32_forward_pyr(affnet_ctx* ctx, int net_kind, const float* d_packed, const float* d_lafs, const int32_t* d_ids,
+                                        const int32_t* d_count, int n_max, float* d_out, float* d_scratch, void* stream) {
+    if (!ctx) return AFFNET_ERR_INVALID;
+    return cnn_launch(ctx, net_kind, d_packed, nullptr, d_lafs, d_ids, d_count, n_max, d_out, d_scratch, -1, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int affnet_cnn32_debug_layer(affnet_ctx* ctx, int net_kind, const float* d_packed, const float* d_patch, int layer, float* d_out,
+                                        void* stream) {
+    if (!ctx || !d_patch || !d_out || layer < 0 || layer > 5) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32_debug_layer: bad argument");
+    return cnn_launch(ctx, net_kind, d_packed, d_patch, nullptr, nullptr, nullptr, 1, d_out, nullptr, layer, d_out, (hipStream_t)stream);
+}
+
+// ---- MFMA layout self-test ------------------------------------------------------------------------------
+__global__ void mfma_selftest_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ out) {
+    const int lane = threadIdx.x, m = lane & 15, kq = lane >> 4;
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(A[m * 4 + kq], B[kq * 16 + m], c, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) out[(4 * kq + r) * 16 + m] = c[r];
+}
+
+extern "C" int affnet_selftest_mfma(const float* d_A, const float* d_B, float* d_out, void* stream) {
+    if (!d_A || !d_B || !d_out) return AFFNET_ERR_INVALID;
+    hipLaunchKernelGGL(mfma_selftest_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_A, d_B, d_out);
+    return hipGetLastError() == hipSuccess ? AFFNET_OK : AFFNET_ERR_HIP;
+}

@@ -1,0 +1,132 @@
+// Shared host/device declarations of libaffnet_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/affnet_hip.h"
+
+#define AFF_WAVE 64
+
+// Counter block kept at the start of the workspace "lists" area (int32 each).
+enum {
+    CNT_RAW0 = 0,                            // CNT_RAW0 + o : raw maxima of octave o
+    CNT_CAND = AFFNET_MAX_OCTAVES,           // accepted candidates (all octaves)
+    CNT_OVERFLOW,                            // != 0 : some fixed-capacity list overflowed
+    CNT_SEL,                                 // rows selected by the global top-k
+    CNT_EQ_TAKEN,                            // ties at the threshold already taken
+    CNT_SEL_MODE,                            // 1 = top-k (descending response), 0 = keep all (key order)
+    CNT_SEL_THRESH,                          // order-preserving uint key of the C-th largest response
+    CNT_SEL_NEED_EQ,                         // how many keys == threshold to take
+    CNT_DET,                                 // rows emitted by the detector
+    CNT_SHAPED,                              // rows after the shape filter
+    CNT_SURVIVED,                            // survivors of the shape filter before top-N
+    CNT_TOTAL = AFFNET_MAX_OCTAVES + 16
+};
+
+struct RawMax {            // one 3-D local maximum found by hessian_nms_kernel
+    int32_t pix;           // flat pixel index y*w+x in the octave
+    int32_t lvl;           // detection level 1..nLevels
+    float val;             // NMS'ed (border-zeroed) response
+    float s, y, x;         // normalised centroid scale / row / column
+};
+
+struct OctaveGeom {
+    int32_t h, w;
+    int64_t pyr_off;       // float offset of level 0 inside the pyramid area
+    int64_t map_off;       // byte offset of the uint8 octaveMap
+    int64_t raw_off;       // RawMax offset of this octave's raw list
+    int32_t raw_cap;
+};
+
+struct affnet_ctx {
+    int device = 0;
+    affnet_config cfg;
+    std::string err;
+    OctaveGeom oct[AFFNET_MAX_OCTAVES];
+    // workspace layout (byte offsets from the workspace base)
+    size_t off_pyr = 0, off_map = 0, off_raw = 0, off_cnt = 0, off_cand = 0, off_sel = 0, off_stage = 0;
+    size_t ws_bytes = 0;
+    size_t pyr_floats = 0, map_bytes = 0, raw_total = 0, cand_cap = 0;
+    int cap_pre = 0, cap_final = 0;
+    char* ws = nullptr;
+    // convenience pointers into the workspace (valid after bind)
+    float* pyr = nullptr;
+    uint8_t* omap = nullptr;
+    RawMax* raw = nullptr;
+    int32_t* cnt = nullptr;
+    float* cand_resp = nullptr; float* cand_syx = nullptr; int32_t* cand_ids = nullptr;
+    float* sel_resp = nullptr; float* sel_syx = nullptr; int32_t* sel_ids = nullptr;
+    // pipeline stage buffers
+    float* st_det_resp = nullptr; float* st_det_lafs = nullptr; int32_t* st_det_ids = nullptr;
+    float* st_A = nullptr; float* st_key = nullptr; int32_t* st_good = nullptr;
+    float* st_R = nullptr; float* st_lafs_norm = nullptr; int32_t* st_lvl_ids = nullptr;
+    float* st_hard_scratch = nullptr;
+    float* st_lafs_shaped = nullptr;
+};
+
+int aff_fail(affnet_ctx* ctx, int code, const char* fmt, ...);
+
+#define AFF_HIP(ctx, expr)                                                                         \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return aff_fail(ctx, AFFNET_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                            __FILE__, __LINE__);                                                   \
+    } while (0)
+
+#define AFF_LAUNCH_CHECK(ctx)                                                                      \
+    do {                                                                                           \
+        hipError_t e_ = hipGetLastError();                                                         \
+        if (e_ != hipSuccess)                                                                      \
+            return aff_fail(ctx, AFFNET_ERR_HIP, "kernel launch failed: %s (%s:%d)",                \
+                            hipGetErrorString(e_), __FILE__, __LINE__);                            \
+    } while (0)
+
+static inline size_t aff_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
+static inline int aff_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- sampler math shared by sampler.hip and cnn32.hip -------------------------------------------
+// Host: fills base[ps] = (linspace(-1,1,ps) * (ps-1)) / ps exactly as torch does on CPU
+// (linspace = fma(step, i, start) / fma(-step, ps-1-i, end); verified bit-for-bit in
+// tests/test_host_mirror.py).
+void aff_base_grid(int ps, float* base);
+
+struct SampleGeom {        // per-level constants of the sampler
+    const float* img;
+    int h, w;
+};
+
+// Device: one bilinear sample.  Follows LAF.py:313-324 + F.affine_grid + F.grid_sample
+// (align_corners=False, zeros padding) operation by operation in fp32:
+//   theta = LAF * [[m,m,w],[m,m,h]];  g = fma(1,t02, fma(v,t01, u*t00));
+//   gn = 2*g/size - 1;  i = fma(gn+1, size/2, -0.5);  out = fma chain nw,ne,sw,se.
+__device__ __forceinline__ float aff_sample_bilinear(const float* __restrict__ img, int h, int w,
+                                                     float t00, float t01, float t02, float t10,
+                                                     float t11, float t12, float u, float v) {
+    float gx = fmaf(1.0f, t02, fmaf(v, t01, u * t00));
+    float gy = fmaf(1.0f, t12, fmaf(v, t11, u * t10));
+    const float fw = (float)w, fh = (float)h;
+    gx = 2.0f * gx / fw - 1.0f;
+    gy = 2.0f * gy / fh - 1.0f;
+    const float ix = fmaf(gx + 1.0f, fw * 0.5f, -0.5f);
+    const float iy = fmaf(gy + 1.0f, fh * 0.5f, -0.5f);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float x1f = x0f + 1.0f, y1f = y0f + 1.0f;
+    const float wx1 = ix - x0f, wx0 = x1f - ix, wy1 = iy - y0f, wy0 = y1f - iy;
+    const float nw = wx0 * wy0, ne = wx1 * wy0, sw = wx0 * wy1, se = wx1 * wy1;
+    // float -> int after range clamping so that huge coordinates cannot overflow
+    const float cx0 = fminf(fmaxf(x0f, -2.0f), fw + 1.0f), cy0 = fminf(fmaxf(y0f, -2.0f), fh + 1.0f);
+    const int x0 = (int)cx0, y0 = (int)cy0, x1 = x0 + 1, y1 = y0 + 1;
+    const bool xin0 = (x0 >= 0) & (x0 < w), xin1 = (x1 >= 0) & (x1 < w);
+    const bool yin0 = (y0 >= 0) & (y0 < h), yin1 = (y1 >= 0) & (y1 < h);
+    const float vnw = (xin0 & yin0) ? img[(size_t)y0 * w + x0] : 0.0f;
+    const float vne = (xin1 & yin0) ? img[(size_t)y0 * w + x1] : 0.0f;
+    const float vsw = (xin0 & yin1) ? img[(size_t)y1 * w + x0] : 0.0f;
+    const float vse = (xin1 & yin1) ? img[(size_t)y1 * w + x1] : 0.0f;
+    return fmaf(vse, se, fmaf(vsw, sw, fmaf(vne, ne, vnw * nw)));
+}

@@ -1,0 +1,157 @@
+// Context, workspace layout and small host helpers of libaffnet_hip.so.
+#include <stdarg.h>
+
+#include "common.h"
+
+int aff_fail(affnet_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+extern "C" const char* affnet_version(void) { return "affnet_hip 0.1 (gfx950, hipcc, fp32 MFMA 16x16x4)"; }
+
+extern "C" const char* affnet_last_error(const affnet_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+void aff_base_grid(int ps, float* base) {
+    // torch.linspace(-1, 1, ps) on CPU: step = (end-start)/(steps-1) in fp32; element i is
+    // fma(step, i, start) for i < steps/2 and fma(-step, steps-1-i, end) otherwise; then
+    // affine_grid (align_corners=False) multiplies by (ps-1) and divides by ps.
+    if (ps == 1) { base[0] = 0.0f; return; }  // linspace(-1,1,1) = [-1]; * 0 / 1 = -0 -> 0 contribution either way
+    const float step = 2.0f / (float)(ps - 1);
+    const int half = ps / 2;
+    for (int i = 0; i < ps; ++i) {
+        float v = (i < half) ? fmaf(step, (float)i, -1.0f) : fmaf(-step, (float)(ps - 1 - i), 1.0f);
+        base[i] = (v * (float)(ps - 1)) / (float)ps;
+    }
+}
+
+extern "C" int affnet_host_base_grid(int ps, float* out) {  // exported for the CPU-side mirror test
+    if (ps < 1 || !out) return AFFNET_ERR_INVALID;
+    aff_base_grid(ps, out);
+    return AFFNET_OK;
+}
+
+static int validate(affnet_ctx* ctx, const affnet_config* c) {
+    if (c->height < 8 || c->width < 8) return aff_fail(ctx, AFFNET_ERR_INVALID, "image %dx%d too small", c->height, c->width);
+    if (c->n_octaves < 1 || c->n_octaves > AFFNET_MAX_OCTAVES) return aff_fail(ctx, AFFNET_ERR_INVALID, "n_octaves=%d", c->n_octaves);
+    if (c->levels_per_octave < 3 || c->levels_per_octave > AFFNET_MAX_LEVELS)
+        return aff_fail(ctx, AFFNET_ERR_INVALID, "levels_per_octave=%d", c->levels_per_octave);
+    if (c->oct_h[0] != c->height || c->oct_w[0] != c->width) return aff_fail(ctx, AFFNET_ERR_INVALID, "octave 0 size mismatch");
+    for (int o = 1; o < c->n_octaves; ++o)
+        if (c->oct_h[o] != (c->oct_h[o - 1] - 1) / 2 + 1 || c->oct_w[o] != (c->oct_w[o - 1] - 1) / 2 + 1)
+            return aff_fail(ctx, AFFNET_ERR_INVALID, "octave %d size is not ceil(prev/2)", o);
+    if (c->first_blur_taps != 0 && (c->first_blur_taps % 2 == 0 || c->first_blur_taps > AFFNET_MAX_TAPS))
+        return aff_fail(ctx, AFFNET_ERR_INVALID, "first_blur_taps=%d", c->first_blur_taps);
+    for (int l = 1; l < c->levels_per_octave; ++l)
+        if (c->level_blur_taps[l] % 2 == 0 || c->level_blur_taps[l] < 1 || c->level_blur_taps[l] > AFFNET_MAX_TAPS)
+            return aff_fail(ctx, AFFNET_ERR_INVALID, "level_blur_taps[%d]=%d", l, c->level_blur_taps[l]);
+    return AFFNET_OK;
+}
+
+extern "C" int affnet_ctx_create(affnet_ctx** out, int device, const affnet_config* cfg) {
+    if (!out) return AFFNET_ERR_INVALID;
+    affnet_ctx* ctx = new affnet_ctx();
+    ctx->device = device;
+    if (!cfg) {  // utility context: stand-alone stage calls (blur, sampler, CNNs on patch tensors), no pyramid
+        memset(&ctx->cfg, 0, sizeof(ctx->cfg));
+        *out = ctx;
+        return AFFNET_OK;
+    }
+    ctx->cfg = *cfg;
+    int rc = validate(ctx, cfg);
+    if (rc != AFFNET_OK) { *out = ctx; return rc; }
+    const affnet_config& c = ctx->cfg;
+    const int div = c.max_raw_per_octave_div > 0 ? c.max_raw_per_octave_div : 4;
+    size_t pyr = 0, mapb = 0, raw = 0;
+    for (int o = 0; o < c.n_octaves; ++o) {
+        OctaveGeom& g = ctx->oct[o];
+        g.h = c.oct_h[o]; g.w = c.oct_w[o];
+        g.pyr_off = (int64_t)pyr; pyr += (size_t)c.levels_per_octave * g.h * g.w;
+        g.map_off = (int64_t)mapb; mapb += aff_align((size_t)g.h * g.w, 16);
+        int cap = (int)((size_t)g.h * g.w / div); if (cap < 256) cap = 256;
+        g.raw_off = (int64_t)raw; g.raw_cap = cap; raw += cap;
+    }
+    ctx->pyr_floats = pyr; ctx->map_bytes = mapb; ctx->raw_total = raw; ctx->cand_cap = raw;
+    const int keep = c.max_keep > 0 ? c.max_keep : 65536;
+    ctx->cap_pre = c.num_prefilter > 0 ? c.num_prefilter : keep;
+    ctx->cap_final = c.num_features > 0 ? c.num_features : ctx->cap_pre;
+    if (ctx->cap_final > ctx->cap_pre) ctx->cap_final = ctx->cap_pre;
+    size_t off = 0;
+    ctx->off_pyr = off; off += aff_align(pyr * sizeof(float));
+    ctx->off_map = off; off += aff_align(mapb);
+    ctx->off_raw = off; off += aff_align(raw * sizeof(RawMax));
+    ctx->off_cnt = off; off += aff_align(CNT_TOTAL * sizeof(int32_t));
+    ctx->off_cand = off; off += aff_align(ctx->cand_cap * 7 * sizeof(float));   // resp + syx[3] + ids[3]
+    ctx->off_sel = off; off += aff_align((size_t)ctx->cap_pre * 7 * sizeof(float));
+    ctx->off_stage = off;
+    const size_t P = (size_t)ctx->cap_pre, F = (size_t)ctx->cap_final;
+    off += aff_align(P * 10 * sizeof(float));          // det resp(1) + lafs(6) + ids(3)
+    off += aff_align(P * 4 * sizeof(float));           // A
+    off += aff_align(P * 2 * sizeof(float));           // key, good
+    off += aff_align(F * 6 * sizeof(float));           // shaped lafs (normalised)
+    off += aff_align(F * 4 * sizeof(float));           // R
+    off += aff_align(F * 9 * sizeof(float));           // lafs_norm(6) + lvl ids(3)
+    off += aff_align(F * 8192 * sizeof(float));        // HardNet trunk output
+    ctx->ws_bytes = off;
+    *out = ctx;
+    return AFFNET_OK;
+}
+
+extern "C" void affnet_ctx_destroy(affnet_ctx* ctx) { delete ctx; }
+
+extern "C" size_t affnet_workspace_bytes(const affnet_ctx* ctx) { return ctx ? ctx->ws_bytes : 0; }
+
+extern "C" int affnet_capacity_prefilter(const affnet_ctx* ctx) { return ctx ? ctx->cap_pre : 0; }
+extern "C" int affnet_capacity_final(const affnet_ctx* ctx) { return ctx ? ctx->cap_final : 0; }
+
+extern "C" int64_t affnet_pyramid_level_offset(const affnet_ctx* ctx, int octave, int level) {
+    if (!ctx || octave < 0 || octave >= ctx->cfg.n_octaves || level < 0 || level >= ctx->cfg.levels_per_octave) return -1;
+    const OctaveGeom& g = ctx->oct[octave];
+    return (int64_t)(ctx->off_pyr / sizeof(float)) + g.pyr_off + (int64_t)level * g.h * g.w;
+}
+
+extern "C" int affnet_bind_workspace(affnet_ctx* ctx, void* d_workspace, size_t bytes) {
+    if (!ctx) return AFFNET_ERR_INVALID;
+    if (!d_workspace || bytes < ctx->ws_bytes)
+        return aff_fail(ctx, AFFNET_ERR_INVALID, "workspace too small: %zu < %zu", bytes, ctx->ws_bytes);
+    if (((uintptr_t)d_workspace & 255) != 0) return aff_fail(ctx, AFFNET_ERR_INVALID, "workspace must be 256-byte aligned");
+    char* b = (char*)d_workspace;
+    ctx->ws = b;
+    ctx->pyr = (float*)(b + ctx->off_pyr);
+    ctx->omap = (uint8_t*)(b + ctx->off_map);
+    ctx->raw = (RawMax*)(b + ctx->off_raw);
+    ctx->cnt = (int32_t*)(b + ctx->off_cnt);
+    float* cand = (float*)(b + ctx->off_cand);
+    ctx->cand_resp = cand; ctx->cand_syx = cand + ctx->cand_cap; ctx->cand_ids = (int32_t*)(cand + 4 * ctx->cand_cap);
+    float* sel = (float*)(b + ctx->off_sel);
+    const size_t P = (size_t)ctx->cap_pre, F = (size_t)ctx->cap_final;
+    ctx->sel_resp = sel; ctx->sel_syx = sel + P; ctx->sel_ids = (int32_t*)(sel + 4 * P);
+    char* s = b + ctx->off_stage;
+    ctx->st_det_resp = (float*)s; ctx->st_det_lafs = (float*)s + P; ctx->st_det_ids = (int32_t*)((float*)s + 7 * P);
+    s += aff_align(P * 10 * sizeof(float));
+    ctx->st_A = (float*)s; s += aff_align(P * 4 * sizeof(float));
+    ctx->st_key = (float*)s; ctx->st_good = (int32_t*)((float*)s + P); s += aff_align(P * 2 * sizeof(float));
+    ctx->st_lafs_shaped = (float*)s; s += aff_align(F * 6 * sizeof(float));
+    ctx->st_R = (float*)s; s += aff_align(F * 4 * sizeof(float));
+    ctx->st_lafs_norm = (float*)s; ctx->st_lvl_ids = (int32_t*)((float*)s + 6 * F); s += aff_align(F * 9 * sizeof(float));
+    ctx->st_hard_scratch = (float*)s;
+    return AFFNET_OK;
+}
+
+extern "C" int affnet_read_counts(affnet_ctx* ctx, int32_t out[4], void* stream) {
+    if (!ctx || !ctx->ws) return AFFNET_ERR_INVALID;
+    int32_t host[CNT_TOTAL];
+    AFF_HIP(ctx, hipMemcpyAsync(host, ctx->cnt, sizeof(host), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    AFF_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
+    out[0] = host[CNT_DET]; out[1] = host[CNT_SHAPED]; out[2] = host[CNT_OVERFLOW];
+    int raw = 0;
+    for (int o = 0; o < ctx->cfg.n_octaves; ++o) raw += host[CNT_RAW0 + o];
+    out[3] = raw;
+    if (host[CNT_OVERFLOW]) return aff_fail(ctx, AFFNET_ERR_CAPACITY, "a fixed-capacity detector list overflowed (flag %d)", host[CNT_OVERFLOW]);
+    return AFFNET_OK;
+}

@@ -1,0 +1,405 @@
+// Hessian scale-space detector for gfx950: response + 3-D NMS + octaveMap + centroid + top-k.
+//
+// Replaces SparseImgRepresenter.py:53-111,198 (multiScaleDetector, x mrSize),
+// HandCraftedModules.py:58-78 (HessianResp), :208-291 (NMS3d, NMS3dAndComposeA),
+// Utils.py:116-148 (grids, zero_response_at_border), LAF.py:431-441 (sc_y_x2LAFs).
+//
+// Structure (per image):
+//   1. hessian_nms_kernel, one launch per octave: a workgroup stages a 64x16 tile (+2 halo) of
+//      all five blurred levels in LDS, computes the five Hessian response tiles (+1 halo) into
+//      LDS - they never touch HBM - runs the 3x3x3 NMS for the three detection levels and
+//      appends every surviving maximum (with its 27-tap response-weighted centroid) to a
+//      per-octave raw list.  The reference instead materialises 30 response maps, runs
+//      max_pool3d, two whole-map 3->3 channel convolutions and a top-k over H*W per level.
+//   2. octave_resolve_kernel, one workgroup per octave: replays the reference's sequential
+//      level loop on the sparse raw list: v = nms * (1 - float(octaveMap)), the `<= 1 positive`
+//      skip rule, octaveMap = uint8(int64(float(octaveMap) + v)) (mod-256 wrap emulated,
+//      HandCraftedModules.py:248-256) and emits accepted candidates (v != 0).
+//   3. select_*: global top-C.  Taking top-C per level and then top-C of the union
+//      (reference) selects the same set as one top-C over all candidates, so the per-level
+//      top-k is skipped; a radix select finds the C-th largest response, a rank sort orders the
+//      survivors (descending response, or (octave, level, pixel) order when nothing is cut).
+//
+// Arithmetic is the reference's fp32 sequence exactly (compiled with -ffp-contract=off):
+// gxx = (l - 2c) + r, gxy from replicate-padded gx, |gxx*gyy - gxy*gxy| * float32(sigma^4),
+// keep iff (c - max27) + 1e-5f > 0, centroid sums as fmaf chains in (level, ky, kx) order.
+#include <math.h>
+
+#include "common.h"
+
+#define HT_X 64
+#define HT_Y 16
+#define HX_W (HT_X + 4)   // blurred tile with 2-px halo
+#define HX_H (HT_Y + 4)
+#define HR_W (HT_X + 2)   // response tile with 1-px halo
+#define HR_H (HT_Y + 2)
+#define HR_S (HR_W + 1)   // padded row stride
+
+struct HessParams {
+    const float* levels;   // 5 blurred levels of this octave, contiguous
+    int h, w, n_levels;    // n_levels = levels_per_octave (5)
+    float sigma[AFFNET_MAX_LEVELS];
+    float sigma4[AFFNET_MAX_LEVELS];
+    float th;
+    int border;            // int(mrSize)
+    RawMax* raw;
+    int raw_cap;
+    int32_t* raw_cnt;
+    int32_t* overflow;
+};
+
+__device__ __forceinline__ float hessian_at(const float* __restrict__ X, int ty, int tx, float s4, float th) {
+    // X: blurred tile, row stride HX_W; (ty,tx) centre in tile coordinates (>= 1 from each edge)
+    const float c = X[ty * HX_W + tx];
+    const float gxx = (X[ty * HX_W + tx - 1] - 2.0f * c) + X[ty * HX_W + tx + 1];
+    const float gyy = (X[(ty - 1) * HX_W + tx] - 2.0f * c) + X[(ty + 1) * HX_W + tx];
+    const float gx_up = 0.5f * X[(ty - 1) * HX_W + tx - 1] - 0.5f * X[(ty - 1) * HX_W + tx + 1];
+    const float gx_dn = 0.5f * X[(ty + 1) * HX_W + tx - 1] - 0.5f * X[(ty + 1) * HX_W + tx + 1];
+    const float gxy = 0.5f * gx_up - 0.5f * gx_dn;
+    const float t1 = gxx * gyy;
+    const float t2 = gxy * gxy;
+    const float r = fabsf(t1 - t2) * s4;
+    return fmaxf(r - th, 0.0f);
+}
+
+__global__ __launch_bounds__(256) void hessian_nms_kernel(HessParams p) {
+    // LDS: 5 blurred tiles (20x68) + 5 response tiles (18x67)
+    __shared__ float X[AFFNET_MAX_LEVELS > 5 ? 5 : 5][HX_H * HX_W];
+    __shared__ float Rr[5][HR_H * HR_S];
+    const int h = p.h, w = p.w;
+    const int x0 = blockIdx.x * HT_X, y0 = blockIdx.y * HT_Y;
+    const size_t lvl_stride = (size_t)h * w;
+    for (int l = 0; l < 5; ++l) {
+        const float* src = p.levels + l * lvl_stride;
+        for (int i = threadIdx.x; i < HX_H * HX_W; i += 256) {
+            const int ty = i / HX_W, tx = i - ty * HX_W;
+            int gy = y0 + ty - 2, gx = x0 + tx - 2;
+            gy = gy < 0 ? 0 : (gy >= h ? h - 1 : gy);   // replicate padding of the Hessian filters
+            gx = gx < 0 ? 0 : (gx >= w ? w - 1 : gx);
+            X[l][i] = src[(size_t)gy * w + gx];
+        }
+    }
+    __syncthreads();
+    for (int l = 0; l < 5; ++l) {
+        const float s4 = p.sigma4[l];
+        for (int i = threadIdx.x; i < HR_H * HR_W; i += 256) {
+            const int ry = i / HR_W, rx = i - ry * HR_W;
+            const int gy = y0 + ry - 1, gx = x0 + rx - 1;
+            float r = -INFINITY;                       // outside the image: -inf for max_pool3d padding
+            if (gy >= 0 && gy < h && gx >= 0 && gx < w) r = hessian_at(X[l], ry + 1, rx + 1, s4, p.th);
+            Rr[l][ry * HR_S + rx] = r;
+        }
+    }
+    __syncthreads();
+    const bool border_ok = (p.border < w) && (p.border < h);
+    // each thread: 4 pixels of one row
+    const int ty = threadIdx.x >> 4, txb = (threadIdx.x & 15) * 4;
+    const int gy = y0 + ty;
+    if (gy >= h) return;
+#pragma unroll 1
+    for (int q = 0; q < 4; ++q) {
+        const int tx = txb + q, gx = x0 + tx;
+        if (gx >= w) break;
+        const bool in_border = !border_ok || gy < p.border || gy >= h - p.border || gx < p.border || gx >= w - p.border;
+        if (in_border) continue;                      // zero_response_at_border -> nms value 0 -> never a candidate
+        // column maxima over the 3x3 spatial window of each of the 5 response levels are shared by the 3 NMS levels
+        float m5[5];
+#pragma unroll
+        for (int l = 0; l < 5; ++l) {
+            const float* r = &Rr[l][ty * HR_S + tx];  // top-left of the 3x3 window (response tile has 1-px halo)
+            float m = fmaxf(fmaxf(r[0], r[1]), r[2]);
+            m = fmaxf(m, fmaxf(fmaxf(r[HR_S], r[HR_S + 1]), r[HR_S + 2]));
+            m = fmaxf(m, fmaxf(fmaxf(r[2 * HR_S], r[2 * HR_S + 1]), r[2 * HR_S + 2]));
+            m5[l] = m;
+        }
+#pragma unroll
+        for (int l = 1; l <= 3; ++l) {
+            const float c = Rr[l][(ty + 1) * HR_S + tx + 1];
+            const float M = fmaxf(fmaxf(m5[l - 1], m5[l]), m5[l + 1]);
+            const float d = c - M;
+            const float e = d + 1e-5f;
+            if (!(e > 0.0f) || c == 0.0f) continue;    // keep * x == 0 -> contributes nothing anywhere
+            // 27-tap centroid on the UNMASKED responses, zero padding (HandCraftedModules.py:279)
+            float ns = 0.f, ny = 0.f, nx = 0.f, den = 0.f;
+#pragma unroll
+            for (int dl = 0; dl < 3; ++dl) {
+                const float sg = p.sigma[l - 1 + dl];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const float oy = (ky == 0) ? -0.5f : (ky == 1 ? 0.5f : 1.5f);
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const float ox = (kx == 0) ? -0.5f : (kx == 1 ? 0.5f : 1.5f);
+                        float r = Rr[l - 1 + dl][(ty + ky) * HR_S + tx + kx];
+                        if (r == -INFINITY) r = 0.0f;  // conv2d zero padding
+                        ns = fmaf(r, sg, ns);
+                        ny = fmaf(r, oy, ny);
+                        nx = fmaf(r, ox, nx);
+                        den = fmaf(r, 1.0f, den);
+                    }
+                }
+            }
+            const float dd = den + 1e-8f;
+            float cs = ns / dd, cy = ny / dd, cx = nx / dd;
+            cy = cy + (float)gy;
+            cx = cx + (float)gx;
+            const float msz = (float)(h < w ? h : w);
+            RawMax rm;
+            rm.pix = gy * w + gx;
+            rm.lvl = l;
+            rm.val = c;
+            rm.s = cs / msz;
+            rm.y = cy / (float)h;
+            rm.x = cx / (float)w;
+            const int slot = atomicAdd(p.raw_cnt, 1);
+            if (slot < p.raw_cap) p.raw[slot] = rm;
+            else atomicOr(p.overflow, 1);
+        }
+    }
+}
+
+// ---- standalone Hessian response (RespNet slot / tests) -------------------------------------------
+__global__ __launch_bounds__(256) void hessian_resp_kernel(const float* __restrict__ in, float* __restrict__ out, int h, int w,
+                                                          float s4) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const int xm = x > 0 ? x - 1 : 0, xp = x < w - 1 ? x + 1 : w - 1;
+    const int ym = y > 0 ? y - 1 : 0, yp = y < h - 1 ? y + 1 : h - 1;
+    const float c = in[(size_t)y * w + x];
+    const float gxx = (in[(size_t)y * w + xm] - 2.0f * c) + in[(size_t)y * w + xp];
+    const float gyy = (in[(size_t)ym * w + x] - 2.0f * c) + in[(size_t)yp * w + x];
+    const float gu = 0.5f * in[(size_t)ym * w + xm] - 0.5f * in[(size_t)ym * w + xp];
+    const float gd = 0.5f * in[(size_t)yp * w + xm] - 0.5f * in[(size_t)yp * w + xp];
+    const float gxy = 0.5f * gu - 0.5f * gd;
+    const float t1 = gxx * gyy, t2 = gxy * gxy;
+    out[(size_t)y * w + x] = fabsf(t1 - t2) * s4;
+}
+
+extern "C" int affnet_hessian_response(affnet_ctx* ctx, const float* d_in, float* d_out, int h, int w, float sigma4, void* stream) {
+    if (!ctx || !d_in || !d_out || h < 1 || w < 1) return aff_fail(ctx, AFFNET_ERR_INVALID, "hessian_response: bad argument");
+    hipLaunchKernelGGL(hessian_resp_kernel, dim3(aff_cdiv(w, 64), aff_cdiv(h, 4)), dim3(256), 0, (hipStream_t)stream, d_in, d_out, h,
+                       w, sigma4);
+    AFF_LAUNCH_CHECK(ctx);
+    return AFFNET_OK;
+}
+
+// ---- sequential octaveMap replay on the sparse raw list -------------------------------------------
+struct ResolveParams {
+    RawMax* raw[AFFNET_MAX_OCTAVES];
+    uint8_t* omap[AFFNET_MAX_OCTAVES];
+    int raw_cap[AFFNET_MAX_OCTAVES];
+    int n_detect_levels;          // nLevels (3)
+    int32_t* cnt;                 // counter block
+    float* cand_resp; float* cand_syx; int32_t* cand_ids;
+    int cand_cap;
+};
+
+__global__ __launch_bounds__(1024) void octave_resolve_kernel(ResolveParams p) {
+    const int o = blockIdx.x;
+    __shared__ int s_pos;
+    RawMax* raw = p.raw[o];
+    volatile uint8_t* omap = p.omap[o];
+    int n = p.cnt[CNT_RAW0 + o];
+    if (n > p.raw_cap[o]) n = p.raw_cap[o];
+    for (int l = 1; l <= p.n_detect_levels; ++l) {
+        if (threadIdx.x == 0) s_pos = 0;
+        __syncthreads();
+        int local = 0;
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            if (raw[i].lvl != l) continue;
+            const float v = raw[i].val * (1.0f - (float)omap[raw[i].pix]);
+            if (v > 0.0f) ++local;
+        }
+        if (local) atomicAdd(&s_pos, local);
+        __syncthreads();
+        const int n_pos = s_pos;
+        __syncthreads();
+        if (n_pos <= 1) continue;                      // HandCraftedModules.py:252-254: level skipped, octaveMap unchanged
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            if (raw[i].lvl != l) continue;
+            const int pix = raw[i].pix;
+            const float m = (float)omap[pix];
+            const float v = raw[i].val * (1.0f - m);
+            const float sum = m + v;
+            omap[pix] = (uint8_t)(long long)sum;        // float -> int64 -> uint8 wrap, as torch's CPU .byte()
+            if (v != 0.0f) {
+                const int slot = atomicAdd(&p.cnt[CNT_CAND], 1);
+                if (slot < p.cand_cap) {
+                    p.cand_resp[slot] = v;
+                    p.cand_syx[3 * slot] = raw[i].s; p.cand_syx[3 * slot + 1] = raw[i].y; p.cand_syx[3 * slot + 2] = raw[i].x;
+                    p.cand_ids[3 * slot] = o; p.cand_ids[3 * slot + 1] = l - 1; p.cand_ids[3 * slot + 2] = pix;
+                } else {
+                    atomicOr(&p.cnt[CNT_OVERFLOW], 2);
+                }
+            }
+        }
+        __threadfence();
+        __syncthreads();
+    }
+}
+
+// ---- global top-C --------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t order_key(float f) {   // larger float -> larger uint
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+// One workgroup.  Decides the selection mode and, for top-k, the threshold key by an MSB-first
+// 8-bit radix select over all candidates.
+__global__ __launch_bounds__(1024) void select_prepare_kernel(const float* __restrict__ resp, int32_t* cnt, int cand_cap, int C,
+                                                              int sel_cap) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t s_prefix, s_mask, s_need;
+    int n = cnt[CNT_CAND];
+    if (n > cand_cap) n = cand_cap;
+    if (threadIdx.x == 0) {
+        cnt[CNT_SEL] = 0; cnt[CNT_EQ_TAKEN] = 0;
+    }
+    if (!(C > 0 && n > C)) {
+        if (threadIdx.x == 0) {
+            cnt[CNT_SEL_MODE] = 0; cnt[CNT_SEL_THRESH] = 0; cnt[CNT_SEL_NEED_EQ] = 0;
+            if (n > sel_cap) atomicOr(&cnt[CNT_OVERFLOW], 4);
+        }
+        return;
+    }
+    if (threadIdx.x == 0) { s_prefix = 0; s_mask = 0; s_need = (uint32_t)C; }
+    __syncthreads();
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int i = threadIdx.x; i < 256; i += 1024) hist[i] = 0;
+        __syncthreads();
+        const uint32_t prefix = s_prefix, mask = s_mask;
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            const uint32_t k = order_key(resp[i]);
+            if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t need = s_need;
+            int d = 255;
+            for (; d > 0; --d) {
+                if (hist[d] >= need) break;
+                need -= hist[d];
+            }
+            s_need = need;                              // rank inside bucket d (1-based), hist[d] >= need
+            s_prefix = prefix | ((uint32_t)d << shift);
+            s_mask = mask | (255u << shift);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        cnt[CNT_SEL_MODE] = 1;
+        cnt[CNT_SEL_THRESH] = (int32_t)s_prefix;        // key of the C-th largest response
+        cnt[CNT_SEL_NEED_EQ] = (int32_t)s_need;         // how many elements equal to it are inside the top C
+    }
+}
+
+__global__ __launch_bounds__(256) void select_compact_kernel(const float* __restrict__ resp, const float* __restrict__ syx,
+                                                             const int32_t* __restrict__ ids, int32_t* cnt, int cand_cap,
+                                                             float* sel_resp, float* sel_syx, int32_t* sel_ids, int sel_cap) {
+    int n = cnt[CNT_CAND];
+    if (n > cand_cap) n = cand_cap;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    bool take = true;
+    if (cnt[CNT_SEL_MODE] == 1) {
+        const uint32_t k = order_key(resp[i]), T = (uint32_t)cnt[CNT_SEL_THRESH];
+        take = k > T;
+        if (k == T) take = atomicAdd(&cnt[CNT_EQ_TAKEN], 1) < cnt[CNT_SEL_NEED_EQ];
+    }
+    if (!take) return;
+    const int slot = atomicAdd(&cnt[CNT_SEL], 1);
+    if (slot >= sel_cap) return;                        // overflow already flagged by select_prepare
+    sel_resp[slot] = resp[i];
+    sel_syx[3 * slot] = syx[3 * i]; sel_syx[3 * slot + 1] = syx[3 * i + 1]; sel_syx[3 * slot + 2] = syx[3 * i + 2];
+    sel_ids[3 * slot] = ids[3 * i]; sel_ids[3 * slot + 1] = ids[3 * i + 1]; sel_ids[3 * slot + 2] = ids[3 * i + 2];
+}
+
+__device__ __forceinline__ unsigned long long ord_key(const int32_t* ids) {  // (octave, level, pixel) lexicographic
+    return ((unsigned long long)(uint32_t)ids[0] << 40) | ((unsigned long long)(uint32_t)ids[1] << 32) | (uint32_t)ids[2];
+}
+
+// Rank sort + emit.  Output row = rank.  mode 1: descending response (ties: key order);
+// mode 0: (octave, level, pixel) ascending = the reference's concatenation order.
+__global__ __launch_bounds__(256) void select_rank_emit_kernel(const float* __restrict__ sel_resp, const float* __restrict__ sel_syx,
+                                                               const int32_t* __restrict__ sel_ids, int32_t* cnt, int sel_cap,
+                                                               float mr, float* out_resp, float* out_lafs, int32_t* out_ids,
+                                                               int32_t* out_count) {
+    __shared__ float t_resp[256];
+    __shared__ unsigned long long t_ord[256];
+    int n = cnt[CNT_SEL];
+    if (n > sel_cap) n = sel_cap;
+    const int mode = cnt[CNT_SEL_MODE];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { cnt[CNT_DET] = n; if (out_count) *out_count = n; }
+    if (blockIdx.x * 256 >= n) return;
+    const bool live = i < n;
+    const float ri = live ? sel_resp[i] : 0.f;
+    const unsigned long long oi = live ? ord_key(sel_ids + 3 * i) : 0ull;
+    int rank = 0;
+    for (int base = 0; base < n; base += 256) {
+        const int j = base + threadIdx.x;
+        __syncthreads();
+        if (j < n) { t_resp[threadIdx.x] = sel_resp[j]; t_ord[threadIdx.x] = ord_key(sel_ids + 3 * j); }
+        __syncthreads();
+        const int m = (n - base) < 256 ? (n - base) : 256;
+        if (mode == 1) {
+            for (int t = 0; t < m; ++t) {
+                const float rj = t_resp[t];
+                rank += (rj > ri) || (rj == ri && t_ord[t] < oi);
+            }
+        } else {
+            for (int t = 0; t < m; ++t) rank += t_ord[t] < oi;
+        }
+    }
+    if (!live) return;
+    out_resp[rank] = ri;
+    const float s = sel_syx[3 * i], y = sel_syx[3 * i + 1], x = sel_syx[3 * i + 2];
+    float* L = out_lafs + 6 * (size_t)rank;
+    const float sm = mr * s;                            // LAFs[:,0:2,0:2] *= mrSize (SparseImgRepresenter.py:198)
+    L[0] = sm; L[1] = mr * 0.0f; L[2] = x;
+    L[3] = mr * 0.0f; L[4] = sm; L[5] = y;
+    out_ids[3 * rank] = sel_ids[3 * i]; out_ids[3 * rank + 1] = sel_ids[3 * i + 1]; out_ids[3 * rank + 2] = sel_ids[3 * i + 2];
+}
+
+extern "C" int affnet_detect(affnet_ctx* ctx, float* d_resp, float* d_lafs, int32_t* d_ids, int32_t* d_count, void* stream) {
+    if (!ctx || !ctx->ws || !d_resp || !d_lafs || !d_ids) return aff_fail(ctx, AFFNET_ERR_INVALID, "detect: context not bound or null output");
+    hipStream_t st = (hipStream_t)stream;
+    const affnet_config& c = ctx->cfg;
+    if (c.levels_per_octave != 5) return aff_fail(ctx, AFFNET_ERR_INVALID, "detect: only nLevels=3 (5 levels per octave) is implemented");
+    AFF_HIP(ctx, hipMemsetAsync(ctx->cnt, 0, CNT_TOTAL * sizeof(int32_t), st));
+    AFF_HIP(ctx, hipMemsetAsync(ctx->omap, 0, ctx->map_bytes, st));
+    const size_t P = (size_t)ctx->cap_pre;
+    AFF_HIP(ctx, hipMemsetAsync(d_resp, 0, P * sizeof(float), st));
+    AFF_HIP(ctx, hipMemsetAsync(d_lafs, 0, P * 6 * sizeof(float), st));
+    AFF_HIP(ctx, hipMemsetAsync(d_ids, 0, P * 3 * sizeof(int32_t), st));
+    ResolveParams rp;
+    memset(&rp, 0, sizeof(rp));
+    for (int o = 0; o < c.n_octaves; ++o) {
+        const OctaveGeom& g = ctx->oct[o];
+        HessParams hp;
+        hp.levels = ctx->pyr + g.pyr_off;
+        hp.h = g.h; hp.w = g.w; hp.n_levels = 5;
+        for (int l = 0; l < 5; ++l) { hp.sigma[l] = c.level_sigma[o][l]; hp.sigma4[l] = c.level_sigma4[o][l]; }
+        hp.th = c.threshold;
+        hp.border = (int)c.mr_size;
+        hp.raw = ctx->raw + g.raw_off; hp.raw_cap = g.raw_cap;
+        hp.raw_cnt = ctx->cnt + CNT_RAW0 + o; hp.overflow = ctx->cnt + CNT_OVERFLOW;
+        hipLaunchKernelGGL(hessian_nms_kernel, dim3(aff_cdiv(g.w, HT_X), aff_cdiv(g.h, HT_Y)), dim3(256), 0, st, hp);
+        AFF_LAUNCH_CHECK(ctx);
+        rp.raw[o] = hp.raw; rp.omap[o] = ctx->omap + g.map_off; rp.raw_cap[o] = g.raw_cap;
+    }
+    rp.n_detect_levels = 3; rp.cnt = ctx->cnt;
+    rp.cand_resp = ctx->cand_resp; rp.cand_syx = ctx->cand_syx; rp.cand_ids = ctx->cand_ids; rp.cand_cap = (int)ctx->cand_cap;
+    hipLaunchKernelGGL(octave_resolve_kernel, dim3(c.n_octaves), dim3(1024), 0, st, rp);
+    AFF_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(select_prepare_kernel, dim3(1), dim3(1024), 0, st, ctx->cand_resp, ctx->cnt, (int)ctx->cand_cap, c.num_prefilter,
+                       ctx->cap_pre);
+    AFF_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(select_compact_kernel, dim3(aff_cdiv((int)ctx->cand_cap, 256)), dim3(256), 0, st, ctx->cand_resp, ctx->cand_syx,
+                       ctx->cand_ids, ctx->cnt, (int)ctx->cand_cap, ctx->sel_resp, ctx->sel_syx, ctx->sel_ids, ctx->cap_pre);
+    AFF_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(select_rank_emit_kernel, dim3(aff_cdiv(ctx->cap_pre, 256)), dim3(256), 0, st, ctx->sel_resp, ctx->sel_syx,
+                       ctx->sel_ids, ctx->cnt, ctx->cap_pre, c.mr_size, d_resp, d_lafs, d_ids, d_count);
+    AFF_LAUNCH_CHECK(ctx);
+    return AFFNET_OK;
+}

@@ -1,0 +1,284 @@
+// LAF-driven patch sampler and LAF algebra kernels for gfx950.
+//
+// Replaces LAF.py:313-324,326-372 (affine grid + grid_sample), :376-404 (pyramid gather),
+// :407-429 (de/normalise), :450-472 (level choice via host scipy cdist),
+// SparseImgRepresenter.py:121-162 (shape compose + filter + top-N), :173-177 (apply rotation),
+// Utils.py:168-175 (batch_eig2x2), LAF.py:91-104 (checkTouchBoundary).
+#include <math.h>
+
+#include "common.h"
+
+#define MAX_PS 64
+
+struct BaseGrid { float v[MAX_PS]; };
+
+struct PyrTable {   // level pointers of the pyramid in the workspace
+    const float* lvl[AFFNET_MAX_OCTAVES][AFFNET_MAX_LEVELS];
+    int h[AFFNET_MAX_OCTAVES], w[AFFNET_MAX_OCTAVES];
+    int n_octaves, n_levels;
+};
+
+void aff_fill_pyr_table(const affnet_ctx* ctx, PyrTable* t) {
+    memset(t, 0, sizeof(*t));
+    t->n_octaves = ctx->cfg.n_octaves; t->n_levels = ctx->cfg.levels_per_octave;
+    for (int o = 0; o < t->n_octaves; ++o) {
+        const OctaveGeom& g = ctx->oct[o];
+        t->h[o] = g.h; t->w[o] = g.w;
+        for (int l = 0; l < t->n_levels; ++l) t->lvl[o][l] = ctx->pyr + g.pyr_off + (size_t)l * g.h * g.w;
+    }
+}
+
+// One workgroup per patch.  The affine footprint of a patch is a few hundred source pixels that
+// are re-read 4x by neighbouring samples: they stay in the CU's L1 (32 KiB) after first touch, and
+// each wave row of 32..64 samples walks a straight line through the level image.
+__global__ __launch_bounds__(256) void grid_sample_kernel(const float* __restrict__ img, int h, int w, PyrTable pt, int use_pyr,
+                                                          const float* __restrict__ lafs, const int32_t* __restrict__ ids,
+                                                          const int32_t* __restrict__ d_count, int n_max, int ps, BaseGrid bg,
+                                                          float* __restrict__ out) {
+    const int p = blockIdx.x;
+    const int n = d_count ? min(*d_count, n_max) : n_max;
+    if (p >= n) return;
+    if (use_pyr) {
+        int o = ids[3 * p], l = ids[3 * p + 1];
+        o = o < 0 ? 0 : (o >= pt.n_octaves ? pt.n_octaves - 1 : o);
+        l = l < 0 ? 0 : (l >= pt.n_levels ? pt.n_levels - 1 : l);
+        img = pt.lvl[o][l]; h = pt.h[o]; w = pt.w[o];
+    }
+    const float* L = lafs + 6 * (size_t)p;
+    const float m = (float)(h < w ? h : w);
+    const float t00 = L[0] * m, t01 = L[1] * m, t02 = L[2] * (float)w;
+    const float t10 = L[3] * m, t11 = L[4] * m, t12 = L[5] * (float)h;
+    float* dst = out + (size_t)p * ps * ps;
+    for (int i = threadIdx.x; i < ps * ps; i += 256) {
+        const int r = i / ps, c = i - r * ps;
+        dst[i] = aff_sample_bilinear(img, h, w, t00, t01, t02, t10, t11, t12, bg.v[c], bg.v[r]);
+    }
+}
+
+static int sample_common(affnet_ctx* ctx, const float* img, int h, int w, int use_pyr, const float* lafs, const int32_t* ids,
+                         const int32_t* cnt, int n, int ps, float* out, hipStream_t st) {
+    if (ps < 1 || ps > MAX_PS) return aff_fail(ctx, AFFNET_ERR_INVALID, "patch size %d not in 1..%d", ps, MAX_PS);
+    if (n <= 0) return AFFNET_OK;
+    BaseGrid bg;
+    memset(&bg, 0, sizeof(bg));
+    aff_base_grid(ps, bg.v);
+    PyrTable pt;
+    if (use_pyr) aff_fill_pyr_table(ctx, &pt); else memset(&pt, 0, sizeof(pt));
+    hipLaunchKernelGGL(grid_sample_kernel, dim3(n), dim3(256), 0, st, img, h, w, pt, use_pyr, lafs, ids, cnt, n, ps, bg, out);
+    AFF_LAUNCH_CHECK(ctx);
+    return AFFNET_OK;
+}
+
+extern "C" int affnet_laf_grid_sample(affnet_ctx* ctx, const float* d_img, int h, int w, const float* d_lafs, int n, int ps,
+                                      float* d_out, void* stream) {
+    if (!ctx || !d_img || !d_lafs || !d_out || h < 1 || w < 1 || n < 0) return aff_fail(ctx, AFFNET_ERR_INVALID, "laf_grid_sample: bad argument");
+    return sample_common(ctx, d_img, h, w, 0, d_lafs, nullptr, nullptr, n, ps, d_out, (hipStream_t)stream);
+}
+
+extern "C" int affnet_pyr_grid_sample(affnet_ctx* ctx, const float* d_lafs, const int32_t* d_ids, const int32_t* d_count, int n_max,
+                                      int ps, float* d_out, void* stream) {
+    if (!ctx || !ctx->ws || !d_lafs || !d_ids || !d_out || n_max < 0) return aff_fail(ctx, AFFNET_ERR_INVALID, "pyr_grid_sample: bad argument");
+    return sample_common(ctx, nullptr, 0, 0, 1, d_lafs, d_ids, d_count, n_max, ps, d_out, (hipStream_t)stream);
+}
+
+// ---- shape compose + filter ------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void shape_filter_kernel(const float* __restrict__ resp, const float* __restrict__ lafs,
+                                                           const float* __restrict__ A, const int32_t* __restrict__ d_count,
+                                                           int n_max, float* __restrict__ key, int32_t* __restrict__ good) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int n = min(*d_count, n_max);
+    if (i >= n_max) return;
+    if (i >= n) { key[i] = 0.f; good[i] = 0; return; }
+    // base_A = bmm(A, I) = A exactly (SparseImgRepresenter.py:136, one iteration)
+    const float a00 = A[4 * i], a01 = A[4 * i + 1], a10 = A[4 * i + 2], a11 = A[4 * i + 3];
+    const float* L = lafs + 6 * (size_t)i;
+    // new_LAF = [base_A * LAF_2x2 | centre]: bmm row-by-column, k ascending, fused accumulate
+    const float n00 = fmaf(a01, L[3], a00 * L[0]), n01 = fmaf(a01, L[4], a00 * L[1]);
+    const float n10 = fmaf(a11, L[3], a10 * L[0]), n11 = fmaf(a11, L[4], a10 * L[1]);
+    const float cx = L[2], cy = L[5];
+    // batch_eig2x2 (Utils.py:168-175), op by op
+    const float tr = a00 + a11;
+    const float p1 = a00 * a11, p2 = a10 * a01;
+    const float d1 = tr * tr - 4.0f * (p1 - p2);
+    const float mk = d1 > 0.f ? 1.0f : 0.0f;
+    const float dl = sqrtf(fabsf(d1));
+    const float l1 = mk * (tr + dl) / 2.0f + 1000.0f * (1.0f - mk);
+    const float l2 = mk * (tr - dl) / 2.0f + 0.0001f * (1.0f - mk);
+    const float ratio = fabsf(l1 / (l2 + 1e-8f));
+    bool ok = (ratio < 6.0f) && (ratio > (float)(1.0 / 6.0));
+    // checkTouchBoundary (LAF.py:98-104): corners (+-1,+-1) of the frame must stay inside [0,1]^2
+    const float px[4] = {-1.f, -1.f, 1.f, 1.f}, py[4] = {-1.f, 1.f, -1.f, 1.f};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float ox = fmaf(cx, 1.0f, fmaf(n01, py[k], n00 * px[k]));
+        const float oy = fmaf(cy, 1.0f, fmaf(n11, py[k], n10 * px[k]));
+        if (ox > 1.0f || ox < 0.0f || oy > 1.0f || oy < 0.0f) ok = false;
+    }
+    good[i] = ok ? 1 : 0;
+    key[i] = resp[i] * (ok ? 1.0f : 0.0f);
+}
+
+// Multi-workgroup selection: each thread ranks one row against all rows.
+//   survivors > N  -> top-N of key (descending; ties by row index) - torch.topk branch (:151-153)
+//   otherwise      -> stable compaction of the good rows            - nonzero branch (:154-156)
+__global__ __launch_bounds__(256) void shape_select_kernel(const float* __restrict__ resp, const float* __restrict__ lafs,
+                                                           const int32_t* __restrict__ ids, const float* __restrict__ A,
+                                                           const float* __restrict__ key, const int32_t* __restrict__ good,
+                                                           const int32_t* __restrict__ d_count, int n_max, int N, int out_cap,
+                                                           float* out_resp, float* out_lafs, int32_t* out_ids, int32_t* out_count,
+                                                           int32_t* cnt) {
+    __shared__ float t_key[256];
+    __shared__ int t_good[256];
+    __shared__ int s_surv;
+    const int n = min(*d_count, n_max);
+    if (threadIdx.x == 0) s_surv = 0;
+    __syncthreads();
+    int local = 0;
+    for (int j = threadIdx.x; j < n; j += 256) local += good[j];
+    if (local) atomicAdd(&s_surv, local);
+    __syncthreads();
+    const int surv = s_surv;
+    const bool topk = (N > 0) && (surv > N);
+    const int n_out = topk ? N : (surv < out_cap ? surv : out_cap);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        *out_count = n_out; cnt[CNT_SHAPED] = n_out; cnt[CNT_SURVIVED] = surv;
+        if (!topk && surv > out_cap) atomicOr(&cnt[CNT_OVERFLOW], 8);
+    }
+    if (blockIdx.x * 256 >= n) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const bool live = i < n;
+    const float ki = live ? key[i] : 0.f;
+    const int gi = live ? good[i] : 0;
+    int pos = 0;
+    for (int base = 0; base < n; base += 256) {
+        const int j = base + threadIdx.x;
+        __syncthreads();
+        if (j < n) { t_key[threadIdx.x] = key[j]; t_good[threadIdx.x] = good[j]; }
+        __syncthreads();
+        const int m = (n - base) < 256 ? (n - base) : 256;
+        if (topk) {
+            for (int t = 0; t < m; ++t) { const float kj = t_key[t]; pos += (kj > ki) || (kj == ki && (base + t) < i); }
+        } else {
+            for (int t = 0; t < m; ++t) pos += (t_good[t] != 0) && ((base + t) < i);
+        }
+    }
+    if (!live) return;
+    if (topk ? (pos >= N) : (!gi || pos >= out_cap)) return;
+    out_resp[pos] = topk ? ki : resp[i];
+    const float a00 = A[4 * i], a01 = A[4 * i + 1], a10 = A[4 * i + 2], a11 = A[4 * i + 3];
+    const float* L = lafs + 6 * (size_t)i;
+    float* O = out_lafs + 6 * (size_t)pos;
+    O[0] = fmaf(a01, L[3], a00 * L[0]); O[1] = fmaf(a01, L[4], a00 * L[1]); O[2] = L[2];
+    O[3] = fmaf(a11, L[3], a10 * L[0]); O[4] = fmaf(a11, L[4], a10 * L[1]); O[5] = L[5];
+    out_ids[3 * pos] = ids[3 * i]; out_ids[3 * pos + 1] = ids[3 * i + 1]; out_ids[3 * pos + 2] = ids[3 * i + 2];
+}
+
+extern "C" int affnet_shape_filter_select(affnet_ctx* ctx, const float* d_resp_in, const float* d_lafs_in, const int32_t* d_ids_in,
+                                          const float* d_A, const int32_t* d_count_in, float* d_resp_out, float* d_lafs_out,
+                                          int32_t* d_ids_out, int32_t* d_count_out, void* stream) {
+    if (!ctx || !ctx->ws || !d_resp_in || !d_lafs_in || !d_ids_in || !d_A || !d_count_in || !d_resp_out || !d_lafs_out || !d_ids_out ||
+        !d_count_out)
+        return aff_fail(ctx, AFFNET_ERR_INVALID, "shape_filter_select: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int P = ctx->cap_pre, F = ctx->cap_final;
+    AFF_HIP(ctx, hipMemsetAsync(d_resp_out, 0, (size_t)F * sizeof(float), st));
+    AFF_HIP(ctx, hipMemsetAsync(d_lafs_out, 0, (size_t)F * 6 * sizeof(float), st));
+    AFF_HIP(ctx, hipMemsetAsync(d_ids_out, 0, (size_t)F * 3 * sizeof(int32_t), st));
+    hipLaunchKernelGGL(shape_filter_kernel, dim3(aff_cdiv(P, 256)), dim3(256), 0, st, d_resp_in, d_lafs_in, d_A, d_count_in, P, ctx->st_key,
+                       ctx->st_good);
+    AFF_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(shape_select_kernel, dim3(aff_cdiv(P, 256)), dim3(256), 0, st, d_resp_in, d_lafs_in, d_ids_in, d_A, ctx->st_key,
+                       ctx->st_good, d_count_in, P, ctx->cfg.num_features, F, d_resp_out, d_lafs_out, d_ids_out, d_count_out, ctx->cnt);
+    AFF_LAUNCH_CHECK(ctx);
+    return AFFNET_OK;
+}
+
+// ---- small elementwise LAF kernels ---------------------------------------------------------------
+__global__ void apply_rotation_kernel(float* __restrict__ lafs, const float* __restrict__ R, const int32_t* __restrict__ d_count,
+                                      int n_max) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = d_count ? min(*d_count, n_max) : n_max;
+    if (i >= n) return;
+    float* L = lafs + 6 * (size_t)i;
+    const float* r = R + 4 * (size_t)i;
+    const float l00 = L[0], l01 = L[1], l10 = L[3], l11 = L[4];
+    L[0] = fmaf(l01, r[2], l00 * r[0]); L[1] = fmaf(l01, r[3], l00 * r[1]);
+    L[3] = fmaf(l11, r[2], l10 * r[0]); L[4] = fmaf(l11, r[3], l10 * r[1]);
+}
+
+extern "C" int affnet_apply_rotation(affnet_ctx* ctx, float* d_lafs, const float* d_R, const int32_t* d_count, int n_max, void* stream) {
+    if (!ctx || !d_lafs || !d_R || n_max < 0) return aff_fail(ctx, AFFNET_ERR_INVALID, "apply_rotation: bad argument");
+    if (n_max == 0) return AFFNET_OK;
+    hipLaunchKernelGGL(apply_rotation_kernel, dim3(aff_cdiv(n_max, 256)), dim3(256), 0, (hipStream_t)stream, d_lafs, d_R, d_count, n_max);
+    AFF_LAUNCH_CHECK(ctx);
+    return AFFNET_OK;
+}
+
+__global__ void scale_lafs_kernel(const float* __restrict__ in, float* __restrict__ out, const int32_t* __restrict__ d_count, int n_max,
+                                  float c_a, float c_x, float c_y) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = d_count ? min(*d_count, n_max) : n_max;
+    if (i >= n_max) return;
+    const float* L = in + 6 * (size_t)i;
+    float* O = out + 6 * (size_t)i;
+    if (i >= n) { O[0] = O[1] = O[2] = O[3] = O[4] = O[5] = 0.f; return; }
+    O[0] = c_a * L[0]; O[1] = c_a * L[1]; O[2] = c_x * L[2];
+    O[3] = c_a * L[3]; O[4] = c_a * L[4]; O[5] = c_y * L[5];
+}
+
+extern "C" int affnet_scale_lafs(affnet_ctx* ctx, const float* d_in, float* d_out, const int32_t* d_count, int n_max, int w, int h,
+                                 int inverse, void* stream) {
+    if (!ctx || !d_in || !d_out || n_max < 0 || w < 1 || h < 1) return aff_fail(ctx, AFFNET_ERR_INVALID, "scale_lafs: bad argument");
+    if (n_max == 0) return AFFNET_OK;
+    const float fw = (float)w, fh = (float)h, m = fw < fh ? fw : fh;
+    // normalizeLAFs: ones/min_size in fp32, 1.0/w and 1.0/h are python doubles stored to fp32 (LAF.py:424-426)
+    const float ca = inverse ? 1.0f / m : m;
+    const float cx = inverse ? (float)(1.0 / (double)fw) : fw;
+    const float cy = inverse ? (float)(1.0 / (double)fh) : fh;
+    hipLaunchKernelGGL(scale_lafs_kernel, dim3(aff_cdiv(n_max, 256)), dim3(256), 0, (hipStream_t)stream, d_in, d_out, d_count, n_max, ca, cx,
+                       cy);
+    AFF_LAUNCH_CHECK(ctx);
+    return AFFNET_OK;
+}
+
+struct LevelTable { double sig[AFFNET_MAX_OCTAVES * AFFNET_MAX_LEVELS]; int n_oct, n_lvl; };
+
+__global__ void level_select_kernel(const float* __restrict__ lafs_px, const int32_t* __restrict__ d_count, int n_max, float ps,
+                                    LevelTable lt, float ca, float cx, float cy, int32_t* __restrict__ ids, float* __restrict__ lafs_norm) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = d_count ? min(*d_count, n_max) : n_max;
+    if (i >= n) return;
+    const float* L = lafs_px + 6 * (size_t)i;
+    // get_LAFs_scales (LAF.py:450-451) in fp32, then / PS in fp32, then float64 |a - b| argmin (cdist on 1-D points)
+    const float p1 = L[0] * L[4], p2 = L[1] * L[3];
+    const float sc = sqrtf(fabsf(p1 - p2) + 1e-12f);
+    const double need = (double)(sc / ps);
+    int best = 0;
+    double bd = INFINITY;
+    const int tot = lt.n_oct * lt.n_lvl;
+    for (int k = 0; k < tot; ++k) {
+        const double df = lt.sig[k] - need;
+        const double d = sqrt(df * df);               // scipy cdist 'euclidean' on 1-D points
+        if (d < bd) { bd = d; best = k; }
+    }
+    ids[3 * i] = best / lt.n_lvl; ids[3 * i + 1] = best % lt.n_lvl; ids[3 * i + 2] = 0;
+    float* O = lafs_norm + 6 * (size_t)i;
+    O[0] = ca * L[0]; O[1] = ca * L[1]; O[2] = cx * L[2];
+    O[3] = ca * L[3]; O[4] = ca * L[4]; O[5] = cy * L[5];
+}
+
+extern "C" int affnet_level_select(affnet_ctx* ctx, const float* d_lafs_px, const int32_t* d_count, int n_max, int ps, int32_t* d_ids,
+                                   float* d_lafs_norm, void* stream) {
+    if (!ctx || !d_lafs_px || !d_ids || !d_lafs_norm || n_max < 0 || ps < 1) return aff_fail(ctx, AFFNET_ERR_INVALID, "level_select: bad argument");
+    if (n_max == 0) return AFFNET_OK;
+    LevelTable lt;
+    const affnet_config& c = ctx->cfg;
+    lt.n_oct = c.n_octaves; lt.n_lvl = c.levels_per_octave;
+    for (int o = 0; o < lt.n_oct; ++o)
+        for (int l = 0; l < lt.n_lvl; ++l) lt.sig[o * lt.n_lvl + l] = c.level_sigma_px[o][l];
+    const float fw = (float)c.width, fh = (float)c.height, m = fw < fh ? fw : fh;
+    hipLaunchKernelGGL(level_select_kernel, dim3(aff_cdiv(n_max, 256)), dim3(256), 0, (hipStream_t)stream, d_lafs_px, d_count, n_max,
+                       (float)ps, lt, 1.0f / m, (float)(1.0 / (double)fw), (float)(1.0 / (double)fh), d_ids, d_lafs_norm);
+    AFF_LAUNCH_CHECK(ctx);
+    return AFFNET_OK;
+}

@@ -1,0 +1,60 @@
+// Fused whole-path entry point: image resident -> (LAFs, responses, descriptors) resident with zero
+// host synchronisation.  Replaces ScaleSpaceAffinePatchExtractor.forward
+// (SparseImgRepresenter.py:189-209), extract_patches_from_pyr (:181-188) and the HardNet call of
+// get_geometry_and_descriptors (train_OriNet_test_on_graffity.py:293-298).
+//
+// Every stage reads its row count from device memory (counter block in the workspace) and is
+// launched with the capacity-sized grid, so data-dependent sizes never travel to the host; the
+// reference synchronises 18x per image on .item() (HandCraftedModules.py:252), once more on
+// num_survived (SparseImgRepresenter.py:151) and round-trips LAF scales through scipy on the
+// host (LAF.py:466).  The reference's discarded extra patch extraction (:178-179) is dropped.
+#include "common.h"
+
+extern "C" int affnet_extract_features(affnet_ctx* ctx, const affnet_nets* nets, const float* d_img, int do_ori, float* d_lafs_px,
+                                       float* d_resp, int32_t* d_ids, float* d_desc, int32_t* d_count, void* stream) {
+    if (!ctx || !ctx->ws || !nets || !d_img || !d_lafs_px || !d_resp || !d_ids || !d_count)
+        return aff_fail(ctx, AFFNET_ERR_INVALID, "extract_features: context not bound or null argument");
+    if (do_ori && !nets->d_orinet) return aff_fail(ctx, AFFNET_ERR_INVALID, "extract_features: do_ori needs OriNet weights");
+    if (d_desc && !nets->d_hardnet) return aff_fail(ctx, AFFNET_ERR_INVALID, "extract_features: descriptors need HardNet weights");
+    hipStream_t st = (hipStream_t)stream;
+    const int P = ctx->cap_pre, F = ctx->cap_final;
+    int rc = affnet_pyramid_build(ctx, d_img, stream);
+    if (rc) return rc;
+    int32_t* det_count = ctx->cnt + CNT_DET;
+    rc = affnet_detect(ctx, ctx->st_det_resp, ctx->st_det_lafs, ctx->st_det_ids, nullptr, stream);
+    if (rc) return rc;
+    if (nets->d_affnet) {
+        rc = affnet_cnn32_forward_pyr(ctx, AFFNET_NET_AFFNET, nets->d_affnet, ctx->st_det_lafs, ctx->st_det_ids, det_count, P, ctx->st_A,
+                                      nullptr, stream);
+        if (rc) return rc;
+        rc = affnet_shape_filter_select(ctx, ctx->st_det_resp, ctx->st_det_lafs, ctx->st_det_ids, ctx->st_A, det_count, d_resp,
+                                        ctx->st_lafs_shaped, d_ids, d_count, stream);
+        if (rc) return rc;
+    } else {
+        // num_Baum_iters == 0: detections pass through unchanged (C == N)
+        if (F != P) return aff_fail(ctx, AFFNET_ERR_INVALID, "extract_features: without AffNet num_prefilter must equal num_features");
+        AFF_HIP(ctx, hipMemcpyAsync(d_resp, ctx->st_det_resp, (size_t)F * sizeof(float), hipMemcpyDeviceToDevice, st));
+        AFF_HIP(ctx, hipMemcpyAsync(ctx->st_lafs_shaped, ctx->st_det_lafs, (size_t)F * 6 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        AFF_HIP(ctx, hipMemcpyAsync(d_ids, ctx->st_det_ids, (size_t)F * 3 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        AFF_HIP(ctx, hipMemcpyAsync(d_count, det_count, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        AFF_HIP(ctx, hipMemcpyAsync(ctx->cnt + CNT_SHAPED, det_count, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    }
+    if (do_ori) {
+        rc = affnet_cnn32_forward_pyr(ctx, AFFNET_NET_ORINET, nets->d_orinet, ctx->st_lafs_shaped, d_ids, d_count, F, ctx->st_R, nullptr,
+                                      stream);
+        if (rc) return rc;
+        rc = affnet_apply_rotation(ctx, ctx->st_lafs_shaped, ctx->st_R, d_count, F, stream);
+        if (rc) return rc;
+    }
+    rc = affnet_scale_lafs(ctx, ctx->st_lafs_shaped, d_lafs_px, d_count, F, ctx->cfg.width, ctx->cfg.height, 0, stream);
+    if (rc) return rc;
+    if (d_desc) {
+        rc = affnet_level_select(ctx, d_lafs_px, d_count, F, 32, ctx->st_lvl_ids, ctx->st_lafs_norm, stream);
+        if (rc) return rc;
+        AFF_HIP(ctx, hipMemsetAsync(d_desc, 0, (size_t)F * 128 * sizeof(float), st));
+        rc = affnet_cnn32_forward_pyr(ctx, AFFNET_NET_HARDNET, nets->d_hardnet, ctx->st_lafs_norm, ctx->st_lvl_ids, d_count, F, d_desc,
+                                      ctx->st_hard_scratch, stream);
+        if (rc) return rc;
+    }
+    return AFFNET_OK;
+}

@@ -1,0 +1,134 @@
+// Gaussian scale pyramid for gfx950.
+//
+// Replaces Utils.py:150-166 (GaussianBlur.forward) and HandCraftedModules.py:23-56
+// (ScalePyramid.forward).  The reference blurs with a full k x k 2-D cross-correlation
+// (F.conv2d) after replicate padding; on CPU that kernel accumulates the taps with fused
+// multiply-adds in row-major tap order starting from 0.  This kernel performs exactly the same
+// fmaf chain per output pixel, so every pyramid level is bit-identical to the reference's CPU
+// result (DESIGN.md "bit-exact detector"); a separable blur would be ~6x fewer MACs but moves
+// levels by ~2e-4 and flips keypoints.
+//
+// Layout: one workgroup = 256 threads = 64 x 16 output tile; each thread owns 4 consecutive
+// output columns of one row and slides a (K+3)-wide register window over the LDS tile
+// (16-byte LDS reads), so one LDS row read feeds 4 x K fmaf.  Taps arrive as a by-value kernel
+// argument (scalar loads -> SGPR operands of v_fmac_f32).  Optional fused stride-2 decimation
+// writes the next octave's level 0 (F.avg_pool2d(k=1, s=2), HandCraftedModules.py:46-47).
+#include "common.h"
+
+#define BT_X 64
+#define BT_Y 16
+
+template <int K>
+struct Taps { float w[K * K]; };
+
+template <int K>
+__global__ __launch_bounds__(256) void blur2d_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                     float* __restrict__ dec_out, int h, int w, int w2, Taps<K> taps) {
+    constexpr int R = K / 2;
+    constexpr int LW = BT_X + 2 * R;               // tile width incl. halo
+    constexpr int LS = (LW + 3) & ~3;              // row stride, multiple of 4 floats (16-B aligned rows)
+    constexpr int LH = BT_Y + 2 * R;
+    __shared__ __attribute__((aligned(16))) float tile[LH * LS];
+    const int x0 = blockIdx.x * BT_X, y0 = blockIdx.y * BT_Y;
+    for (int i = threadIdx.x; i < LH * LW; i += 256) {
+        const int ty = i / LW, tx = i - ty * LW;
+        int gy = y0 + ty - R, gx = x0 + tx - R;
+        gy = gy < 0 ? 0 : (gy >= h ? h - 1 : gy);   // replicate padding
+        gx = gx < 0 ? 0 : (gx >= w ? w - 1 : gx);
+        tile[ty * LS + tx] = in[(size_t)gy * w + gx];
+    }
+    __syncthreads();
+    const int tx = (threadIdx.x & 15) * 4, ty = threadIdx.x >> 4;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    constexpr int NV = (K + 3 + 3) / 4;            // float4 loads covering K+3 values
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+        float r[NV * 4];
+        const float4* row = reinterpret_cast<const float4*>(&tile[(ty + i) * LS + tx]);
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            const float4 q = row[v];
+            r[4 * v] = q.x; r[4 * v + 1] = q.y; r[4 * v + 2] = q.z; r[4 * v + 3] = q.w;
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const float wt = taps.w[i * K + j];
+            a0 = fmaf(r[j], wt, a0);
+            a1 = fmaf(r[j + 1], wt, a1);
+            a2 = fmaf(r[j + 2], wt, a2);
+            a3 = fmaf(r[j + 3], wt, a3);
+        }
+    }
+    const int y = y0 + ty, x = x0 + tx;
+    if (y >= h) return;
+    const float res[4] = {a0, a1, a2, a3};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (x + q < w) {
+            out[(size_t)y * w + x + q] = res[q];
+            if (dec_out && !(y & 1) && !((x + q) & 1)) dec_out[(size_t)(y >> 1) * w2 + ((x + q) >> 1)] = res[q];
+        }
+    }
+}
+
+template <int K>
+static void launch_blur(const float* in, float* out, float* dec, int h, int w, const float* taps, hipStream_t st) {
+    Taps<K> t;
+    memcpy(t.w, taps, sizeof(float) * K * K);
+    dim3 grid(aff_cdiv(w, BT_X), aff_cdiv(h, BT_Y));
+    hipLaunchKernelGGL(blur2d_kernel<K>, grid, dim3(256), 0, st, in, out, dec, h, w, (w - 1) / 2 + 1, t);
+}
+
+static int blur_dispatch(affnet_ctx* ctx, const float* in, float* out, float* dec, int h, int w, const float* taps, int k,
+                         hipStream_t st) {
+    switch (k) {
+        case 3: launch_blur<3>(in, out, dec, h, w, taps, st); break;
+        case 5: launch_blur<5>(in, out, dec, h, w, taps, st); break;
+        case 7: launch_blur<7>(in, out, dec, h, w, taps, st); break;
+        case 9: launch_blur<9>(in, out, dec, h, w, taps, st); break;
+        case 11: launch_blur<11>(in, out, dec, h, w, taps, st); break;
+        case 13: launch_blur<13>(in, out, dec, h, w, taps, st); break;
+        case 15: launch_blur<15>(in, out, dec, h, w, taps, st); break;
+        case 17: launch_blur<17>(in, out, dec, h, w, taps, st); break;
+        case 19: launch_blur<19>(in, out, dec, h, w, taps, st); break;
+        case 21: launch_blur<21>(in, out, dec, h, w, taps, st); break;
+        default:
+            return aff_fail(ctx, AFFNET_ERR_INVALID, "unsupported Gaussian size %d (supported: odd 3..21)", k);
+    }
+    AFF_LAUNCH_CHECK(ctx);
+    return AFFNET_OK;
+}
+
+extern "C" int affnet_gauss_blur(affnet_ctx* ctx, const float* d_in, float* d_out, int h, int w, const float* h_taps, int k,
+                                 void* stream) {
+    if (!ctx || !d_in || !d_out || !h_taps || h < 1 || w < 1) return aff_fail(ctx, AFFNET_ERR_INVALID, "gauss_blur: bad argument");
+    return blur_dispatch(ctx, d_in, d_out, nullptr, h, w, h_taps, k, (hipStream_t)stream);
+}
+
+extern "C" int affnet_pyramid_build(affnet_ctx* ctx, const float* d_img, void* stream) {
+    if (!ctx || !ctx->ws || !d_img) return aff_fail(ctx, AFFNET_ERR_INVALID, "pyramid_build: context not bound or null image");
+    hipStream_t st = (hipStream_t)stream;
+    const affnet_config& c = ctx->cfg;
+    const int L = c.levels_per_octave;
+    const int dec_level = L - 2;  // i == nLevels (HandCraftedModules.py:46)
+    for (int o = 0; o < c.n_octaves; ++o) {
+        const OctaveGeom& g = ctx->oct[o];
+        float* base = ctx->pyr + g.pyr_off;
+        const size_t lvl = (size_t)g.h * g.w;
+        if (o == 0) {
+            if (c.first_blur_taps > 0) {
+                int rc = blur_dispatch(ctx, d_img, base, nullptr, g.h, g.w, c.first_blur, c.first_blur_taps, st);
+                if (rc) return rc;
+            } else {
+                AFF_HIP(ctx, hipMemcpyAsync(base, d_img, lvl * sizeof(float), hipMemcpyDeviceToDevice, st));
+            }
+        }
+        for (int l = 1; l < L; ++l) {
+            float* dec = nullptr;
+            if (l == dec_level && o + 1 < c.n_octaves) dec = ctx->pyr + ctx->oct[o + 1].pyr_off;
+            int rc = blur_dispatch(ctx, base + (l - 1) * lvl, base + l * lvl, dec, g.h, g.w, c.level_blur[l], c.level_blur_taps[l], st);
+            if (rc) return rc;
+        }
+    }
+    return AFFNET_OK;
+}

@@ -1,0 +1,130 @@
+"""Thin Python owner of libaffnet_hip contexts, workspaces and packed weights.
+PyTorch is used for device memory and streams only."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import lib, check, ptr
+from .host_plan import PyramidPlan
+
+_UTILITY = {}
+
+
+def require_cuda(t, what="tensor"):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise RuntimeError("affnet_amd: %s must live on the MI355X (tensor.cuda()); this implementation has no CPU path" % what)
+
+
+def utility_ctx(device):
+    """Context without a pyramid, for stand-alone stage calls."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _UTILITY:
+        h = C.c_void_p()
+        check(lib.affnet_ctx_create(C.byref(h), idx, None), None, "affnet_ctx_create(utility)")
+        _UTILITY[idx] = h
+    return _UTILITY[idx]
+
+
+def stream_of(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class Context(object):
+    """One extractor instance on one device: config, workspace, pyramid views."""
+
+    def __init__(self, height, width, device, n_levels, init_sigma, border, mr_size, threshold,
+                 num_features, num_prefilter, max_keep=16384):
+        self.plan = PyramidPlan(height, width, n_levels, init_sigma, border)
+        self.cfg = self.plan.fill_config(mr_size, threshold, num_features, num_prefilter, max_keep)
+        self.device = device
+        self.handle = C.c_void_p()
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        rc = lib.affnet_ctx_create(C.byref(self.handle), idx, C.byref(self.cfg))
+        check(rc, self.handle, "affnet_ctx_create")
+        nbytes = lib.affnet_workspace_bytes(self.handle)
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        check(lib.affnet_bind_workspace(self.handle, ptr(self.workspace), nbytes), self.handle, "affnet_bind_workspace")
+        self.cap_pre = lib.affnet_capacity_prefilter(self.handle)
+        self.cap_final = lib.affnet_capacity_final(self.handle)
+        self._ws_f32 = self.workspace.view(torch.float32)
+
+    def pyramid_views(self):
+        """scale_pyr[o][l] as (1,1,h,w) views into the workspace (SparseImgRepresenter.py:55)."""
+        pyr = []
+        for o, (h, w) in enumerate(self.plan.sizes):
+            levels = []
+            for l in range(self.plan.levels_per_octave):
+                off = lib.affnet_pyramid_level_offset(self.handle, o, l)
+                levels.append(self._ws_f32[off:off + h * w].view(1, 1, h, w))
+            pyr.append(levels)
+        return pyr
+
+    def read_counts(self):
+        out = (C.c_int32 * 4)()
+        rc = lib.affnet_read_counts(self.handle, C.byref(out), stream_of(self.device))
+        check(rc, self.handle, "affnet_read_counts")
+        return list(out)
+
+    def __del__(self):
+        try:
+            if self.handle:
+                lib.affnet_ctx_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+def pack_state_dict(kind, sd):
+    """state dict (reference key layout) -> packed fp32 blob (CPU tensor)."""
+    conv_idx, bn_idx = (0, 3, 6, 9, 12, 15), (1, 4, 7, 10, 13, 16)
+
+    def f32(name):
+        return sd[name].detach().to("cpu", torch.float32).contiguous()
+
+    keep = []
+    convs = [f32("features.%d.weight" % i) for i in conv_idx]
+    means = [f32("features.%d.running_mean" % i) for i in bn_idx]
+    vars_ = [f32("features.%d.running_var" % i) for i in bn_idx]
+    head_w = f32("features.19.weight")
+    head_b = f32("features.19.bias") if "features.19.bias" in sd else None
+    hbm = f32("features.20.running_mean") if kind == _lib.NET_HARDNET else None
+    hbv = f32("features.20.running_var") if kind == _lib.NET_HARDNET else None
+    keep += convs + means + vars_ + [head_w, head_b, hbm, hbv]
+    arr = lambda ts: (C.c_void_p * 6)(*[t.data_ptr() for t in ts])
+    n = lib.affnet_cnn32_packed_floats(kind)
+    out = torch.empty(n, dtype=torch.float32)
+    rc = lib.affnet_cnn32_pack_weights(kind, arr(convs), arr(means), arr(vars_), ptr(head_w), ptr(head_b), ptr(hbm), ptr(hbv), ptr(out))
+    check(rc, None, "affnet_cnn32_pack_weights")
+    del keep
+    return out
+
+
+def cnn_forward(kind, packed, patches, scratch=None):
+    """patches (n,1,32,32) or (n,32,32) cuda fp32 -> (n,2,2) / (n,128)."""
+    require_cuda(patches, "patches")
+    if patches.dim() == 4:
+        if patches.size(1) != 1:
+            raise ValueError("expected single-channel patches")
+        patches = patches[:, 0]
+    if tuple(patches.shape[1:]) != (32, 32):
+        raise ValueError("the HIP CNN kernels are specialised for 32x32 patches, got %s" % (tuple(patches.shape),))
+    patches = patches.contiguous().float()
+    n = patches.size(0)
+    dev = patches.device
+    out = torch.empty((n, 128) if kind == _lib.NET_HARDNET else (n, 2, 2), dtype=torch.float32, device=dev)
+    if n == 0:
+        return out
+    if kind == _lib.NET_HARDNET and scratch is None:
+        scratch = torch.empty(n * 8192, dtype=torch.float32, device=dev)
+    ctx = utility_ctx(dev)
+    rc = lib.affnet_cnn32_forward(ctx, kind, ptr(packed), ptr(patches), None, n, ptr(out), ptr(scratch), stream_of(dev))
+    check(rc, ctx, "affnet_cnn32_forward")
+    return out
+
+
+def base_grid(ps):
+    buf = (C.c_float * ps)()
+    check(lib.affnet_host_base_grid(ps, buf), None, "affnet_host_base_grid")
+    return np.array(buf, dtype=np.float32)

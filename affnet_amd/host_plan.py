@@ -1,0 +1,87 @@
+"""Host-side mirror of the reference's pyramid bookkeeping: octave sizes, level sigmas, Gaussian
+tap tables.  Fills the affnet_config struct of include/affnet_hip.h.
+
+Follows HandCraftedModules.py:14-56 (ScalePyramid) and Utils.py:92-114,155-161
+(CircularGaussKernel / GaussianBlur.calculate_weights) under Python-3 semantics (`kernlen / 2`
+is a true division), which is the behaviour the parity oracle pins.  Keeping these formulas on
+the host means device code never hard-codes a Gaussian.
+"""
+import numpy as np
+
+from . import _lib
+
+
+def gaussian_taps(sigma):
+    """(k, k) float32 taps, k = int(6 sigma + 1) | 1, sampled at linspace(-k/2, k/2, k)."""
+    k = int(2.0 * 3.0 * sigma + 1.0)
+    k += (k % 2 == 0)
+    half = k / 2
+    ax = np.linspace(-half, half, k)
+    xv, yv = np.meshgrid(ax, ax, sparse=False, indexing="xy")
+    ker = np.exp(-((xv ** 2 + yv ** 2) / (2.0 * sigma * sigma)))
+    ker /= np.sum(ker)
+    return ker.astype(np.float32)
+
+
+class PyramidPlan(object):
+    def __init__(self, height, width, n_levels=3, init_sigma=1.6, border=5):
+        self.height, self.width = int(height), int(width)
+        self.n_levels, self.init_sigma, self.border = n_levels, init_sigma, border
+        step = 2 ** (1.0 / float(n_levels))
+        min_size = 2 * border + 2 + 1
+        cur = 0.5
+        self.first_blur_sigma = None
+        if init_sigma > cur:
+            self.first_blur_sigma = float(np.sqrt(init_sigma ** 2 - cur ** 2))
+            cur = init_sigma
+        self.sizes, self.sigmas, self.pix_dists = [], [], []
+        self.blur_sigmas = None
+        h, w, pix = self.height, self.width, 1.0
+        while True:
+            lev, blur = [cur], []
+            for _ in range(1, n_levels + 2):
+                blur.append(float(cur * np.sqrt(step * step - 1.0)))
+                cur *= step
+                lev.append(cur)
+            if self.blur_sigmas is None:
+                self.blur_sigmas = blur  # identical for every octave: curSigma restarts at init_sigma
+            self.sizes.append((h, w))
+            self.sigmas.append(lev)
+            self.pix_dists.append([pix] * len(lev))
+            nh, nw = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+            pix *= 2.0
+            cur = init_sigma
+            if nh <= min_size or nw <= min_size:
+                break
+            h, w = nh, nw
+        self.n_octaves = len(self.sizes)
+        self.levels_per_octave = n_levels + 2
+
+    def fill_config(self, mr_size, threshold, num_features, num_prefilter, max_keep=16384, raw_div=4):
+        if self.n_octaves > _lib.MAX_OCTAVES or self.levels_per_octave > _lib.MAX_LEVELS:
+            raise ValueError("pyramid too deep for the library limits")
+        c = _lib.Config()
+        c.height, c.width = self.height, self.width
+        c.n_octaves, c.levels_per_octave = self.n_octaves, self.levels_per_octave
+        for o, (h, w) in enumerate(self.sizes):
+            c.oct_h[o], c.oct_w[o] = h, w
+            for l, s in enumerate(self.sigmas[o]):
+                c.level_sigma[o][l] = np.float32(s)
+                c.level_sigma4[o][l] = np.float32(s ** 4)   # tensor * python float -> float32 scalar
+                c.level_sigma_px[o][l] = float(np.array(s) * np.array(self.pix_dists[o][l]))
+        if self.first_blur_sigma is not None:
+            t = gaussian_taps(self.first_blur_sigma)
+            c.first_blur_taps = t.shape[0]
+            for i, v in enumerate(t.reshape(-1)):
+                c.first_blur[i] = v
+        for l, s in enumerate(self.blur_sigmas, start=1):
+            t = gaussian_taps(s)
+            if t.shape[0] > 21:
+                raise ValueError("Gaussian of %d taps not supported by the blur kernel (max 21)" % t.shape[0])
+            c.level_blur_taps[l] = t.shape[0]
+            for i, v in enumerate(t.reshape(-1)):
+                c.level_blur[l][i] = v
+        c.mr_size, c.threshold = float(mr_size), float(threshold)
+        c.num_features, c.num_prefilter = int(num_features), int(num_prefilter)
+        c.max_raw_per_octave_div, c.max_keep = int(raw_div), int(max_keep)
+        return c

@@ -1,0 +1,247 @@
+/*
+ * affnet_hip.h - C ABI of libaffnet_hip.so: the MI355X (gfx950) implementation of the
+ * ScaleSpaceAffinePatchExtractor hot path of ducha-aiki/affnet.
+ *
+ * The reference has no FFI: its "plugin API" for this path is Python duck typing
+ * (SURVEY.md section 8b).  Each entry point below names the reference function(s) it replaces
+ * (file:line relative to the reference repo).  The host-side mirror that binds these
+ * symbols with ctypes is affnet_amd/_lib.py; INTEGRATION.md shows the stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *  - every `d_*` pointer is a DEVICE pointer owned by the caller (torch tensors in the
+ *    Python mirror); the library never allocates or frees device memory;
+ *  - `stream` is a hipStream_t passed as void* (NULL = the null stream); every call only
+ *    enqueues work on it and returns - no host synchronisation, no host read-back, except
+ *    the explicitly named affnet_read_counts();
+ *  - all functions return AFFNET_OK (0) or a negative error code; affnet_last_error(ctx)
+ *    returns a human readable message for the last failure on that context;
+ *  - a context is not re-entrant: one thread / one stream at a time per context (the
+ *    reference object is stateful in the same way, SparseImgRepresenter.py:55);
+ *  - all image / LAF / descriptor arithmetic is IEEE fp32, compiled with
+ *    -ffp-contract=off; fused multiply-adds are used only where the reference's CPU
+ *    kernels use them ("bit-exact detector").
+ */
+#ifndef AFFNET_HIP_H
+#define AFFNET_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AFFNET_OK 0
+#define AFFNET_ERR_INVALID (-1)   /* bad argument / unsupported configuration          */
+#define AFFNET_ERR_HIP (-2)       /* a HIP runtime call failed (message has details)   */
+#define AFFNET_ERR_CAPACITY (-3)  /* a fixed-capacity device list overflowed           */
+#define AFFNET_ERR_EMPTY (-4)     /* no detections (reference: torch.cat([]) raises)   */
+
+#define AFFNET_MAX_OCTAVES 16
+#define AFFNET_MAX_LEVELS 8       /* n_levels + 2 <= 8                                 */
+#define AFFNET_MAX_TAPS 31        /* Gaussian kernels up to 31 x 31                    */
+
+/* Network kinds for the 32x32-patch CNNs. */
+#define AFFNET_NET_AFFNET 0       /* architectures.py:204-252 AffNetFast               */
+#define AFFNET_NET_ORINET 1       /* architectures.py:33-82   OriNetFast               */
+#define AFFNET_NET_HARDNET 2      /* HardNet.py:61-101        HardNet                  */
+
+typedef struct affnet_ctx affnet_ctx;
+
+/*
+ * Static description of one extractor instance.  The host mirror fills it with the
+ * reference's own formulas (ScalePyramid.__init__/forward, HandCraftedModules.py:14-56;
+ * CircularGaussKernel, Utils.py:92-114) so that no Gaussian / sigma formula is baked into
+ * device code (SURVEY.md section 7 "hard parts": py2-vs-py3 semantics live on the host).
+ */
+typedef struct affnet_config {
+    int32_t height, width;                 /* input image size                                         */
+    int32_t n_octaves;                     /* result of the stop rule (HandCraftedModules.py:50)       */
+    int32_t levels_per_octave;             /* nLevels + 2 (5)                                          */
+    int32_t oct_h[AFFNET_MAX_OCTAVES];     /* octave sizes: avg_pool2d(k=1,s=2) => ceil(h/2)           */
+    int32_t oct_w[AFFNET_MAX_OCTAVES];
+    float level_sigma[AFFNET_MAX_OCTAVES][AFFNET_MAX_LEVELS];  /* sigmas[o][l]  (centroid weights)    */
+    float level_sigma4[AFFNET_MAX_OCTAVES][AFFNET_MAX_LEVELS]; /* float32(sigma**4) (HessianResp)     */
+    double level_sigma_px[AFFNET_MAX_OCTAVES][AFFNET_MAX_LEVELS]; /* sigma*pix_dist, float64 (LAF.py:459) */
+    int32_t first_blur_taps;               /* 0 = no initial blur (init_sigma <= 0.5)                  */
+    float first_blur[AFFNET_MAX_TAPS * AFFNET_MAX_TAPS];       /* k x k, row-major                    */
+    int32_t level_blur_taps[AFFNET_MAX_LEVELS];                /* blur producing level l (l>=1)       */
+    float level_blur[AFFNET_MAX_LEVELS][AFFNET_MAX_TAPS * AFFNET_MAX_TAPS];
+    float mr_size;                         /* mrSize (ctor kwarg, SparseImgRepresenter.py:19)          */
+    float threshold;                       /* th; responses are clamp(resp - th, 0) (:77)              */
+    int32_t num_features;                  /* N; <= 0: keep everything (th given => num = -1, :33-35)  */
+    int32_t num_prefilter;                 /* C = int(1.5 N) if Baumberg iters > 0 else N (:192-194)   */
+    int32_t max_raw_per_octave_div;        /* raw-maxima capacity of octave o = h*w / div (default 4)  */
+    int32_t max_keep;                      /* capacity of the selected list when N <= 0                */
+} affnet_config;
+
+/* ---- context ------------------------------------------------------------------------------- */
+
+/* Creates a context bound to HIP device `device` (one context per (device, stream) user).
+ * cfg == NULL creates a utility context for the stand-alone stage calls that do not touch the
+ * pyramid (gauss_blur, hessian_response, laf_grid_sample, cnn32_forward, apply_rotation, scale_lafs). */
+int affnet_ctx_create(affnet_ctx** out, int device, const affnet_config* cfg);
+void affnet_ctx_destroy(affnet_ctx* ctx);
+const char* affnet_last_error(const affnet_ctx* ctx);
+/* Library / build identification, e.g. "affnet_hip 0.1 gfx950". */
+const char* affnet_version(void);
+
+/* Bytes of caller-owned device workspace the context needs (pyramid + detector lists +
+ * CNN scratch).  Offsets into it are exposed so the host mirror can present the pyramid as
+ * tensors (`scale_pyr`, SparseImgRepresenter.py:55). */
+size_t affnet_workspace_bytes(const affnet_ctx* ctx);
+int affnet_bind_workspace(affnet_ctx* ctx, void* d_workspace, size_t bytes);
+/* Float offset (from the workspace base) of pyramid level (o, l); -1 if out of range. */
+int64_t affnet_pyramid_level_offset(const affnet_ctx* ctx, int octave, int level);
+/* Maximum number of rows the detector / shape stages can emit (C and N capacities). */
+int affnet_capacity_prefilter(const affnet_ctx* ctx);
+int affnet_capacity_final(const affnet_ctx* ctx);
+
+/* ---- stage entry points -------------------------------------------------------------------- */
+
+/* Gaussian blur of one image: replicate padding + full 2-D k x k cross-correlation
+ * accumulated with fmaf in row-major tap order (bit-identical to the reference's conv2d on
+ * CPU).  Replaces Utils.py:150-166 (GaussianBlur.forward).  `h_taps` is a HOST pointer to
+ * k*k floats. */
+int affnet_gauss_blur(affnet_ctx* ctx, const float* d_in, float* d_out, int h, int w,
+                      const float* h_taps, int k, void* stream);
+
+/* Whole scale pyramid into the bound workspace.  Replaces ScalePyramid.forward,
+ * HandCraftedModules.py:23-56.  d_img: (H, W) fp32, 0..255. */
+int affnet_pyramid_build(affnet_ctx* ctx, const float* d_img, void* stream);
+
+/* Hessian response of one level (for the RespNet slot / tests).  Replaces
+ * HessianResp.forward, HandCraftedModules.py:74-78.  sigma4 = float32(sigma**4). */
+int affnet_hessian_response(affnet_ctx* ctx, const float* d_in, float* d_out, int h, int w,
+                            float sigma4, void* stream);
+
+/* Detector on the pyramid in the workspace: Hessian response, clamp(resp - th, 0), 3-D NMS,
+ * border zeroing, octaveMap masking (uint8 wrap emulated), response-weighted 27-tap
+ * centroid, per-level and global top-k (C = num_prefilter), x mrSize.
+ * Replaces SparseImgRepresenter.py:53-111,198 + HandCraftedModules.py:208-291 +
+ * Utils.py:116-148 + LAF.py:431-441.
+ * Outputs (capacity affnet_capacity_prefilter rows; rows >= count are zero):
+ *   d_resp (cap) fp32, d_lafs (cap,2,3) fp32 normalised LAFs (A scaled by mrSize),
+ *   d_ids (cap,3) int32 = (octave, level-1 "prevBlur", flat pixel index),
+ *   d_count (1) int32 number of valid rows.
+ * Row order = the reference's: descending response when more than C candidates exist,
+ * otherwise (octave, level, pixel) order. */
+int affnet_detect(affnet_ctx* ctx, float* d_resp, float* d_lafs, int32_t* d_ids,
+                  int32_t* d_count, void* stream);
+
+/* Affine patch sampler: affine_grid + bilinear grid_sample, zeros padding,
+ * align_corners=False, including the reference's fp32 coordinate round trip.
+ * Replaces LAF.py:313-324,326-372 (generate_patch_grid_from_normalized_LAFs,
+ * batched_grid_apply, extract_patches).  d_img (h,w) one level; d_lafs (n,2,3) normalised;
+ * d_out (n, ps, ps). */
+int affnet_laf_grid_sample(affnet_ctx* ctx, const float* d_img, int h, int w,
+                           const float* d_lafs, int n, int ps, float* d_out, void* stream);
+
+/* Same, gathering each patch from pyramid level d_ids[i] = (octave, level, *) of the bound
+ * workspace; only rows < *d_count are written (d_count may be NULL => n_max rows).
+ * Replaces LAF.py:376-404 (inverted index + per-level extraction). */
+int affnet_pyr_grid_sample(affnet_ctx* ctx, const float* d_lafs, const int32_t* d_ids,
+                           const int32_t* d_count, int n_max, int ps, float* d_out, void* stream);
+
+/* ---- CNNs ---------------------------------------------------------------------------------- */
+
+/* Number of floats of the packed (BN-folded, MFMA-ordered) weight blob of a network. */
+size_t affnet_cnn32_packed_floats(int net_kind);
+/* Packs a state dict on the HOST.  conv_w[i] (i=0..5): trunk conv weights (Cout,Cin,3,3);
+ * bn_mean[i], bn_var[i]: running stats (eps 1e-5, affine=False) folded into weight+bias;
+ * head_w / head_b: final conv (AffNet (3,64,8,8)+bias, OriNet (2,64,8,8)+bias,
+ * HardNet (128,128,8,8), no bias, followed by BN head_bn_mean/var).
+ * h_out receives affnet_cnn32_packed_floats(kind) floats; the caller uploads them.
+ * Replaces the nn.Sequential definitions architectures.py:207-229,36-59, HardNet.py:67-89. */
+int affnet_cnn32_pack_weights(int net_kind, const float* const* conv_w, const float* const* bn_mean,
+                              const float* const* bn_var, const float* head_w, const float* head_b,
+                              const float* head_bn_mean, const float* head_bn_var, float* h_out);
+
+/* Forward of one network on n 32x32 patches (d_patches (n,32,32) fp32, raw intensities; the
+ * per-patch mean / unbiased-std normalisation is fused).
+ *   AffNet : d_out (n,2,2) rectified affine shape      (architectures.py:246-252, LAF.py:285-291)
+ *   OriNet : d_out (n,2,2) rotation matrix             (architectures.py:76-82,  LAF.py:276-283)
+ *   HardNet: d_out (n,128) L2-normalised descriptor    (HardNet.py:98-101)
+ * Only rows < *d_count are computed when d_count != NULL.  d_scratch: HardNet needs
+ * n*8192 floats for the trunk output (NULL for the other nets). */
+int affnet_cnn32_forward(affnet_ctx* ctx, int net_kind, const float* d_packed, const float* d_patches,
+                         const int32_t* d_count, int n_max, float* d_out, float* d_scratch, void* stream);
+
+/* Same, but each 32x32 input patch is sampled on the fly from the pyramid in the workspace
+ * (fused affnet_pyr_grid_sample + affnet_cnn32_forward; no patch tensor in HBM). */
+int affnet_cnn32_forward_pyr(affnet_ctx* ctx, int net_kind, const float* d_packed, const float* d_lafs,
+                             const int32_t* d_ids, const int32_t* d_count, int n_max, float* d_out,
+                             float* d_scratch, void* stream);
+
+/* Debug / parity aid: runs the trunk on ONE patch and copies the activation tensor after
+ * trunk layer `layer` (0..5, post BN+ReLU, (C,H,W) fp32) to d_out. */
+int affnet_cnn32_debug_layer(affnet_ctx* ctx, int net_kind, const float* d_packed, const float* d_patch,
+                             int layer, float* d_out, void* stream);
+
+/* ---- LAF stages ---------------------------------------------------------------------------- */
+
+/* base_A = A; new_LAF = [A * LAF_2x2 | centre]; keep rows with 1/6 < |l1/(l2+1e-8)| < 6 and
+ * all four frame corners inside [0,1]^2; if more than N survive take the N largest
+ * responses (bad rows zeroed first), else keep survivors in order.
+ * Replaces SparseImgRepresenter.py:121-162 (num_Baum_iters == 1), Utils.py:168-175,
+ * LAF.py:91-104.  Inputs have *d_count_in valid rows (capacity C); outputs capacity N
+ * (or C when N <= 0). */
+int affnet_shape_filter_select(affnet_ctx* ctx, const float* d_resp_in, const float* d_lafs_in,
+                               const int32_t* d_ids_in, const float* d_A, const int32_t* d_count_in,
+                               float* d_resp_out, float* d_lafs_out, int32_t* d_ids_out,
+                               int32_t* d_count_out, void* stream);
+
+/* LAF_2x2 <- LAF_2x2 * R for rows < *d_count.  SparseImgRepresenter.py:173-177. */
+int affnet_apply_rotation(affnet_ctx* ctx, float* d_lafs, const float* d_R, const int32_t* d_count,
+                          int n_max, void* stream);
+
+/* LAFs <- LAFs * [[m,m,W],[m,m,H]] (inverse=0) or / (inverse=1), m = min(H,W).
+ * LAF.py:407-429 (denormalizeLAFs / normalizeLAFs). */
+int affnet_scale_lafs(affnet_ctx* ctx, const float* d_in, float* d_out, const int32_t* d_count, int n_max,
+                      int w, int h, int inverse, void* stream);
+
+/* Pyramid level for descriptor patches: argmin over (o,l) of |sigma[o][l]*2^o - sqrt|det A|/PS|
+ * in float64, first minimum wins; also writes normalised LAFs (by pyr[0][0] size).
+ * Replaces LAF.py:450-472 (host scipy cdist round trip) + SparseImgRepresenter.py:181-188.
+ * d_lafs_px (n,2,3) pixel LAFs -> d_ids (n,3) (octave, level, 0), d_lafs_norm (n,2,3). */
+int affnet_level_select(affnet_ctx* ctx, const float* d_lafs_px, const int32_t* d_count, int n_max,
+                        int ps, int32_t* d_ids, float* d_lafs_norm, void* stream);
+
+/* ---- fused pipeline ------------------------------------------------------------------------ */
+
+typedef struct affnet_nets {
+    const float* d_affnet;   /* packed AffNet weights, NULL => num_Baum_iters = 0            */
+    const float* d_orinet;   /* packed OriNet weights, NULL => do_ori must be 0              */
+    const float* d_hardnet;  /* packed HardNet weights, NULL => no descriptors               */
+} affnet_nets;
+
+/* Whole path, image resident -> results resident, zero host synchronisation:
+ * pyramid -> detect -> [AffNet shape + filter] -> [OriNet] -> denormalise ->
+ * [level select -> sample -> HardNet].
+ * Replaces ScaleSpaceAffinePatchExtractor.forward (SparseImgRepresenter.py:189-209) +
+ * extract_patches_from_pyr (:181-188) + HardNet forward = get_geometry_and_descriptors
+ * (train_OriNet_test_on_graffity.py:293-298).
+ * Outputs (capacity affnet_capacity_final rows): d_lafs_px (cap,2,3), d_resp (cap),
+ * d_ids (cap,3) (octave, level-1, pixel) of the detection, d_desc (cap,128) or NULL,
+ * d_count (1). */
+int affnet_extract_features(affnet_ctx* ctx, const affnet_nets* nets, const float* d_img, int do_ori,
+                            float* d_lafs_px, float* d_resp, int32_t* d_ids, float* d_desc,
+                            int32_t* d_count, void* stream);
+
+/* The one optional read-back: copies counters to the host after synchronising `stream`:
+ * out[0] = rows after detection, out[1] = rows after shape filter, out[2] = capacity-overflow
+ * flag (non-zero => AFFNET_ERR_CAPACITY semantics), out[3] = raw maxima found. */
+int affnet_read_counts(affnet_ctx* ctx, int32_t out[4], void* stream);
+
+/* Host helper (no GPU): out[ps] = affine_grid base coordinates (linspace(-1,1,ps)*(ps-1))/ps with
+ * torch's CPU rounding; exported so the CPU test-suite can pin it against torch.linspace. */
+int affnet_host_base_grid(int ps, float* out);
+
+/* 16x16x4 fp32 MFMA layout self-test: d_out (16,16) = A (16,4) * B (4,16). */
+int affnet_selftest_mfma(const float* d_A, const float* d_B, float* d_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AFFNET_HIP_H */

@@ -1,0 +1,174 @@
+"""CPU: the C-ABI library loads and exports every declared symbol; the host-side mirror
+(tap tables, pyramid plan, weight packing, affine_grid base coordinates) agrees with the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import affnet_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from affnet_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "affnet_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(affnet_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
+    raw = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert b"gfx950" in _lib.lib.affnet_version()
+    assert C.sizeof(_lib.Config) > 30000  # struct mirrors the 8 x 31x31 tap tables
+
+
+def test_base_grid_matches_torch_affine_grid():
+    from affnet_amd import engine
+    for ps in list(range(2, 65)):
+        ref = (torch.linspace(-1, 1, ps) * (ps - 1) / ps).numpy()
+        assert np.array_equal(engine.base_grid(ps), ref), ps
+    theta = torch.tensor([[[1.0, 0, 0], [0, 1.0, 0]]])
+    g = F.affine_grid(theta, torch.Size((1, 1, 32, 32)), align_corners=False)
+    assert np.array_equal(g[0, 0, :, 0].numpy(), engine.base_grid(32))
+
+
+@pytest.mark.parametrize("hw", [(768, 1024), (640, 800), (2160, 3840), (240, 320), (65, 97)])
+def test_pyramid_plan_and_taps_match_oracle(hw):
+    from affnet_amd.host_plan import PyramidPlan, gaussian_taps
+    plan = PyramidPlan(hw[0], hw[1], 3, 1.6, 5)
+    ref = orc.pyramid_plan(hw[0], hw[1], 3, 1.6, 5)
+    assert plan.sizes == [(o["h"], o["w"]) for o in ref["octaves"]]
+    assert plan.sigmas == [o["level_sigmas"] for o in ref["octaves"]]
+    assert plan.blur_sigmas == ref["octaves"][0]["blur_sigmas"]
+    for s in [plan.first_blur_sigma] + plan.blur_sigmas:
+        assert np.array_equal(gaussian_taps(s), orc.gauss_kernel_2d(s)[0])
+    cfg = plan.fill_config(5.192, 0.0, 2000, 3000)
+    assert cfg.n_octaves == len(ref["octaves"]) and cfg.level_blur_taps[1] == 9 and cfg.level_blur_taps[4] == 15
+    assert cfg.first_blur_taps == 11
+    assert np.float32(cfg.level_sigma4[0][2]) == np.float32(plan.sigmas[0][2] ** 4)
+
+
+def test_context_layout_no_gpu_needed():
+    from affnet_amd import _lib
+    from affnet_amd.host_plan import PyramidPlan
+    cfg = PyramidPlan(768, 1024).fill_config(5.192, 0.0, 2000, 3000)
+    h = C.c_void_p()
+    assert _lib.lib.affnet_ctx_create(C.byref(h), 0, C.byref(cfg)) == 0
+    nbytes = _lib.lib.affnet_workspace_bytes(h)
+    assert 20e6 * 4 < nbytes < 400e6
+    assert _lib.lib.affnet_capacity_prefilter(h) == 3000 and _lib.lib.affnet_capacity_final(h) == 2000
+    o00, o01, o10 = (_lib.lib.affnet_pyramid_level_offset(h, *a) for a in [(0, 0), (0, 1), (1, 0)])
+    assert o01 - o00 == 768 * 1024 and o10 - o00 == 5 * 768 * 1024
+    assert _lib.lib.affnet_pyramid_level_offset(h, 6, 0) == -1
+    # error behaviour: unbound workspace -> ERR_INVALID + message
+    rc = _lib.lib.affnet_pyramid_build(h, None, None)
+    assert rc == _lib.ERR_INVALID and b"not bound" in _lib.lib.affnet_last_error(h)
+    bad = PyramidPlan(768, 1024).fill_config(5.192, 0.0, 2000, 3000)
+    bad.oct_h[1] = 100
+    h2 = C.c_void_p()
+    assert _lib.lib.affnet_ctx_create(C.byref(h2), 0, C.byref(bad)) == _lib.ERR_INVALID
+    _lib.lib.affnet_ctx_destroy(h)
+    _lib.lib.affnet_ctx_destroy(h2)
+
+
+def _unpack_trunk(kind, blob):
+    """Rebuilds conv weights / biases from the packed blob (the layout cnn32.hip documents)."""
+    cb = 32 if kind == 2 else 16
+    ch = [1, cb, cb, 2 * cb, 2 * cb, 4 * cb, 4 * cb]
+    off, layers = 0, []
+    for i in range(6):
+        ci, co = ch[i], ch[i + 1]
+        w = blob[off:off + 9 * ci * co]
+        off += 9 * ci * co
+        b = blob[off:off + co]
+        off += co
+        off = (off + 3) & ~3
+        if i == 0:
+            W = w.view(co, 1, 3, 3)
+        else:
+            W = w.view(9, ci, co).permute(2, 1, 0).reshape(co, ci, 3, 3)
+        layers.append((W.contiguous(), b.clone()))
+    return layers, off
+
+
+@pytest.mark.parametrize("kind,name", [(0, "AffNet"), (1, "OriNet"), (2, "HardNet")])
+def test_packed_weights_reproduce_the_network(kind, name, weights):
+    """BN folding + packing order: a torch-CPU forward driven ONLY by the packed blob equals the oracle."""
+    from affnet_amd import engine
+    sd = weights[name]
+    blob = engine.pack_state_dict(kind, sd)
+    layers, off = _unpack_trunk(kind, blob)
+    g = torch.Generator().manual_seed(3)
+    p = torch.rand(6, 1, 32, 32, generator=g) * 255
+    x = orc.input_norm(p)
+    for i, (W, b) in enumerate(layers):
+        x = F.relu(F.conv2d(x, W, b, stride=2 if i in (2, 4) else 1, padding=1))
+    if kind == 2:
+        Bw = blob[off:off + 8192 * 128].view(8192, 128)
+        bias = blob[off + 8192 * 128: off + 8192 * 128 + 128]
+        y = x.reshape(6, -1) @ Bw + bias
+        got = y / torch.sqrt((y * y).sum(1, keepdim=True) + 1e-8)
+        want = orc.hardnet_forward(sd, p)
+    elif kind == 0:
+        hw = blob[off:off + 3 * 4096].view(3, 4096)
+        hb = blob[off + 3 * 4096: off + 3 * 4096 + 3]
+        t = torch.tanh(x.reshape(6, -1) @ hw.t() + hb)
+        A = torch.zeros(6, 2, 2)
+        A[:, 0, 0], A[:, 1, 0], A[:, 1, 1] = 1 + t[:, 0], t[:, 1], 1 + t[:, 2]
+        got, want = orc.rectify_up_is_up(A), orc.affnet_forward(sd, p)
+    else:
+        hw = blob[off:off + 2 * 4096].view(2, 64, 8, 8)
+        hb = blob[off + 2 * 4096: off + 2 * 4096 + 2]
+        t = torch.tanh(F.conv2d(x, hw, hb, padding=1)).mean(dim=(2, 3))
+        got = orc.rotation_matrix(torch.atan2(t[:, 0] + 1e-8, t[:, 1] + 1e-8))
+        want = orc.orinet_forward(sd, p)
+    assert float((got - want).abs().max()) < 2e-5
+
+
+def test_reference_checkpoints_load_into_the_mirrors(weights):
+    import affnet_amd
+    A = affnet_amd.AffNetFast(PS=32)
+    A.load_state_dict(weights["AffNet"])
+    O = affnet_amd.OriNetFast(PS=32)
+    O.load_state_dict(weights["OriNet"])
+    Hn = affnet_amd.HardNet()
+    Hn.load_state_dict(weights["HardNet"])
+    assert A.PS == 32 and O.PS == 32 and sorted(k for k in A.state_dict() if "num_batches" not in k) == sorted(weights["AffNet"])
+
+
+def test_no_cpu_fallback_and_unbuilt_slots_fail_loudly(weights):
+    import affnet_amd
+    A = affnet_amd.AffNetFast(PS=32)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        A(torch.zeros(2, 1, 32, 32))
+    det = affnet_amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=100, border=5, num_Baum_iters=1, AffNet=A)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        det(torch.zeros(1, 1, 64, 64))
+    with pytest.raises(NotImplementedError):
+        affnet_amd.ScaleSpaceAffinePatchExtractor(num_Baum_iters=1)           # Baumberg default slot: section 8f
+    with pytest.raises(NotImplementedError):
+        affnet_amd.ScaleSpaceAffinePatchExtractor(RespNet=lambda x, s: x)
+    d = affnet_amd.ScaleSpaceAffinePatchExtractor(th=28.41)
+    assert d.num == -1                                                        # SparseImgRepresenter.py:33-35
+    with pytest.raises(RuntimeError, match="forward"):
+        d.extract_patches_from_pyr(torch.zeros(1, 2, 3))
+
+
+def test_exact_arithmetic_spec_of_the_blur():
+    """Documents WHY the HIP blur is bit-exact: torch's CPU conv2d == row-major sequential fmaf chain."""
+    x = orc.synthetic_image(40, 56, 5)
+    ker, pad = orc.gauss_kernel_2d(1.2262734984654078)
+    ref = orc.gaussian_blur(x, 1.2262734984654078)[0, 0].numpy()
+    xp = np.pad(x[0, 0].numpy(), pad, mode="edge")
+    acc = np.zeros_like(ref)
+    k = ker.shape[0]
+    for i in range(k):
+        for j in range(k):
+            acc = (xp[i:i + 40, j:j + 56].astype(np.float64) * np.float64(ker[i, j]) + acc.astype(np.float64)).astype(np.float32)
+    assert np.array_equal(acc, ref)
