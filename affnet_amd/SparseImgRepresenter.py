@@ -72,9 +72,9 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
     def _native(slot):
         return slot is None or isinstance(slot, _HipPatchNet)
 
-    def run(self, x, do_ori=False, desc=None):
-        """Fused path.  Returns dict(LAFs px (N,2,3), responses (N,), ids (N,3), descriptors (N,128)|None).
-        `desc`: affnet_amd.HardNet.HardNet or None."""
+    def enqueue(self, x, do_ori=False, desc=None):
+        """Enqueues the whole fused path on the current stream and returns capacity-sized device
+        tensors plus the device row count - no host synchronisation (throughput / multi-stream use)."""
         ctx = self._context(x)
         dev = x.device
         if do_ori and self.OriNet is None:
@@ -93,13 +93,22 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
         rc = lib.affnet_extract_features(ctx.handle, C.byref(nets), ptr(img), int(bool(do_ori)), ptr(lafs), ptr(resp), ptr(ids),
                                          ptr(dsc), ptr(count), engine.stream_of(dev))
         check(rc, ctx.handle, "affnet_extract_features")
+        return {"LAFs": lafs, "responses": resp, "ids": ids, "descriptors": dsc, "count": count, "_img": img}
+
+    def run(self, x, do_ori=False, desc=None):
+        """Fused path.  Returns dict(LAFs px (N,2,3), responses (N,), ids (N,3), descriptors (N,128)|None).
+        `desc`: affnet_amd.HardNet.HardNet or None."""
+        r = self.enqueue(x, do_ori=do_ori, desc=desc)
+        ctx = self._ctx
         self._publish_pyramid(ctx)
         counts = ctx.read_counts()          # the one host read-back (also surfaces capacity overflow)
-        n = int(count.item())
+        n = int(r["count"].item())
         if counts[0] == 0:
             raise RuntimeError("no keypoints detected (the reference raises in torch.cat, SparseImgRepresenter.py:100)")
-        self.last_ids = ids[:n]
-        return {"LAFs": lafs[:n], "responses": resp[:n], "ids": ids[:n], "descriptors": None if dsc is None else dsc[:n]}
+        self.last_ids = r["ids"][:n]
+        dsc = r["descriptors"]
+        return {"LAFs": r["LAFs"][:n], "responses": r["responses"][:n], "ids": r["ids"][:n],
+                "descriptors": None if dsc is None else dsc[:n]}
 
     # ------------------------------------------------------------------------------------------
     def _staged(self, x, do_ori):

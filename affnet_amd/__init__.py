@@ -7,5 +7,6 @@ from .SparseImgRepresenter import ScaleSpaceAffinePatchExtractor, get_geometry_a
 from .architectures import AffNetFast, OriNetFast  # noqa: F401
 from .HardNet import HardNet  # noqa: F401
 from . import LAF  # noqa: F401
+from .synthetic import synthetic_image, synthetic_hardnet_state  # noqa: F401
 
 __version__ = "0.1.0"

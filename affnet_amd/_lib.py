@@ -63,6 +63,8 @@ SYMBOLS = {
     "affnet_scale_lafs": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "affnet_level_select": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     "affnet_extract_features": (_I, [_P, C.POINTER(Nets), _P, _I, _P, _P, _P, _P, _P, _P]),
+    "affnet_profile_enable": (_I, [_P, _I]),
+    "affnet_profile_read": (_I, [_P, C.POINTER(C.c_double * 8), C.POINTER(C.c_int32)]),
     "affnet_read_counts": (_I, [_P, C.POINTER(C.c_int32 * 4), _P]),
     "affnet_host_base_grid": (_I, [_I, C.POINTER(C.c_float)]),
     "affnet_selftest_mfma": (_I, [_P, _P, _P, _P]),

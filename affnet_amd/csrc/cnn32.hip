@@ -539,7 +539,8 @@ void aff_fill_pyr_src(const affnet_ctx* ctx, PyrSrc* t) {
 }
 
 static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const float* patches, const float* lafs, const int32_t* ids,
-                      const int32_t* count, int n_max, float* out, float* scratch, int dbg_layer, float* dbg_out, hipStream_t st) {
+                      const int32_t* count, int n_max, float* out, float* scratch, int dbg_layer, float* dbg_out, hipStream_t st,
+                      bool mark_head = false) {
     if (kind < 0 || kind > 2) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: unknown net kind %d", kind);
     if (!packed || !out || n_max < 0 || (!patches && (!lafs || !ids))) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: null argument");
     if (!patches && !ctx->ws) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: sampling from the pyramid needs a bound workspace");
@@ -557,6 +558,7 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
     else if (kind == AFFNET_NET_ORINET) hipLaunchKernelGGL(cnn32_trunk_kernel<AFFNET_NET_ORINET>, grid, block, 0, st, a, ps);
     else hipLaunchKernelGGL(cnn32_trunk_kernel<AFFNET_NET_HARDNET>, grid, block, 0, st, a, ps);
     AFF_LAUNCH_CHECK(ctx);
+    if (mark_head) aff_prof_mark(ctx, 7, st);
     if (kind == AFFNET_NET_HARDNET && dbg_layer < 0) {
         hipLaunchKernelGGL(hardnet_head_kernel, dim3(aff_cdiv(n_max, 16)), dim3(256), 0, st, scratch, packed + L.head_w, packed + L.head_b,
                            count, n_max, out);
@@ -575,6 +577,11 @@ extern "C" int affnet_cnn32_forward_pyr(affnet_ctx* ctx, int net_kind, const flo
                                         const int32_t* d_count, int n_max, float* d_out, float* d_scratch, void* stream) {
     if (!ctx) return AFFNET_ERR_INVALID;
     return cnn_launch(ctx, net_kind, d_packed, nullptr, d_lafs, d_ids, d_count, n_max, d_out, d_scratch, -1, nullptr, (hipStream_t)stream);
+}
+
+int aff_hardnet_forward_pyr_marked(affnet_ctx* ctx, const float* packed, const float* lafs, const int32_t* ids, const int32_t* count,
+                                   int n_max, float* out, float* scratch, hipStream_t st) {
+    return cnn_launch(ctx, AFFNET_NET_HARDNET, packed, nullptr, lafs, ids, count, n_max, out, scratch, -1, nullptr, st, true);
 }
 
 extern "C" int affnet_cnn32_debug_layer(affnet_ctx* ctx, int net_kind, const float* d_packed, const float* d_patch, int layer, float* d_out,

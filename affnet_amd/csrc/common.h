@@ -67,7 +67,15 @@ struct affnet_ctx {
     float* st_R = nullptr; float* st_lafs_norm = nullptr; int32_t* st_lvl_ids = nullptr;
     float* st_hard_scratch = nullptr;
     float* st_lafs_shaped = nullptr;
+    // stage profiling (HIP events on the caller's stream)
+    bool prof_on = false;
+    std::vector<hipEvent_t> prof_ev;   // ring: PROF_RING calls x (AFFNET_PROFILE_STAGES + 1) events
+    int prof_calls = 0;
 };
+
+#define PROF_RING 256
+// pipeline.hip / cnn32.hip: record stage boundary `idx` of the current call (no-op when disabled)
+void aff_prof_mark(affnet_ctx* ctx, int idx, hipStream_t st);
 
 int aff_fail(affnet_ctx* ctx, int code, const char* fmt, ...);
 
@@ -95,11 +103,6 @@ static inline int aff_cdiv(int a, int b) { return (a + b - 1) / b; }
 // (linspace = fma(step, i, start) / fma(-step, ps-1-i, end); verified bit-for-bit in
 // tests/test_host_mirror.py).
 void aff_base_grid(int ps, float* base);
-
-struct SampleGeom {        // per-level constants of the sampler
-    const float* img;
-    int h, w;
-};
 
 // Device: one bilinear sample.  Follows LAF.py:313-324 + F.affine_grid + F.grid_sample
 // (align_corners=False, zeros padding) operation by operation in fp32:

@@ -10,6 +10,41 @@
 // host (LAF.py:466).  The reference's discarded extra patch extraction (:178-179) is dropped.
 #include "common.h"
 
+void aff_prof_mark(affnet_ctx* ctx, int idx, hipStream_t st) {
+    if (!ctx->prof_on || ctx->prof_calls >= PROF_RING) return;
+    (void)hipEventRecord(ctx->prof_ev[(size_t)ctx->prof_calls * (AFFNET_PROFILE_STAGES + 1) + idx], st);
+}
+
+extern "C" int affnet_profile_enable(affnet_ctx* ctx, int on) {
+    if (!ctx) return AFFNET_ERR_INVALID;
+    if (on && ctx->prof_ev.empty()) {
+        ctx->prof_ev.resize((size_t)PROF_RING * (AFFNET_PROFILE_STAGES + 1));
+        for (auto& e : ctx->prof_ev) AFF_HIP(ctx, hipEventCreate(&e));
+    }
+    ctx->prof_on = on != 0;
+    ctx->prof_calls = 0;
+    return AFFNET_OK;
+}
+
+extern "C" int affnet_profile_read(affnet_ctx* ctx, double sum_ms[AFFNET_PROFILE_STAGES], int32_t* n_calls) {
+    if (!ctx || !sum_ms || !n_calls) return AFFNET_ERR_INVALID;
+    for (int s = 0; s < AFFNET_PROFILE_STAGES; ++s) sum_ms[s] = 0.0;
+    *n_calls = ctx->prof_calls;
+    for (int c = 0; c < ctx->prof_calls; ++c)
+        for (int s = 0; s < AFFNET_PROFILE_STAGES; ++s) {
+            float ms = 0.f;
+            const size_t b = (size_t)c * (AFFNET_PROFILE_STAGES + 1);
+            AFF_HIP(ctx, hipEventElapsedTime(&ms, ctx->prof_ev[b + s], ctx->prof_ev[b + s + 1]));
+            sum_ms[s] += ms;
+        }
+    ctx->prof_calls = 0;
+    return AFFNET_OK;
+}
+
+// HardNet with a stage mark between trunk and head (cnn32.hip)
+int aff_hardnet_forward_pyr_marked(affnet_ctx* ctx, const float* packed, const float* lafs, const int32_t* ids, const int32_t* count,
+                                   int n_max, float* out, float* scratch, hipStream_t st);
+
 extern "C" int affnet_extract_features(affnet_ctx* ctx, const affnet_nets* nets, const float* d_img, int do_ori, float* d_lafs_px,
                                        float* d_resp, int32_t* d_ids, float* d_desc, int32_t* d_count, void* stream) {
     if (!ctx || !ctx->ws || !nets || !d_img || !d_lafs_px || !d_resp || !d_ids || !d_count)
@@ -18,19 +53,24 @@ extern "C" int affnet_extract_features(affnet_ctx* ctx, const affnet_nets* nets,
     if (d_desc && !nets->d_hardnet) return aff_fail(ctx, AFFNET_ERR_INVALID, "extract_features: descriptors need HardNet weights");
     hipStream_t st = (hipStream_t)stream;
     const int P = ctx->cap_pre, F = ctx->cap_final;
+    aff_prof_mark(ctx, 0, st);
     int rc = affnet_pyramid_build(ctx, d_img, stream);
     if (rc) return rc;
+    aff_prof_mark(ctx, 1, st);
     int32_t* det_count = ctx->cnt + CNT_DET;
     rc = affnet_detect(ctx, ctx->st_det_resp, ctx->st_det_lafs, ctx->st_det_ids, nullptr, stream);
     if (rc) return rc;
+    aff_prof_mark(ctx, 2, st);
     if (nets->d_affnet) {
         rc = affnet_cnn32_forward_pyr(ctx, AFFNET_NET_AFFNET, nets->d_affnet, ctx->st_det_lafs, ctx->st_det_ids, det_count, P, ctx->st_A,
                                       nullptr, stream);
         if (rc) return rc;
+        aff_prof_mark(ctx, 3, st);
         rc = affnet_shape_filter_select(ctx, ctx->st_det_resp, ctx->st_det_lafs, ctx->st_det_ids, ctx->st_A, det_count, d_resp,
                                         ctx->st_lafs_shaped, d_ids, d_count, stream);
         if (rc) return rc;
     } else {
+        aff_prof_mark(ctx, 3, st);
         // num_Baum_iters == 0: detections pass through unchanged (C == N)
         if (F != P) return aff_fail(ctx, AFFNET_ERR_INVALID, "extract_features: without AffNet num_prefilter must equal num_features");
         AFF_HIP(ctx, hipMemcpyAsync(d_resp, ctx->st_det_resp, (size_t)F * sizeof(float), hipMemcpyDeviceToDevice, st));
@@ -39,6 +79,7 @@ extern "C" int affnet_extract_features(affnet_ctx* ctx, const affnet_nets* nets,
         AFF_HIP(ctx, hipMemcpyAsync(d_count, det_count, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
         AFF_HIP(ctx, hipMemcpyAsync(ctx->cnt + CNT_SHAPED, det_count, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
     }
+    aff_prof_mark(ctx, 4, st);
     if (do_ori) {
         rc = affnet_cnn32_forward_pyr(ctx, AFFNET_NET_ORINET, nets->d_orinet, ctx->st_lafs_shaped, d_ids, d_count, F, ctx->st_R, nullptr,
                                       stream);
@@ -46,15 +87,22 @@ extern "C" int affnet_extract_features(affnet_ctx* ctx, const affnet_nets* nets,
         rc = affnet_apply_rotation(ctx, ctx->st_lafs_shaped, ctx->st_R, d_count, F, stream);
         if (rc) return rc;
     }
+    aff_prof_mark(ctx, 5, st);
     rc = affnet_scale_lafs(ctx, ctx->st_lafs_shaped, d_lafs_px, d_count, F, ctx->cfg.width, ctx->cfg.height, 0, stream);
     if (rc) return rc;
     if (d_desc) {
         rc = affnet_level_select(ctx, d_lafs_px, d_count, F, 32, ctx->st_lvl_ids, ctx->st_lafs_norm, stream);
         if (rc) return rc;
         AFF_HIP(ctx, hipMemsetAsync(d_desc, 0, (size_t)F * 128 * sizeof(float), st));
-        rc = affnet_cnn32_forward_pyr(ctx, AFFNET_NET_HARDNET, nets->d_hardnet, ctx->st_lafs_norm, ctx->st_lvl_ids, d_count, F, d_desc,
-                                      ctx->st_hard_scratch, stream);
+        aff_prof_mark(ctx, 6, st);
+        rc = aff_hardnet_forward_pyr_marked(ctx, nets->d_hardnet, ctx->st_lafs_norm, ctx->st_lvl_ids, d_count, F, d_desc,
+                                            ctx->st_hard_scratch, st);
         if (rc) return rc;
+    } else {
+        aff_prof_mark(ctx, 6, st);
+        aff_prof_mark(ctx, 7, st);
     }
+    aff_prof_mark(ctx, 8, st);
+    if (ctx->prof_on && ctx->prof_calls < PROF_RING) ++ctx->prof_calls;
     return AFFNET_OK;
 }

@@ -1,0 +1,182 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path on MI355X (see the contract in DESIGN.md "Measurement").
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" = one pass of the whole hot path (pyramid -> Hessian/NMS detector -> AffNet -> filter ->
+OriNet -> level select -> HardNet) over one batch of 64 synthetic 1024x768 images, 2000 keypoints
+each (BASELINE.json configs[2], the configuration the metric is quoted on), per rank (weak scaling),
+images resident in HBM before the timed region, followed for N > 1 by the all_gather of the padded
+(count, LAFs, responses, descriptors) records.  value = keypoints returned by all ranks / max-over-ranks time.
+
+roofline   : dominant kernel = fused HardNet trunk (cnn32_trunk_kernel<2>, fp32 MFMA).  achieved =
+             algorithmic FLOPs per launch / mean launch duration measured with HIP events around that
+             launch on its own stream inside the timed region (affnet_profile_*).
+cpu_baseline: the CPU oracle (port of the reference, same torch CPU operators) on this host's cores
+             on a bounded sample of the same workload (rank 0, N == 1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H, W, NKP, BATCH = 768, 1024, 2000, 64
+# algorithmic work: 2*MAC per patch, dense, BN/ReLU/normalisation excluded
+FLOP_AFF, FLOP_ORI, FLOP_HARD = 19193856.0, 19316736.0, 78184448.0
+FLOP_HARD_HEAD = 2.0 * 8192 * 128
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
+
+
+def cpu_baseline(n_timed=2):
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import affnet_oracle as orc
+    torch.set_num_threads(os.cpu_count())
+    sd = {k: torch.load(os.path.join(ROOT, "pretrained", k + ".pth"), map_location="cpu", weights_only=False)["state_dict"]
+          for k in ("AffNet", "OriNet")}
+    hard = orc.synthetic_hardnet_state(0)
+    kp, t = 0, 0.0
+    for i in range(n_timed + 1):
+        x = orc.synthetic_image(H, W, i)
+        ex = orc.OracleExtractor(mrSize=5.192, num_features=NKP, border=5, num_Baum_iters=1, affnet_sd=sd["AffNet"],
+                                 orinet_sd=sd["OriNet"], reproduce_wasted_extraction=True)
+        t0 = time.perf_counter()
+        L, r, P, D = orc.describe(x, ex, hard, do_ori=True, ps=32)
+        dt = time.perf_counter() - t0
+        if i > 0:                       # first image = warm-up
+            kp += L.shape[0]
+            t += dt
+    return {"value": kp / t, "unit": "keypoints/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d synthetic 1024x768 images x 2000 kp (seeds 1..%d) after 1 warm-up, %.1f s of CPU work; "
+                      "oracle/affnet_oracle.py = the reference's torch-CPU operator sequence incl. its discarded extra extraction"
+                      % (n_timed, n_timed, t)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=BATCH, help="images per step per rank")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("AFFNET_BENCH_STREAMS", "1")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import affnet_amd
+    from affnet_amd import _lib, sharded
+    from affnet_amd.synthetic import synthetic_image
+    import importlib.util  # the synthetic HardNet stand-in weights come from a tiny helper, not from the oracle
+
+    def load(name, cls):
+        net = cls(PS=32) if name != "HardNet" else cls()
+        if name != "HardNet":
+            net.load_state_dict(torch.load(os.path.join(ROOT, "pretrained", name + ".pth"), map_location="cpu", weights_only=False)["state_dict"])
+        else:
+            net.load_state_dict(affnet_amd.synthetic_hardnet_state(0))
+        return net.to(dev)
+
+    A, O, Hn = load("AffNet", affnet_amd.AffNetFast), load("OriNet", affnet_amd.OriNetFast), load("HardNet", affnet_amd.HardNet)
+    # global image i of a step lives on rank i % world (weak scaling: `batch` images per rank per step)
+    seeds = [rank + world * j for j in range(args.batch)]
+    imgs = [synthetic_image(H, W, s).to(dev) for s in seeds]
+    S = max(1, args.streams)
+    dets = [affnet_amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=NKP, border=5, num_Baum_iters=1, AffNet=A, OriNet=O).to(dev)
+            for _ in range(S)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+
+    def step(profile=False):
+        results = [None] * len(imgs)
+        for i, x in enumerate(imgs):
+            with torch.cuda.stream(streams[i % S]):
+                results[i] = dets[i % S].enqueue(x, do_ori=True, desc=Hn)
+        for s in streams:
+            s.synchronize()
+        if world > 1:
+            rec = sharded.pack_records(results, NKP, dev)
+            rec = sharded.gather_features(rec, len(imgs) * world)
+            torch.cuda.synchronize()
+        return results
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    for d in dets:
+        _lib.check(_lib.lib.affnet_profile_enable(d._ctx.handle, 1), d._ctx.handle, "profile_enable")
+    barrier()
+    t0 = time.perf_counter()
+    kp = 0
+    for _ in range(args.steps):
+        res = step()
+        kp += int(sum(int(r["count"].item()) for r in res))   # device counts, read after the step's sync
+    barrier()
+    dt = time.perf_counter() - t0
+    # stage timings recorded by HIP events on the launch streams during the timed region
+    sums, calls = [0.0] * 8, 0
+    for d in dets:
+        buf, n = (C.c_double * 8)(), C.c_int32(0)
+        _lib.check(_lib.lib.affnet_profile_read(d._ctx.handle, C.byref(buf), C.byref(n)), d._ctx.handle, "profile_read")
+        calls += n.value
+        sums = [a + b for a, b in zip(sums, list(buf))]
+    t_all = torch.tensor([dt], dtype=torch.float64, device=dev)
+    kp_all = torch.tensor([kp], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+        dist.all_reduce(kp_all, op=dist.ReduceOp.SUM)
+    if rank == 0:
+        tmax, kps = float(t_all.item()), float(kp_all.item())
+        stage_ms = [s / max(calls, 1) for s in sums]
+        names = ["pyramid", "detector", "affnet", "shape_filter", "orinet", "denorm_levelsel", "hardnet_trunk", "hardnet_head"]
+        trunk_ms = stage_ms[6]
+        kp_per_img = kps / max(1, args.steps * args.batch * world)
+        flops_launch = kp_per_img * (FLOP_HARD - FLOP_HARD_HEAD)
+        achieved = flops_launch / (trunk_ms * 1e-3) / 1e12 if trunk_ms > 0 else 0.0
+        out = {
+            "metric": "keypoints/sec (detect+AffNet+OriNet+HardNet) per image, 2000 kp @1024x768",
+            "value": kps / tmax, "unit": "keypoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": tmax / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[2]: batch of %d synthetic 1024x768 grayscale images per GPU per step, "
+                                   "2000 kp each, full path detect+AffNet+OriNet+HardNet; AffNet/OriNet shipped weights, "
+                                   "HardNet seeded synthetic weights (HardNet++.pth is a missing blob)" % args.batch,
+                       "global_batch": args.batch * world, "keypoints_per_image": kp_per_img, "streams_per_gpu": S,
+                       "parallelism": "image-per-GPU x%d, all_gather of padded records" % world if world > 1 else "1 GPU"},
+            "ms_per_image": tmax / (args.steps * args.batch) * 1e3,
+            "stage_ms_per_image": dict(zip(names, [round(v, 4) for v in stage_ms])),
+            "roofline": {"kernel": "cnn32_trunk_kernel<HardNet> (fp32 MFMA 16x16x4, fused sampler+norm+6 convs)", "bound": "mfma",
+                         "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
+                         "traffic": None, "flops_per_launch": flops_launch, "launch_ms": trunk_ms,
+                         "all_cnn_tflops": kp_per_img * (1.5 * FLOP_AFF + FLOP_ORI + FLOP_HARD) /
+                                           (max(stage_ms[2] + stage_ms[4] + stage_ms[6] + stage_ms[7], 1e-9) * 1e-3) / 1e12},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -229,6 +229,16 @@ int affnet_extract_features(affnet_ctx* ctx, const affnet_nets* nets, const floa
                             float* d_lafs_px, float* d_resp, int32_t* d_ids, float* d_desc,
                             int32_t* d_count, void* stream);
 
+/* Stage timing with HIP events recorded on the caller's stream around the stages of
+ * affnet_extract_features (no host synchronisation while enabled; a ring of 256 calls).
+ * Stages: 0 pyramid, 1 detector, 2 AffNet trunk(+sampling), 3 shape filter/select, 4 OriNet(+rotation),
+ * 5 denormalise + level select, 6 HardNet trunk (+sampling), 7 HardNet head GEMM. */
+#define AFFNET_PROFILE_STAGES 8
+int affnet_profile_enable(affnet_ctx* ctx, int on);
+/* After the caller synchronised the stream(s): sums the elapsed milliseconds per stage over the
+ * calls recorded since the last read, returns the number of calls in *n_calls and clears the ring. */
+int affnet_profile_read(affnet_ctx* ctx, double sum_ms[AFFNET_PROFILE_STAGES], int32_t* n_calls);
+
 /* The one optional read-back: copies counters to the host after synchronising `stream`:
  * out[0] = rows after detection, out[1] = rows after shape filter, out[2] = capacity-overflow
  * flag (non-zero => AFFNET_ERR_CAPACITY semantics), out[3] = raw maxima found. */
