@@ -172,28 +172,44 @@ __device__ __forceinline__ void conv3x3_mfma(const float* act, const float* __re
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // K = (tap, cin) is walked in chunks of 4*UNROLL; a chunk never straddles a tap (CIN % (4*UNROLL) == 0).
+    // The B fragments (global / L2, ~1 us latency under load) of chunk c+1 are requested BEFORE the MFMAs of
+    // chunk c and consumed one iteration later; A fragments come from LDS right before use.
+    constexpr int KSTEP = 4 * UNROLL;
+    constexpr int NCHUNK = 9 * CIN / KSTEP;
+    float bn[UNROLL][TN];
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bn[u][j] = Wg[(4 * u) * COUT + b_base[j]];
 #pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-        const int ky = tap / 3, kx = tap - 3 * ky;
-        const int a_tap = ky * WPI + kx;
-        const float* wt = Wg + (size_t)tap * CIN * COUT;
-#pragma unroll 1
-        for (int c0 = 0; c0 < CIN; c0 += 4 * UNROLL) {
-            float a[UNROLL][TM], b[UNROLL][TN];
+    for (int ch = 0; ch < NCHUNK; ++ch) {
+        const int k0 = ch * KSTEP;
+        const int tap = k0 / CIN, c0 = k0 - tap * CIN;
+        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;          // tap / 3, tap % 3 for tap < 9
+        const int a_off = c0 * PSI + ky * WPI + kx;
+        float a[UNROLL][TM], b[UNROLL][TN];
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
+        for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) b[u][j] = wt[(c0 + 4 * u) * COUT + b_base[j]];
+            for (int j = 0; j < TN; ++j) b[u][j] = bn[u][j];
+        const int kn = (ch + 1 < NCHUNK) ? k0 + KSTEP : k0;         // last chunk re-reads itself (in bounds)
+        const float* wn = Wg + (size_t)kn * COUT;
 #pragma unroll
-                for (int i = 0; i < TM; ++i) a[u][i] = act[(c0 + 4 * u) * PSI + a_tap + a_base[i]];
-            }
+        for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u)
+            for (int j = 0; j < TN; ++j) bn[u][j] = wn[(4 * u) * COUT + b_base[j]];
+        __builtin_amdgcn_sched_barrier(0);                           // keep the prefetch ahead of this chunk's MFMAs
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+        for (int u = 0; u < UNROLL; ++u)
 #pragma unroll
-                    for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
-        }
+            for (int i = 0; i < TM; ++i) a[u][i] = act[(4 * u) * PSI + a_off + a_base[i]];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
     }
 }
 
@@ -442,12 +458,29 @@ __global__ __launch_bounds__(CNN_THREADS, (KIND == AFFNET_NET_HARDNET) ? 2 : 4) 
                 s[0][q] = fmaf(v, w0, s[0][q]); s[1][q] = fmaf(v, w1, s[1][q]);
             }
         }
+        // reduce the 18 partial sums: wave shuffles, then one LDS exchange ([wave][18]) - 2 barriers in total
+#pragma unroll
+        for (int o = 0; o < 2; ++o)
+#pragma unroll
+            for (int q = 0; q < 9; ++q) s[o][q] = wave_sum(s[o][q]);
+        __syncthreads();
+        float* red2 = patch;                                          // the input patch is dead by now: reuse its LDS
+        if (lane == 0) {
+#pragma unroll
+            for (int o = 0; o < 2; ++o)
+#pragma unroll
+                for (int q = 0; q < 9; ++q) red2[wave * 18 + o * 9 + q] = s[o][q];
+        }
+        __syncthreads();
         float t0 = 0.f, t1 = 0.f;
         const float* hb = a.packed + a.off.head_b;
+        if (tid == 0) {
 #pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            const float r0 = block_sum(s[0][q], red), r1 = block_sum(s[1][q], red);
-            t0 += tanhf(r0 + hb[0]); t1 += tanhf(r1 + hb[1]);
+            for (int q = 0; q < 9; ++q) {
+                float r0 = 0.f, r1 = 0.f;
+                for (int wv = 0; wv < 8; ++wv) { r0 += red2[wv * 18 + q]; r1 += red2[wv * 18 + 9 + q]; }
+                t0 += tanhf(r0 + hb[0]); t1 += tanhf(r1 + hb[1]);
+            }
         }
         if (tid == 0) {
             const float yv = t0 / 9.0f, xv = t1 / 9.0f;                       // AdaptiveAvgPool2d(1)
@@ -460,68 +493,84 @@ __global__ __launch_bounds__(CNN_THREADS, (KIND == AFFNET_NET_HARDNET) ? 2 : 4) 
 }
 
 // ---- HardNet head: (n x 8192) x (8192 x 128) GEMM + BN bias + L2 normalisation ----------------------
-// One workgroup = 256 threads = 16 patches x 128 outputs; wave w owns N-tiles 2w, 2w+1.  The A tile
-// (16 x KC) is staged through LDS with coalesced 16-byte loads; B streams from L2.
-#define HEAD_KC 256
-#define HEAD_AS (HEAD_KC + 1)
+// Split-K GEMM on the fp32 matrix cores.  One workgroup = 256 threads = 32 patches x 128 outputs x one
+// quarter of K (2048): wave w owns N-tiles 2w, 2w+1 for both 16-patch M-tiles (4 accumulators, each A and
+// B fragment is used twice).  The A slab (32 x 128) is staged through LDS with 16-byte loads / stores; B
+// ([k][n], BN-folded) streams from L2.  Partial sums go to a scratch [4][n][128] with plain stores (no float
+// atomics: bit-reproducible); hardnet_finish_kernel adds them in fixed order, adds the bias and
+// L2-normalises.  ceil(n/32) x 4 workgroups (252 for 2000 patches) fill the 256 CUs.
+#define HEAD_MP 32
+#define HEAD_KSPLIT 4
+#define HEAD_KC 128
+#define HEAD_AS (HEAD_KC + 4)    // row stride: 16-byte aligned rows, 2-way worst-case bank conflicts
 __global__ __launch_bounds__(256) void hardnet_head_kernel(const float* __restrict__ trunk, const float* __restrict__ Bw,
-                                                           const float* __restrict__ bias, const int32_t* __restrict__ count, int n_max,
-                                                           float* __restrict__ out) {
-    __shared__ float As[16 * HEAD_AS];
-    __shared__ float nrm[4][16];
+                                                           const int32_t* __restrict__ count, int n_max, float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float As[HEAD_MP * HEAD_AS];
     const int n = count ? min(*count, n_max) : n_max;
-    const int p0 = blockIdx.x * 16;
+    const int p0 = blockIdx.x * HEAD_MP;
     if (p0 >= n) return;
+    const int kbeg = blockIdx.y * (HEAD_K / HEAD_KSPLIT);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int m = lane & 15, kq = lane >> 4;
-    f32x4 acc[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-    for (int k0 = 0; k0 < HEAD_K; k0 += HEAD_KC) {
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int k0 = kbeg; k0 < kbeg + HEAD_K / HEAD_KSPLIT; k0 += HEAD_KC) {
         __syncthreads();
-        // stage 16 x 256 floats: 1024 float4, 4 per thread
+        // stage 32 x 128 floats = 1024 float4, 4 per thread (coalesced: 32 consecutive float4 per row)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int f = tid + 256 * r;            // float4 index
-            const int row = f >> 6, c4 = f & 63;
+            const int f = tid + 256 * r;
+            const int row = f >> 5, c4 = f & 31;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p0 + row < n) v = *reinterpret_cast<const float4*>(trunk + (size_t)(p0 + row) * HEAD_K + k0 + 4 * c4);
-            float* d = &As[row * HEAD_AS + 4 * c4];
-            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            *reinterpret_cast<float4*>(&As[row * HEAD_AS + 4 * c4]) = v;
         }
         __syncthreads();
         const float* bptr = Bw + (size_t)(k0 + kq) * 128 + wave * 32 + m;
 #pragma unroll 8
         for (int kk = 0; kk < HEAD_KC; kk += 4) {
-            const float av = As[m * HEAD_AS + kk + kq];
+            const float a0 = As[m * HEAD_AS + kk + kq], a1 = As[(16 + m) * HEAD_AS + kk + kq];
             const float b0 = bptr[(size_t)kk * 128], b1 = bptr[(size_t)kk * 128 + 16];
-            acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[0], 0, 0, 0);
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc[1], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
         }
     }
-    // acc[j][r]: patch row 4*(lane>>4)+r, channel wave*32 + 16*j + (lane&15)
+    // acc[i][j][r]: patch p0 + 16 i + 4 (lane>>4) + r, channel 32 wave + 16 j + (lane & 15)
     const int g = lane >> 4;
-    const float bv0 = bias[wave * 32 + m], bv1 = bias[wave * 32 + 16 + m];
-    float val[2][4], ss[4];
+    float* dst = partial + (size_t)blockIdx.y * n_max * 128;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        val[0][r] = acc[0][r] + bv0; val[1][r] = acc[1][r] + bv1;
-        ss[r] = val[0][r] * val[0][r] + val[1][r] * val[1][r];
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) ss[r] += __shfl_xor(ss[r], o, 64);   // over the 16 lanes sharing g
+        for (int r = 0; r < 4; ++r) {
+            const int row = p0 + 16 * i + 4 * g + r;
+            if (row >= n) continue;
+            dst[(size_t)row * 128 + wave * 32 + m] = acc[i][0][r];
+            dst[(size_t)row * 128 + wave * 32 + 16 + m] = acc[i][1][r];
+        }
+}
+
+// One wavefront per patch: sum the K-split partials in fixed order, + BN bias, L2 normalise (eps 1e-8).
+__global__ __launch_bounds__(256) void hardnet_finish_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
+                                                             const int32_t* __restrict__ count, int n_max, float* __restrict__ out) {
+    const int n = count ? min(*count, n_max) : n_max;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= n) return;
+    float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+    for (int s = 0; s < HEAD_KSPLIT; ++s) {
+        const float* p = partial + ((size_t)s * n_max + row) * 128;
+        v0 += p[lane]; v1 += p[64 + lane];
     }
-    if (m == 0) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) nrm[wave][4 * g + r] = ss[r];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = 4 * g + r;
-        if (p0 + row >= n) continue;
-        const float tot = (nrm[0][row] + nrm[1][row]) + (nrm[2][row] + nrm[3][row]);
-        const float inv = sqrtf(tot + 1e-8f);                                  // L2Norm eps 1e-8 (HardNet.py:15-18)
-        float* o = out + (size_t)(p0 + row) * 128 + wave * 32 + m;
-        o[0] = val[0][r] / inv; o[16] = val[1][r] / inv;
-    }
+    v0 += bias[lane]; v1 += bias[64 + lane];
+    const float tot = wave_sum(v0 * v0 + v1 * v1);
+    const float nrm = sqrtf(tot + 1e-8f);                                  // L2Norm (HardNet.py:15-18)
+    out[(size_t)row * 128 + lane] = v0 / nrm;
+    out[(size_t)row * 128 + 64 + lane] = v1 / nrm;
 }
 
 // ---- host entry points -------------------------------------------------------------------------------
@@ -544,7 +593,7 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
     if (kind < 0 || kind > 2) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: unknown net kind %d", kind);
     if (!packed || !out || n_max < 0 || (!patches && (!lafs || !ids))) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: null argument");
     if (!patches && !ctx->ws) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: sampling from the pyramid needs a bound workspace");
-    if (kind == AFFNET_NET_HARDNET && dbg_layer < 0 && !scratch) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: HardNet needs d_scratch (n*8192 floats)");
+    if (kind == AFFNET_NET_HARDNET && dbg_layer < 0 && !scratch) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: HardNet needs d_scratch (n*(8192+512) floats)");
     if (n_max == 0) return AFFNET_OK;
     const NetLayout L = net_layout(kind);
     CnnArgs a;
@@ -560,8 +609,11 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
     AFF_LAUNCH_CHECK(ctx);
     if (mark_head) aff_prof_mark(ctx, 7, st);
     if (kind == AFFNET_NET_HARDNET && dbg_layer < 0) {
-        hipLaunchKernelGGL(hardnet_head_kernel, dim3(aff_cdiv(n_max, 16)), dim3(256), 0, st, scratch, packed + L.head_w, packed + L.head_b,
-                           count, n_max, out);
+        float* partial = scratch + (size_t)n_max * HEAD_K;   // [HEAD_KSPLIT][n_max][128] behind the trunk output
+        hipLaunchKernelGGL(hardnet_head_kernel, dim3(aff_cdiv(n_max, HEAD_MP), HEAD_KSPLIT), dim3(256), 0, st, scratch, packed + L.head_w,
+                           count, n_max, partial);
+        AFF_LAUNCH_CHECK(ctx);
+        hipLaunchKernelGGL(hardnet_finish_kernel, dim3(aff_cdiv(n_max, 4)), dim3(256), 0, st, partial, packed + L.head_b, count, n_max, out);
         AFF_LAUNCH_CHECK(ctx);
     }
     return AFFNET_OK;

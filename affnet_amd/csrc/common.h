@@ -67,6 +67,7 @@ struct affnet_ctx {
     float* st_R = nullptr; float* st_lafs_norm = nullptr; int32_t* st_lvl_ids = nullptr;
     float* st_hard_scratch = nullptr;
     float* st_lafs_shaped = nullptr;
+    int32_t* st_rank = nullptr;          // partial ranks / positions of the two selection stages (cap_pre ints)
     // stage profiling (HIP events on the caller's stream)
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;   // ring: PROF_RING calls x (AFFNET_PROFILE_STAGES + 1) events

@@ -93,10 +93,11 @@ extern "C" int affnet_ctx_create(affnet_ctx** out, int device, const affnet_conf
     off += aff_align(P * 10 * sizeof(float));          // det resp(1) + lafs(6) + ids(3)
     off += aff_align(P * 4 * sizeof(float));           // A
     off += aff_align(P * 2 * sizeof(float));           // key, good
+    off += aff_align(P * sizeof(int32_t));             // rank / pos
     off += aff_align(F * 6 * sizeof(float));           // shaped lafs (normalised)
     off += aff_align(F * 4 * sizeof(float));           // R
     off += aff_align(F * 9 * sizeof(float));           // lafs_norm(6) + lvl ids(3)
-    off += aff_align(F * 8192 * sizeof(float));        // HardNet trunk output
+    off += aff_align(F * (8192 + 4 * 128) * sizeof(float));   // HardNet trunk output + split-K head partials
     ctx->ws_bytes = off;
     *out = ctx;
     return AFFNET_OK;
@@ -136,6 +137,7 @@ extern "C" int affnet_bind_workspace(affnet_ctx* ctx, void* d_workspace, size_t 
     s += aff_align(P * 10 * sizeof(float));
     ctx->st_A = (float*)s; s += aff_align(P * 4 * sizeof(float));
     ctx->st_key = (float*)s; ctx->st_good = (int32_t*)((float*)s + P); s += aff_align(P * 2 * sizeof(float));
+    ctx->st_rank = (int32_t*)s; s += aff_align(P * sizeof(int32_t));
     ctx->st_lafs_shaped = (float*)s; s += aff_align(F * 6 * sizeof(float));
     ctx->st_R = (float*)s; s += aff_align(F * 4 * sizeof(float));
     ctx->st_lafs_norm = (float*)s; ctx->st_lvl_ids = (int32_t*)((float*)s + 6 * F); s += aff_align(F * 9 * sizeof(float));

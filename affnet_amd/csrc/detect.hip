@@ -34,6 +34,7 @@
 #define HR_W (HT_X + 2)   // response tile with 1-px halo
 #define HR_H (HT_Y + 2)
 #define HR_S (HR_W + 1)   // padded row stride
+#define HN_CAP 320        // per-workgroup staging capacity (1024 px x 3 levels; ~2% are maxima)
 
 struct HessParams {
     const float* levels;   // 5 blurred levels of this octave, contiguous
@@ -64,8 +65,13 @@ __device__ __forceinline__ float hessian_at(const float* __restrict__ X, int ty,
 
 __global__ __launch_bounds__(256) void hessian_nms_kernel(HessParams p) {
     // LDS: 5 blurred tiles (20x68) + 5 response tiles (18x67)
-    __shared__ float X[AFFNET_MAX_LEVELS > 5 ? 5 : 5][HX_H * HX_W];
+    __shared__ float X[5][HX_H * HX_W];
     __shared__ float Rr[5][HR_H * HR_S];
+    // Maxima found by this workgroup are staged here and appended with ONE global atomic (a single
+    // contended counter retires only ~90 atomics/us: per-candidate atomics cost 150 us on octave 0).
+    __shared__ RawMax s_list[HN_CAP];
+    __shared__ int s_n, s_base;
+    if (threadIdx.x == 0) s_n = 0;
     const int h = p.h, w = p.w;
     const int x0 = blockIdx.x * HT_X, y0 = blockIdx.y * HT_Y;
     const size_t lvl_stride = (size_t)h * w;
@@ -95,11 +101,10 @@ __global__ __launch_bounds__(256) void hessian_nms_kernel(HessParams p) {
     // each thread: 4 pixels of one row
     const int ty = threadIdx.x >> 4, txb = (threadIdx.x & 15) * 4;
     const int gy = y0 + ty;
-    if (gy >= h) return;
 #pragma unroll 1
     for (int q = 0; q < 4; ++q) {
         const int tx = txb + q, gx = x0 + tx;
-        if (gx >= w) break;
+        if (gx >= w || gy >= h) break;
         const bool in_border = !border_ok || gy < p.border || gy >= h - p.border || gx < p.border || gx >= w - p.border;
         if (in_border) continue;                      // zero_response_at_border -> nms value 0 -> never a candidate
         // column maxima over the 3x3 spatial window of each of the 5 response levels are shared by the 3 NMS levels
@@ -151,10 +156,25 @@ __global__ __launch_bounds__(256) void hessian_nms_kernel(HessParams p) {
             rm.s = cs / msz;
             rm.y = cy / (float)h;
             rm.x = cx / (float)w;
-            const int slot = atomicAdd(p.raw_cnt, 1);
-            if (slot < p.raw_cap) p.raw[slot] = rm;
-            else atomicOr(p.overflow, 1);
+            const int ls = atomicAdd(&s_n, 1);
+            if (ls < HN_CAP) {
+                s_list[ls] = rm;
+            } else {                                   // staging full (pathological tile): direct append
+                const int slot = atomicAdd(p.raw_cnt, 1);
+                if (slot < p.raw_cap) p.raw[slot] = rm;
+                else atomicOr(p.overflow, 1);
+            }
         }
+    }
+    __syncthreads();
+    const int n_loc = s_n < HN_CAP ? s_n : HN_CAP;
+    if (n_loc == 0) return;
+    if (threadIdx.x == 0) s_base = atomicAdd(p.raw_cnt, n_loc);
+    __syncthreads();
+    const int base = s_base;
+    for (int i = threadIdx.x; i < n_loc; i += 256) {
+        if (base + i < p.raw_cap) p.raw[base + i] = s_list[i];
+        else atomicOr(p.overflow, 1);
     }
 }
 
@@ -215,19 +235,35 @@ __global__ __launch_bounds__(1024) void octave_resolve_kernel(ResolveParams p) {
         const int n_pos = s_pos;
         __syncthreads();
         if (n_pos <= 1) continue;                      // HandCraftedModules.py:252-254: level skipped, octaveMap unchanged
-        for (int i = threadIdx.x; i < n; i += 1024) {
-            if (raw[i].lvl != l) continue;
-            const int pix = raw[i].pix;
-            const float m = (float)omap[pix];
-            const float v = raw[i].val * (1.0f - m);
-            const float sum = m + v;
-            omap[pix] = (uint8_t)(long long)sum;        // float -> int64 -> uint8 wrap, as torch's CPU .byte()
-            if (v != 0.0f) {
-                const int slot = atomicAdd(&p.cnt[CNT_CAND], 1);
+        for (int i0 = 0; i0 < n; i0 += 1024) {
+            const int i = i0 + threadIdx.x;
+            bool emit = false;
+            float v = 0.f;
+            RawMax r;
+            if (i < n) {
+                r = raw[i];
+                if (r.lvl == l) {
+                    const float m = (float)omap[r.pix];
+                    v = r.val * (1.0f - m);
+                    const float sum = m + v;
+                    omap[r.pix] = (uint8_t)(long long)sum;   // float -> int64 -> uint8 wrap, as torch's CPU .byte()
+                    emit = v != 0.0f;
+                }
+            }
+            // one global atomic per wavefront instead of one per candidate
+            const unsigned long long bal = __ballot(emit);
+            const int lane = threadIdx.x & 63;
+            int wbase = 0;
+            if (bal) {
+                if (lane == 0) wbase = atomicAdd(&p.cnt[CNT_CAND], __popcll(bal));
+                wbase = __shfl(wbase, 0, 64);
+            }
+            if (emit) {
+                const int slot = wbase + __popcll(bal & ((1ull << lane) - 1ull));
                 if (slot < p.cand_cap) {
                     p.cand_resp[slot] = v;
-                    p.cand_syx[3 * slot] = raw[i].s; p.cand_syx[3 * slot + 1] = raw[i].y; p.cand_syx[3 * slot + 2] = raw[i].x;
-                    p.cand_ids[3 * slot] = o; p.cand_ids[3 * slot + 1] = l - 1; p.cand_ids[3 * slot + 2] = pix;
+                    p.cand_syx[3 * slot] = r.s; p.cand_syx[3 * slot + 1] = r.y; p.cand_syx[3 * slot + 2] = r.x;
+                    p.cand_ids[3 * slot] = o; p.cand_ids[3 * slot + 1] = l - 1; p.cand_ids[3 * slot + 2] = r.pix;
                 } else {
                     atomicOr(&p.cnt[CNT_OVERFLOW], 2);
                 }
@@ -318,47 +354,55 @@ __device__ __forceinline__ unsigned long long ord_key(const int32_t* ids) {  // 
     return ((unsigned long long)(uint32_t)ids[0] << 40) | ((unsigned long long)(uint32_t)ids[1] << 32) | (uint32_t)ids[2];
 }
 
-// Rank sort + emit.  Output row = rank.  mode 1: descending response (ties: key order);
-// mode 0: (octave, level, pixel) ascending = the reference's concatenation order.
-__global__ __launch_bounds__(256) void select_rank_emit_kernel(const float* __restrict__ sel_resp, const float* __restrict__ sel_syx,
-                                                               const int32_t* __restrict__ sel_ids, int32_t* cnt, int sel_cap,
-                                                               float mr, float* out_resp, float* out_lafs, int32_t* out_ids,
-                                                               int32_t* out_count) {
+// Rank sort, split over a 2-D grid: block (bx, by) counts, for its 256 rows i, how many of the 256 rows j
+// of chunk by come before them; partial ranks are accumulated with integer atomics (exact, order
+// independent).  mode 1: descending response (ties: key order); mode 0: (octave, level, pixel)
+// ascending = the reference's concatenation order.
+__global__ __launch_bounds__(256) void select_rank_kernel(const float* __restrict__ sel_resp, const int32_t* __restrict__ sel_ids,
+                                                          const int32_t* __restrict__ cnt, int sel_cap, int32_t* __restrict__ rank) {
     __shared__ float t_resp[256];
     __shared__ unsigned long long t_ord[256];
     int n = cnt[CNT_SEL];
     if (n > sel_cap) n = sel_cap;
     const int mode = cnt[CNT_SEL_MODE];
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x == 0 && threadIdx.x == 0) { cnt[CNT_DET] = n; if (out_count) *out_count = n; }
-    if (blockIdx.x * 256 >= n) return;
-    const bool live = i < n;
-    const float ri = live ? sel_resp[i] : 0.f;
-    const unsigned long long oi = live ? ord_key(sel_ids + 3 * i) : 0ull;
-    int rank = 0;
-    for (int base = 0; base < n; base += 256) {
-        const int j = base + threadIdx.x;
-        __syncthreads();
-        if (j < n) { t_resp[threadIdx.x] = sel_resp[j]; t_ord[threadIdx.x] = ord_key(sel_ids + 3 * j); }
-        __syncthreads();
-        const int m = (n - base) < 256 ? (n - base) : 256;
-        if (mode == 1) {
-            for (int t = 0; t < m; ++t) {
-                const float rj = t_resp[t];
-                rank += (rj > ri) || (rj == ri && t_ord[t] < oi);
-            }
-        } else {
-            for (int t = 0; t < m; ++t) rank += t_ord[t] < oi;
+    const int i = blockIdx.x * 256 + threadIdx.x, base = blockIdx.y * 256;
+    if (blockIdx.x * 256 >= n || base >= n) return;
+    const int j = base + threadIdx.x;
+    if (j < n) { t_resp[threadIdx.x] = sel_resp[j]; t_ord[threadIdx.x] = ord_key(sel_ids + 3 * j); }
+    __syncthreads();
+    if (i >= n) return;
+    const float ri = sel_resp[i];
+    const unsigned long long oi = ord_key(sel_ids + 3 * i);
+    const int m = (n - base) < 256 ? (n - base) : 256;
+    int r = 0;
+    if (mode == 1) {
+        for (int t = 0; t < m; ++t) {
+            const float rj = t_resp[t];
+            r += (rj > ri) || (rj == ri && t_ord[t] < oi);
         }
+    } else {
+        for (int t = 0; t < m; ++t) r += t_ord[t] < oi;
     }
-    if (!live) return;
-    out_resp[rank] = ri;
+    if (r) atomicAdd(&rank[i], r);
+}
+
+__global__ __launch_bounds__(256) void select_emit_kernel(const float* __restrict__ sel_resp, const float* __restrict__ sel_syx,
+                                                          const int32_t* __restrict__ sel_ids, int32_t* cnt, int sel_cap,
+                                                          const int32_t* __restrict__ rank, float mr, float* out_resp,
+                                                          float* out_lafs, int32_t* out_ids, int32_t* out_count) {
+    int n = cnt[CNT_SEL];
+    if (n > sel_cap) n = sel_cap;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) { cnt[CNT_DET] = n; if (out_count) *out_count = n; }
+    if (i >= n) return;
+    const int r = rank[i];
+    out_resp[r] = sel_resp[i];
     const float s = sel_syx[3 * i], y = sel_syx[3 * i + 1], x = sel_syx[3 * i + 2];
-    float* L = out_lafs + 6 * (size_t)rank;
+    float* L = out_lafs + 6 * (size_t)r;
     const float sm = mr * s;                            // LAFs[:,0:2,0:2] *= mrSize (SparseImgRepresenter.py:198)
     L[0] = sm; L[1] = mr * 0.0f; L[2] = x;
     L[3] = mr * 0.0f; L[4] = sm; L[5] = y;
-    out_ids[3 * rank] = sel_ids[3 * i]; out_ids[3 * rank + 1] = sel_ids[3 * i + 1]; out_ids[3 * rank + 2] = sel_ids[3 * i + 2];
+    out_ids[3 * r] = sel_ids[3 * i]; out_ids[3 * r + 1] = sel_ids[3 * i + 1]; out_ids[3 * r + 2] = sel_ids[3 * i + 2];
 }
 
 extern "C" int affnet_detect(affnet_ctx* ctx, float* d_resp, float* d_lafs, int32_t* d_ids, int32_t* d_count, void* stream) {
@@ -372,6 +416,7 @@ extern "C" int affnet_detect(affnet_ctx* ctx, float* d_resp, float* d_lafs, int3
     AFF_HIP(ctx, hipMemsetAsync(d_resp, 0, P * sizeof(float), st));
     AFF_HIP(ctx, hipMemsetAsync(d_lafs, 0, P * 6 * sizeof(float), st));
     AFF_HIP(ctx, hipMemsetAsync(d_ids, 0, P * 3 * sizeof(int32_t), st));
+    AFF_HIP(ctx, hipMemsetAsync(ctx->st_rank, 0, P * sizeof(int32_t), st));
     ResolveParams rp;
     memset(&rp, 0, sizeof(rp));
     for (int o = 0; o < c.n_octaves; ++o) {
@@ -398,8 +443,11 @@ extern "C" int affnet_detect(affnet_ctx* ctx, float* d_resp, float* d_lafs, int3
     hipLaunchKernelGGL(select_compact_kernel, dim3(aff_cdiv((int)ctx->cand_cap, 256)), dim3(256), 0, st, ctx->cand_resp, ctx->cand_syx,
                        ctx->cand_ids, ctx->cnt, (int)ctx->cand_cap, ctx->sel_resp, ctx->sel_syx, ctx->sel_ids, ctx->cap_pre);
     AFF_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(select_rank_emit_kernel, dim3(aff_cdiv(ctx->cap_pre, 256)), dim3(256), 0, st, ctx->sel_resp, ctx->sel_syx,
-                       ctx->sel_ids, ctx->cnt, ctx->cap_pre, c.mr_size, d_resp, d_lafs, d_ids, d_count);
+    const int nb = aff_cdiv(ctx->cap_pre, 256);
+    hipLaunchKernelGGL(select_rank_kernel, dim3(nb, nb), dim3(256), 0, st, ctx->sel_resp, ctx->sel_ids, ctx->cnt, ctx->cap_pre, ctx->st_rank);
+    AFF_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(select_emit_kernel, dim3(nb), dim3(256), 0, st, ctx->sel_resp, ctx->sel_syx, ctx->sel_ids, ctx->cnt, ctx->cap_pre,
+                       ctx->st_rank, c.mr_size, d_resp, d_lafs, d_ids, d_count);
     AFF_LAUNCH_CHECK(ctx);
     return AFFNET_OK;
 }

@@ -118,59 +118,68 @@ __global__ __launch_bounds__(256) void shape_filter_kernel(const float* __restri
     key[i] = resp[i] * (ok ? 1.0f : 0.0f);
 }
 
-// Multi-workgroup selection: each thread ranks one row against all rows.
+// Selection, split over a 2-D grid like the detector's rank sort: block (bx, by) counts for its 256
+// rows how many rows of chunk `by` precede them; partial positions are accumulated with integer atomics.
 //   survivors > N  -> top-N of key (descending; ties by row index) - torch.topk branch (:151-153)
 //   otherwise      -> stable compaction of the good rows            - nonzero branch (:154-156)
-__global__ __launch_bounds__(256) void shape_select_kernel(const float* __restrict__ resp, const float* __restrict__ lafs,
-                                                           const int32_t* __restrict__ ids, const float* __restrict__ A,
-                                                           const float* __restrict__ key, const int32_t* __restrict__ good,
-                                                           const int32_t* __restrict__ d_count, int n_max, int N, int out_cap,
-                                                           float* out_resp, float* out_lafs, int32_t* out_ids, int32_t* out_count,
-                                                           int32_t* cnt) {
+__global__ __launch_bounds__(256) void shape_count_kernel(const int32_t* __restrict__ good, const int32_t* __restrict__ d_count, int n_max,
+                                                          int32_t* cnt) {
+    const int n = min(*d_count, n_max);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int g = (i < n) ? good[i] : 0;
+    const unsigned long long bal = __ballot(g != 0);
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&cnt[CNT_SURVIVED], __popcll(bal));
+}
+
+__global__ __launch_bounds__(256) void shape_rank_kernel(const float* __restrict__ key, const int32_t* __restrict__ good,
+                                                         const int32_t* __restrict__ d_count, int n_max, int N,
+                                                         const int32_t* __restrict__ cnt, int32_t* __restrict__ pos) {
     __shared__ float t_key[256];
     __shared__ int t_good[256];
-    __shared__ int s_surv;
     const int n = min(*d_count, n_max);
-    if (threadIdx.x == 0) s_surv = 0;
+    const int i = blockIdx.x * 256 + threadIdx.x, base = blockIdx.y * 256;
+    if (blockIdx.x * 256 >= n || base >= n) return;
+    const bool topk = (N > 0) && (cnt[CNT_SURVIVED] > N);
+    const int j = base + threadIdx.x;
+    if (j < n) { t_key[threadIdx.x] = key[j]; t_good[threadIdx.x] = good[j]; }
     __syncthreads();
-    int local = 0;
-    for (int j = threadIdx.x; j < n; j += 256) local += good[j];
-    if (local) atomicAdd(&s_surv, local);
-    __syncthreads();
-    const int surv = s_surv;
+    if (i >= n) return;
+    const float ki = key[i];
+    const int m = (n - base) < 256 ? (n - base) : 256;
+    int r = 0;
+    if (topk) {
+        for (int t = 0; t < m; ++t) { const float kj = t_key[t]; r += (kj > ki) || (kj == ki && (base + t) < i); }
+    } else {
+        for (int t = 0; t < m; ++t) r += (t_good[t] != 0) && ((base + t) < i);
+    }
+    if (r) atomicAdd(&pos[i], r);
+}
+
+__global__ __launch_bounds__(256) void shape_emit_kernel(const float* __restrict__ resp, const float* __restrict__ lafs,
+                                                         const int32_t* __restrict__ ids, const float* __restrict__ A,
+                                                         const float* __restrict__ key, const int32_t* __restrict__ good,
+                                                         const int32_t* __restrict__ pos, const int32_t* __restrict__ d_count, int n_max,
+                                                         int N, int out_cap, float* out_resp, float* out_lafs, int32_t* out_ids,
+                                                         int32_t* out_count, int32_t* cnt) {
+    const int n = min(*d_count, n_max);
+    const int surv = cnt[CNT_SURVIVED];
     const bool topk = (N > 0) && (surv > N);
-    const int n_out = topk ? N : (surv < out_cap ? surv : out_cap);
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        *out_count = n_out; cnt[CNT_SHAPED] = n_out; cnt[CNT_SURVIVED] = surv;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) {
+        const int n_out = topk ? N : (surv < out_cap ? surv : out_cap);
+        *out_count = n_out; cnt[CNT_SHAPED] = n_out;
         if (!topk && surv > out_cap) atomicOr(&cnt[CNT_OVERFLOW], 8);
     }
-    if (blockIdx.x * 256 >= n) return;
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const bool live = i < n;
-    const float ki = live ? key[i] : 0.f;
-    const int gi = live ? good[i] : 0;
-    int pos = 0;
-    for (int base = 0; base < n; base += 256) {
-        const int j = base + threadIdx.x;
-        __syncthreads();
-        if (j < n) { t_key[threadIdx.x] = key[j]; t_good[threadIdx.x] = good[j]; }
-        __syncthreads();
-        const int m = (n - base) < 256 ? (n - base) : 256;
-        if (topk) {
-            for (int t = 0; t < m; ++t) { const float kj = t_key[t]; pos += (kj > ki) || (kj == ki && (base + t) < i); }
-        } else {
-            for (int t = 0; t < m; ++t) pos += (t_good[t] != 0) && ((base + t) < i);
-        }
-    }
-    if (!live) return;
-    if (topk ? (pos >= N) : (!gi || pos >= out_cap)) return;
-    out_resp[pos] = topk ? ki : resp[i];
+    if (i >= n) return;
+    const int p = pos[i];
+    if (topk ? (p >= N) : (!good[i] || p >= out_cap)) return;
+    out_resp[p] = topk ? key[i] : resp[i];
     const float a00 = A[4 * i], a01 = A[4 * i + 1], a10 = A[4 * i + 2], a11 = A[4 * i + 3];
     const float* L = lafs + 6 * (size_t)i;
-    float* O = out_lafs + 6 * (size_t)pos;
+    float* O = out_lafs + 6 * (size_t)p;
     O[0] = fmaf(a01, L[3], a00 * L[0]); O[1] = fmaf(a01, L[4], a00 * L[1]); O[2] = L[2];
     O[3] = fmaf(a11, L[3], a10 * L[0]); O[4] = fmaf(a11, L[4], a10 * L[1]); O[5] = L[5];
-    out_ids[3 * pos] = ids[3 * i]; out_ids[3 * pos + 1] = ids[3 * i + 1]; out_ids[3 * pos + 2] = ids[3 * i + 2];
+    out_ids[3 * p] = ids[3 * i]; out_ids[3 * p + 1] = ids[3 * i + 1]; out_ids[3 * p + 2] = ids[3 * i + 2];
 }
 
 extern "C" int affnet_shape_filter_select(affnet_ctx* ctx, const float* d_resp_in, const float* d_lafs_in, const int32_t* d_ids_in,
@@ -187,8 +196,16 @@ extern "C" int affnet_shape_filter_select(affnet_ctx* ctx, const float* d_resp_i
     hipLaunchKernelGGL(shape_filter_kernel, dim3(aff_cdiv(P, 256)), dim3(256), 0, st, d_resp_in, d_lafs_in, d_A, d_count_in, P, ctx->st_key,
                        ctx->st_good);
     AFF_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(shape_select_kernel, dim3(aff_cdiv(P, 256)), dim3(256), 0, st, d_resp_in, d_lafs_in, d_ids_in, d_A, ctx->st_key,
-                       ctx->st_good, d_count_in, P, ctx->cfg.num_features, F, d_resp_out, d_lafs_out, d_ids_out, d_count_out, ctx->cnt);
+    AFF_HIP(ctx, hipMemsetAsync(ctx->st_rank, 0, (size_t)P * sizeof(int32_t), st));
+    AFF_HIP(ctx, hipMemsetAsync(ctx->cnt + CNT_SURVIVED, 0, sizeof(int32_t), st));
+    const int nb = aff_cdiv(P, 256);
+    hipLaunchKernelGGL(shape_count_kernel, dim3(nb), dim3(256), 0, st, ctx->st_good, d_count_in, P, ctx->cnt);
+    AFF_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(shape_rank_kernel, dim3(nb, nb), dim3(256), 0, st, ctx->st_key, ctx->st_good, d_count_in, P, ctx->cfg.num_features,
+                       ctx->cnt, ctx->st_rank);
+    AFF_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(shape_emit_kernel, dim3(nb), dim3(256), 0, st, d_resp_in, d_lafs_in, d_ids_in, d_A, ctx->st_key, ctx->st_good,
+                       ctx->st_rank, d_count_in, P, ctx->cfg.num_features, F, d_resp_out, d_lafs_out, d_ids_out, d_count_out, ctx->cnt);
     AFF_LAUNCH_CHECK(ctx);
     return AFFNET_OK;
 }

@@ -41,7 +41,9 @@ __global__ __launch_bounds__(256) void blur2d_kernel(const float* __restrict__ i
     const int tx = (threadIdx.x & 15) * 4, ty = threadIdx.x >> 4;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     constexpr int NV = (K + 3 + 3) / 4;            // float4 loads covering K+3 values
-#pragma unroll
+    // Row loop stays rolled: one (K+3)-wide register window + K scalar taps per iteration keeps the kernel
+    // at <= 64 VGPRs (8 waves/SIMD); fully unrolled it needed 255 VGPRs and ran at 1 wave/SIMD.
+#pragma unroll 1
     for (int i = 0; i < K; ++i) {
         float r[NV * 4];
         const float4* row = reinterpret_cast<const float4*>(&tile[(ty + i) * LS + tx]);

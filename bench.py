@@ -39,7 +39,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32
 def cpu_baseline(n_timed=2):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import affnet_oracle as orc
-    torch.set_num_threads(os.cpu_count())
+    # torch's default intra-op thread count (respects the container's CPU affinity / quota)
     sd = {k: torch.load(os.path.join(ROOT, "pretrained", k + ".pth"), map_location="cpu", weights_only=False)["state_dict"]
           for k in ("AffNet", "OriNet")}
     hard = orc.synthetic_hardnet_state(0)
@@ -84,7 +84,6 @@ def main():
     import affnet_amd
     from affnet_amd import _lib, sharded
     from affnet_amd.synthetic import synthetic_image
-    import importlib.util  # the synthetic HardNet stand-in weights come from a tiny helper, not from the oracle
 
     def load(name, cls):
         net = cls(PS=32) if name != "HardNet" else cls()

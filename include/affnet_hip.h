@@ -164,7 +164,7 @@ int affnet_cnn32_pack_weights(int net_kind, const float* const* conv_w, const fl
  *   OriNet : d_out (n,2,2) rotation matrix             (architectures.py:76-82,  LAF.py:276-283)
  *   HardNet: d_out (n,128) L2-normalised descriptor    (HardNet.py:98-101)
  * Only rows < *d_count are computed when d_count != NULL.  d_scratch: HardNet needs
- * n*8192 floats for the trunk output (NULL for the other nets). */
+ * n*(8192+512) floats (trunk output + split-K partials of the head GEMM; NULL for the other nets). */
 int affnet_cnn32_forward(affnet_ctx* ctx, int net_kind, const float* d_packed, const float* d_patches,
                          const int32_t* d_count, int n_max, float* d_out, float* d_scratch, void* stream);
 

@@ -64,7 +64,15 @@ def main():
 
     # 1. synthetic image, small: the CPU suite re-runs the oracle on this one
     x = orc.synthetic_image(240, 320, 1)
-    np.savez_compressed(os.path.join(HERE, "synth_240x320_s1_n300.npz"), **full(x, 300))
+    gold = full(x, 300)
+    # detector stage alone (SparseImgRepresenter.py:53-111 + :198): C = 450 candidates before AffNet
+    det = SSAPE(mrSize=5.192, num_features=300, border=5, num_Baum_iters=1, AffNet=A, OriNet=O)
+    with torch.no_grad(), rh.quiet():
+        r_, L_, o_, l_ = det.multiScaleDetector(x, 450)
+        L_[:, 0:2, 0:2] = 5.192 * L_[:, :, 0:2]
+        Lpx = ns.LAF.denormalizeLAFs(L_, 320, 240)
+    gold.update(det_resp=r_.numpy(), det_LAFs_px=Lpx.numpy(), det_oct=o_.numpy(), det_lev=l_.numpy())
+    np.savez_compressed(os.path.join(HERE, "synth_240x320_s1_n300.npz"), **gold)
     # 2. config 2: test-graf/img1.png (N=500 keeps the fixture small; N=2000 is checked live vs the oracle)
     g1 = load_gray(os.path.join(HERE, "graf_img1.png"))
     np.savez_compressed(os.path.join(HERE, "graf_img1_n500.npz"), **full(g1, 500))

@@ -16,7 +16,7 @@ fi
 if [ -n "$DO_PROF" ]; then
 echo "== rocprofv3 kernel stats"
 export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d gpurun_out/prof -o run -- python bench.py --steps 1 --warmup 1 --batch 16 --no-cpu-baseline > gpurun_out/prof.log 2>&1; echo "prof exit: $?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o run -- python bench.py --steps 1 --warmup 1 --batch 16 --no-cpu-baseline > gpurun_out/prof.log 2>&1; echo "prof exit: $?"
 find gpurun_out/prof -name "*stats*" | head; 
 f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -n 25 "$f"
 fi
