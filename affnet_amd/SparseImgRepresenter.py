@@ -72,9 +72,12 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
     def _native(slot):
         return slot is None or isinstance(slot, _HipPatchNet)
 
-    def enqueue(self, x, do_ori=False, desc=None):
-        """Enqueues the whole fused path on the current stream and returns capacity-sized device
-        tensors plus the device row count - no host synchronisation (throughput / multi-stream use)."""
+    def enqueue(self, x, do_ori=False, desc=None, det_stream=None):
+        """Enqueues the whole fused path and returns capacity-sized device tensors plus the device row
+        count - no host synchronisation (throughput use).  With `det_stream` (a torch.cuda.Stream) the
+        pyramid + detector run there and the CNN stages on the current stream, ordered by events, so that
+        two extractor objects alternating over a stream of images overlap the latency-bound detector of
+        image i+1 with the MFMA-bound CNN stages of image i."""
         ctx = self._context(x)
         dev = x.device
         if do_ori and self.OriNet is None:
@@ -90,9 +93,25 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
         nets.d_affnet = self.AffNet.packed_weights(dev).data_ptr() if self.num_Baum_iters > 0 else None
         nets.d_orinet = self.OriNet.packed_weights(dev).data_ptr() if do_ori else None
         nets.d_hardnet = desc.packed_weights(dev).data_ptr() if desc is not None else None
-        rc = lib.affnet_extract_features(ctx.handle, C.byref(nets), ptr(img), int(bool(do_ori)), ptr(lafs), ptr(resp), ptr(ids),
-                                         ptr(dsc), ptr(count), engine.stream_of(dev))
-        check(rc, ctx.handle, "affnet_extract_features")
+        if det_stream is None:
+            rc = lib.affnet_extract_features(ctx.handle, C.byref(nets), ptr(img), int(bool(do_ori)), ptr(lafs), ptr(resp), ptr(ids),
+                                             ptr(dsc), ptr(count), engine.stream_of(dev))
+            check(rc, ctx.handle, "affnet_extract_features")
+        else:
+            cur = torch.cuda.current_stream(dev)
+            det_stream.wait_stream(cur)                      # image upload / previous users of x
+            if getattr(self, "_busy", None) is not None:
+                det_stream.wait_event(self._busy)            # workspace still read by the previous describe
+            rc = lib.affnet_detect_image(ctx.handle, ptr(img), C.c_void_p(det_stream.cuda_stream))
+            check(rc, ctx.handle, "affnet_detect_image")
+            ev = torch.cuda.Event()
+            ev.record(det_stream)
+            cur.wait_event(ev)
+            rc = lib.affnet_describe_detected(ctx.handle, C.byref(nets), int(bool(do_ori)), ptr(lafs), ptr(resp), ptr(ids), ptr(dsc),
+                                              ptr(count), engine.stream_of(dev))
+            check(rc, ctx.handle, "affnet_describe_detected")
+            self._busy = torch.cuda.Event()
+            self._busy.record(cur)
         return {"LAFs": lafs, "responses": resp, "ids": ids, "descriptors": dsc, "count": count, "_img": img}
 
     def run(self, x, do_ori=False, desc=None):

@@ -57,12 +57,15 @@ SYMBOLS = {
     "affnet_cnn32_pack_weights": (_I, [_I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _P, _P, _P, _P]),
     "affnet_cnn32_forward": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P]),
     "affnet_cnn32_forward_pyr": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
+    "affnet_cnn32_debug_timing": (_I, [_P]),
     "affnet_cnn32_debug_layer": (_I, [_P, _I, _P, _P, _I, _P, _P]),
     "affnet_shape_filter_select": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "affnet_apply_rotation": (_I, [_P, _P, _P, _P, _I, _P]),
     "affnet_scale_lafs": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "affnet_level_select": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     "affnet_extract_features": (_I, [_P, C.POINTER(Nets), _P, _I, _P, _P, _P, _P, _P, _P]),
+    "affnet_detect_image": (_I, [_P, _P, _P]),
+    "affnet_describe_detected": (_I, [_P, C.POINTER(Nets), _I, _P, _P, _P, _P, _P, _P]),
     "affnet_profile_enable": (_I, [_P, _I]),
     "affnet_profile_read": (_I, [_P, C.POINTER(C.c_double * 8), C.POINTER(C.c_int32)]),
     "affnet_read_counts": (_I, [_P, C.POINTER(C.c_int32 * 4), _P]),

@@ -24,18 +24,23 @@
 //     head (8192 x 128, 4.2 MB of weights) is a separate GEMM over all patches so the weights are
 //     read once per 16 patches instead of once per patch, with BN + L2 normalisation fused.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define PST32 1157   // plane strides (floats) of the padded 34x34 / 18x18 / 10x10 planes, odd => the
-#define PST16 325    // 16 lanes of an epilogue store (16 channels, same pixel) hit 16 distinct banks
-#define PST8 101
+// Plane strides (floats) of the padded 34x34 / 18x18 / 10x10 planes, all == 17 (mod 32): the 4 k-planes of
+// an A fragment (lanes 16..31 read the plane after lanes 0..15) land 17 banks apart -> at most 1 of 16 banks
+// collides inside a 32-lane half (PMC: SQ_LDS_BANK_CONFLICT was 47% of LDS cycles with stride == 5 mod 32),
+// the stride-2 layers are conflict free (even vs odd banks), and the epilogue stores (16 channels of one
+// pixel per 16 lanes) hit 16 distinct banks because 17 is odd.
+#define PST32 1169
+#define PST16 337
+#define PST8 113
 #define WP32 34
 #define WP16 18
 #define WP8 10
-#define CNN_THREADS 512
 #define HEAD_K 8192
 
 // ---- packed weight layout --------------------------------------------------------------------------
@@ -124,21 +129,25 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// Sum `v` over the 512 threads of the workgroup; red must hold >= 8 floats.  Two barriers.
+// Sum `v` over the NW wavefronts of the workgroup; red must hold >= NW floats.  Two barriers.
+template <int NW>
 __device__ __forceinline__ float block_sum(float v, float* red) {
     v = wave_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
-    return ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+    float t = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += red[w];
+    return t;
 }
 
 // Zero the 1-pixel halo of `cout` planes of an (H+2)x(H+2) padded layout.
-template <int H, int PST>
+template <int H, int PST, int NTHR>
 __device__ __forceinline__ void zero_halo(float* act, int cout) {
     constexpr int WP = H + 2;
     constexpr int CELLS = 4 * (H + 1);
-    for (int i = threadIdx.x; i < cout * CELLS; i += CNN_THREADS) {
+    for (int i = threadIdx.x; i < cout * CELLS; i += NTHR) {
         const int c = i / CELLS, e = i - c * CELLS;
         int y, x;
         if (e < WP) { y = 0; x = e; }
@@ -151,11 +160,11 @@ __device__ __forceinline__ void zero_halo(float* act, int cout) {
 // Implicit-GEMM 3x3 convolution (padding 1) of the planar LDS tensor `act` ([CIN][HIN+2][HIN+2],
 // plane stride PSI) with packed weights Wg [9*CIN][COUT]; leaves the TM x TN tiles of this wave in
 // `acc` (pre-activation, no bias).  HOUT = HIN / STRIDE.
-template <int CIN, int COUT, int HOUT, int STRIDE, int TM, int TN, int PSI, int WPI, int UNROLL>
+template <int NW, int CIN, int COUT, int HOUT, int STRIDE, int TM, int TN, int PSI, int WPI, int UNROLL>
 __device__ __forceinline__ void conv3x3_mfma(const float* act, const float* __restrict__ Wg, f32x4 (&acc)[TM][TN], int wave, int lane) {
     constexpr int MT = HOUT * HOUT / 16, NT = COUT / 16;
     constexpr int MG = MT / TM, NG = NT / TN;
-    static_assert(MG * NG == 8, "8 waves must tile the layer exactly");
+    static_assert(MG * NG == NW, "the waves must tile the layer exactly");
     static_assert(CIN % 4 == 0 && (CIN / 4) % UNROLL == 0, "bad unroll");
     const int mg = wave % MG, ng = wave / MG;
     const int m = lane & 15, kq = lane >> 4;
@@ -174,7 +183,9 @@ __device__ __forceinline__ void conv3x3_mfma(const float* act, const float* __re
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     // K = (tap, cin) is walked in chunks of 4*UNROLL; a chunk never straddles a tap (CIN % (4*UNROLL) == 0).
     // The B fragments (global / L2, ~1 us latency under load) of chunk c+1 are requested BEFORE the MFMAs of
-    // chunk c and consumed one iteration later; A fragments come from LDS right before use.
+    // chunk c and consumed one iteration later; A fragments come from LDS right before use.  (Also double
+    // buffering A in registers was measured SLOWER: hipcc turns the ping-pong into 64 v_mov per chunk pair and
+    // waits for the new loads at the end of the chunk.)
     constexpr int KSTEP = 4 * UNROLL;
     constexpr int NCHUNK = 9 * CIN / KSTEP;
     float bn[UNROLL][TN];
@@ -276,42 +287,61 @@ struct CnnArgs {
     float* out;            // AffNet/OriNet: (n,2,2); HardNet: trunk output (n,8192)
     int dbg_layer;         // >= 0: dump activations after this trunk layer of patch 0 and exit
     float* dbg_out;
+    unsigned long long* dbg_time;   // != NULL: s_memtime stamps [patch][wave][16] at the phase boundaries (tuning aid)
 };
+
+#define CNN_STAMP(k)                                                                                     \
+    do {                                                                                                 \
+        if (a.dbg_time && lane == 0) a.dbg_time[((size_t)pidx * NW + wave) * 16 + (k)] = __builtin_readcyclecounter(); \
+    } while (0)
 
 template <int CB>
 struct TrunkLds {
     static constexpr int ACT = CB * PST32;
     static constexpr int PATCH = WP32 * WP32;
-    static constexpr int TOTAL = ACT + PATCH + 64;
+    static constexpr int W0 = 12 * 32;                  // conv0 taps + bias, 12 floats per output channel
+    static constexpr int TOTAL = ACT + PATCH + 64 + W0;
 };
 
-template <int C, int H, int PST>
+template <int C, int H, int PST, int NTHR>
 __device__ __forceinline__ void dump_planes(const float* act, float* dst) {
     constexpr int WP = H + 2;
-    for (int i = threadIdx.x; i < C * H * H; i += CNN_THREADS) {
+    for (int i = threadIdx.x; i < C * H * H; i += NTHR) {
         const int c = i / (H * H), r = i - c * H * H, y = r / H, x = r - y * H;
         dst[i] = act[c * PST + (y + 1) * WP + x + 1];
     }
 }
 
-// KIND: 0 AffNet, 1 OriNet, 2 HardNet.  CB = 16 for KIND 0/1, 32 for KIND 2.
-template <int KIND>
-__global__ __launch_bounds__(CNN_THREADS, (KIND == AFFNET_NET_HARDNET) ? 2 : 4) void cnn32_trunk_kernel(CnnArgs a, PyrSrc ps) {
+// KIND: 0 AffNet, 1 OriNet, 2 HardNet (CB = 16 / 16 / 32).  NW = wavefronts per workgroup (8 or 16).
+// AffNet / OriNet: 8 waves, 79 KB LDS -> 2 workgroups per CU (4 waves / SIMD).  HardNet needs 154 KB LDS
+// (1 workgroup per CU): 16 waves give the CU 4 waves / SIMD to cover LDS / L2 latency and barriers.
+template <int KIND, int NW>
+__global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4) void cnn32_trunk_kernel(CnnArgs a, PyrSrc ps) {
     constexpr int CB = (KIND == AFFNET_NET_HARDNET) ? 32 : 16;
+    constexpr int NTHR = NW * 64;
+    constexpr int PPT = 1024 / NTHR;                    // input pixels per thread (2 or 1)
+    constexpr int RPT = 32 / PPT;                       // patch rows covered by one pass of the workgroup
+    // per-wave register blocking (TM x TN tiles of 16 px x 16 ch); MG * NG == NW for every layer
+    constexpr int T1M = (CB == 16) ? 8 : 64 / NW, T1N = CB / 16;
+    constexpr int T2M = (CB == 16) ? 2 : 32 / NW, T2N = 2;
+    constexpr int T4M = (CB == 16) ? 2 : 32 / NW, T4N = 1;
     __shared__ __attribute__((aligned(16))) float lds[TrunkLds<CB>::TOTAL];
     float* act = lds;
     float* patch = lds + TrunkLds<CB>::ACT;
     float* red = patch + TrunkLds<CB>::PATCH;
+    float* w0s = red + 64;                              // [CB][12]: 9 taps, bias, 2 pad (16-byte rows)
     const int pidx = blockIdx.x;
     const int n = a.count ? min(*a.count, a.n_max) : a.n_max;
     if (pidx >= n) return;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    CNN_STAMP(0);
 
-    // ---- input: load or sample 1024 pixels (2 per thread), standardise, store padded --------------
-    float v0, v1;
+    // ---- input: load or sample 1024 pixels (PPT per thread), standardise, store padded ----------------
+    float v[PPT];
     if (a.patches) {
         const float* src = a.patches + (size_t)pidx * 1024;
-        v0 = src[tid]; v1 = src[tid + 512];
+#pragma unroll
+        for (int q = 0; q < PPT; ++q) v[q] = src[tid + q * NTHR];
     } else {
         int o = a.ids[3 * pidx], l = a.ids[3 * pidx + 1];
         o = o < 0 ? 0 : (o >= ps.n_octaves ? ps.n_octaves - 1 : o);
@@ -322,101 +352,126 @@ __global__ __launch_bounds__(CNN_THREADS, (KIND == AFFNET_NET_HARDNET) ? 2 : 4) 
         const float m = (float)(h < w ? h : w);
         const float t00 = L[0] * m, t01 = L[1] * m, t02 = L[2] * (float)w;
         const float t10 = L[3] * m, t11 = L[4] * m, t12 = L[5] * (float)h;
-        v0 = aff_sample_bilinear(img, h, w, t00, t01, t02, t10, t11, t12, ps.base[tid & 31], ps.base[tid >> 5]);
-        v1 = aff_sample_bilinear(img, h, w, t00, t01, t02, t10, t11, t12, ps.base[tid & 31], ps.base[(tid >> 5) + 16]);
+#pragma unroll
+        for (int q = 0; q < PPT; ++q)
+            v[q] = aff_sample_bilinear(img, h, w, t00, t01, t02, t10, t11, t12, ps.base[tid & 31], ps.base[(tid >> 5) + q * RPT]);
     }
-    for (int i = tid; i < WP32 * WP32; i += CNN_THREADS) patch[i] = 0.0f;   // halo (interior overwritten below)
-    const float mean = block_sum(v0 + v1, red) * (1.0f / 1024.0f);
-    const float d0 = v0 - mean, d1 = v1 - mean;
-    const float var = block_sum(d0 * d0 + d1 * d1, red) * (1.0f / 1023.0f);    // torch.std: unbiased
+    for (int i = tid; i < WP32 * WP32; i += NTHR) patch[i] = 0.0f;   // halo (interior overwritten below)
+    // conv0 taps + bias -> LDS once per workgroup (as uniform scalar loads inside the channel loop they cost
+    // 21-34k cycles per patch: a chain of dependent L2 round trips)
+    for (int i = tid; i < CB * 12; i += NTHR) {
+        const int c = i / 12, t = i - c * 12;
+        w0s[i] = t < 9 ? a.packed[a.off.w[0] + c * 9 + t] : (t == 9 ? a.packed[a.off.b[0] + c] : 0.0f);
+    }
+    float sum = 0.f;
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) sum += v[q];
+    const float mean = block_sum<NW>(sum, red) * (1.0f / 1024.0f);
+    float sq = 0.f;
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) { v[q] -= mean; sq += v[q] * v[q]; }
+    const float var = block_sum<NW>(sq, red) * (1.0f / 1023.0f);       // torch.std: unbiased
     const float sd = sqrtf(var) + 1e-7f;
-    patch[((tid >> 5) + 1) * WP32 + (tid & 31) + 1] = d0 / sd;
-    patch[((tid >> 5) + 17) * WP32 + (tid & 31) + 1] = d1 / sd;
-    zero_halo<32, PST32>(act, CB);
+#pragma unroll
+    for (int q = 0; q < PPT; ++q) patch[((tid >> 5) + q * RPT + 1) * WP32 + (tid & 31) + 1] = v[q] / sd;
+    zero_halo<32, PST32, NTHR>(act, CB);
     __syncthreads();
+    CNN_STAMP(1);
 
     // ---- conv0: 1 -> CB, K = 9, VALU ---------------------------------------------------------------
     {
-        const float* w0 = a.packed + a.off.w[0];
-        const float* b0 = a.packed + a.off.b[0];
+        float q[PPT][9];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int y = (tid >> 5) + 16 * half, x = tid & 31;
-            float q[9];
+        for (int qq = 0; qq < PPT; ++qq) {
+            const int y = (tid >> 5) + qq * RPT, x = tid & 31;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) q[t] = patch[(y + t / 3) * WP32 + x + t % 3];
+            for (int t = 0; t < 9; ++t) q[qq][t] = patch[(y + t / 3) * WP32 + x + t % 3];
+        }
 #pragma unroll 4
-            for (int c = 0; c < CB; ++c) {
-                float s = b0[c];
+        for (int c = 0; c < CB; ++c) {
+            const float4 wa = *reinterpret_cast<const float4*>(&w0s[c * 12]);        // broadcast reads
+            const float4 wb = *reinterpret_cast<const float4*>(&w0s[c * 12 + 4]);
+            const float4 wc = *reinterpret_cast<const float4*>(&w0s[c * 12 + 8]);
+            const float wt[9] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w, wc.x};
 #pragma unroll
-                for (int t = 0; t < 9; ++t) s = fmaf(q[t], w0[c * 9 + t], s);
-                act[c * PST32 + (y + 1) * WP32 + x + 1] = fmaxf(s, 0.0f);
+            for (int qq = 0; qq < PPT; ++qq) {
+                const int y = (tid >> 5) + qq * RPT, x = tid & 31;
+                float sacc = wc.y;                                                   // bias
+#pragma unroll
+                for (int t = 0; t < 9; ++t) sacc = fmaf(q[qq][t], wt[t], sacc);
+                act[c * PST32 + (y + 1) * WP32 + x + 1] = fmaxf(sacc, 0.0f);
             }
         }
     }
     __syncthreads();
-    if (a.dbg_layer == 0) { dump_planes<CB, 32, PST32>(act, a.dbg_out); return; }
+    if (a.dbg_layer == 0) { dump_planes<CB, 32, PST32, NTHR>(act, a.dbg_out); return; }
+    CNN_STAMP(2);
 
     // ---- conv1: CB -> CB @32x32 --------------------------------------------------------------------
     {
-        constexpr int TN = CB / 16;
-        f32x4 acc[8][TN];
-        conv3x3_mfma<CB, CB, 32, 1, 8, TN, PST32, WP32, 4>(act, a.packed + a.off.w[1], acc, wave, lane);
+        f32x4 acc[T1M][T1N];
+        conv3x3_mfma<NW, CB, CB, 32, 1, T1M, T1N, PST32, WP32, 4>(act, a.packed + a.off.w[1], acc, wave, lane);
+        CNN_STAMP(3);
         __syncthreads();
-        store_tiles_lds<CB, 32, 8, TN, PST32>(act, a.packed + a.off.b[1], acc, wave, lane);   // halo already zero
+        store_tiles_lds<CB, 32, T1M, T1N, PST32>(act, a.packed + a.off.b[1], acc, wave, lane);   // halo already zero
         __syncthreads();
+        CNN_STAMP(4);
     }
-    if (a.dbg_layer == 1) { dump_planes<CB, 32, PST32>(act, a.dbg_out); return; }
+    if (a.dbg_layer == 1) { dump_planes<CB, 32, PST32, NTHR>(act, a.dbg_out); return; }
 
     // ---- conv2: CB -> 2CB, stride 2 @16x16 -----------------------------------------------------------
     {
-        constexpr int TM = CB / 8, TN = 2;              // 16: 2x2 (MG 8, NG 1) ; 32: 4x2 (MG 4, NG 2)
-        f32x4 acc[TM][TN];
-        conv3x3_mfma<CB, 2 * CB, 16, 2, TM, TN, PST32, WP32, 4>(act, a.packed + a.off.w[2], acc, wave, lane);
+        f32x4 acc[T2M][T2N];
+        conv3x3_mfma<NW, CB, 2 * CB, 16, 2, T2M, T2N, PST32, WP32, 4>(act, a.packed + a.off.w[2], acc, wave, lane);
+        CNN_STAMP(5);
         __syncthreads();
-        zero_halo<16, PST16>(act, 2 * CB);
-        store_tiles_lds<2 * CB, 16, TM, TN, PST16>(act, a.packed + a.off.b[2], acc, wave, lane);
+        zero_halo<16, PST16, NTHR>(act, 2 * CB);
+        store_tiles_lds<2 * CB, 16, T2M, T2N, PST16>(act, a.packed + a.off.b[2], acc, wave, lane);
         __syncthreads();
+        CNN_STAMP(6);
     }
-    if (a.dbg_layer == 2) { dump_planes<2 * CB, 16, PST16>(act, a.dbg_out); return; }
+    if (a.dbg_layer == 2) { dump_planes<2 * CB, 16, PST16, NTHR>(act, a.dbg_out); return; }
 
     // ---- conv3: 2CB -> 2CB @16x16 --------------------------------------------------------------------
     {
-        constexpr int TM = CB / 8, TN = 2;
-        f32x4 acc[TM][TN];
-        conv3x3_mfma<2 * CB, 2 * CB, 16, 1, TM, TN, PST16, WP16, 8>(act, a.packed + a.off.w[3], acc, wave, lane);
+        f32x4 acc[T2M][T2N];
+        conv3x3_mfma<NW, 2 * CB, 2 * CB, 16, 1, T2M, T2N, PST16, WP16, 8>(act, a.packed + a.off.w[3], acc, wave, lane);
+        CNN_STAMP(7);
         __syncthreads();
-        store_tiles_lds<2 * CB, 16, TM, TN, PST16>(act, a.packed + a.off.b[3], acc, wave, lane);
+        store_tiles_lds<2 * CB, 16, T2M, T2N, PST16>(act, a.packed + a.off.b[3], acc, wave, lane);
         __syncthreads();
+        CNN_STAMP(8);
     }
-    if (a.dbg_layer == 3) { dump_planes<2 * CB, 16, PST16>(act, a.dbg_out); return; }
+    if (a.dbg_layer == 3) { dump_planes<2 * CB, 16, PST16, NTHR>(act, a.dbg_out); return; }
 
     // ---- conv4: 2CB -> 4CB, stride 2 @8x8 --------------------------------------------------------------
     {
-        constexpr int TM = CB / 8, TN = 1;              // 16: 2x1 (MG 2, NG 4) ; 32: 4x1 (MG 1, NG 8)
-        f32x4 acc[TM][TN];
-        conv3x3_mfma<2 * CB, 4 * CB, 8, 2, TM, TN, PST16, WP16, 8>(act, a.packed + a.off.w[4], acc, wave, lane);
+        f32x4 acc[T4M][T4N];
+        conv3x3_mfma<NW, 2 * CB, 4 * CB, 8, 2, T4M, T4N, PST16, WP16, 8>(act, a.packed + a.off.w[4], acc, wave, lane);
+        CNN_STAMP(9);
         __syncthreads();
-        zero_halo<8, PST8>(act, 4 * CB);
-        store_tiles_lds<4 * CB, 8, TM, TN, PST8>(act, a.packed + a.off.b[4], acc, wave, lane);
+        zero_halo<8, PST8, NTHR>(act, 4 * CB);
+        store_tiles_lds<4 * CB, 8, T4M, T4N, PST8>(act, a.packed + a.off.b[4], acc, wave, lane);
         __syncthreads();
+        CNN_STAMP(10);
     }
-    if (a.dbg_layer == 4) { dump_planes<4 * CB, 8, PST8>(act, a.dbg_out); return; }
+    if (a.dbg_layer == 4) { dump_planes<4 * CB, 8, PST8, NTHR>(act, a.dbg_out); return; }
 
     // ---- conv5: 4CB -> 4CB @8x8 ------------------------------------------------------------------------
     {
-        constexpr int TM = CB / 8, TN = 1;
-        f32x4 acc[TM][TN];
-        conv3x3_mfma<4 * CB, 4 * CB, 8, 1, TM, TN, PST8, WP8, 8>(act, a.packed + a.off.w[5], acc, wave, lane);
+        f32x4 acc[T4M][T4N];
+        conv3x3_mfma<NW, 4 * CB, 4 * CB, 8, 1, T4M, T4N, PST8, WP8, 8>(act, a.packed + a.off.w[5], acc, wave, lane);
+        CNN_STAMP(11);
         if (KIND == AFFNET_NET_HARDNET && a.dbg_layer < 0) {
-            store_tiles_global<4 * CB, TM, TN>(a.out + (size_t)pidx * HEAD_K, a.packed + a.off.b[5], acc, wave, lane);
+            store_tiles_global<4 * CB, T4M, T4N>(a.out + (size_t)pidx * HEAD_K, a.packed + a.off.b[5], acc, wave, lane);
             return;
         }
         __syncthreads();
-        store_tiles_lds<4 * CB, 8, TM, TN, PST8>(act, a.packed + a.off.b[5], acc, wave, lane);
+        store_tiles_lds<4 * CB, 8, T4M, T4N, PST8>(act, a.packed + a.off.b[5], acc, wave, lane);
         __syncthreads();
+        CNN_STAMP(12);
     }
-    if (a.dbg_layer == 5) { dump_planes<4 * CB, 8, PST8>(act, a.dbg_out); return; }
+    if (a.dbg_layer == 5) { dump_planes<4 * CB, 8, PST8, NTHR>(act, a.dbg_out); return; }
 
     // ---- heads (AffNet / OriNet), VALU -----------------------------------------------------------------
     if (KIND == AFFNET_NET_AFFNET) {
@@ -424,12 +479,12 @@ __global__ __launch_bounds__(CNN_THREADS, (KIND == AFFNET_NET_HARDNET) ? 2 : 4) 
         const float* hw = a.packed + a.off.head_w;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int e = tid; e < 4096; e += CNN_THREADS) {
+        for (int e = tid; e < 4096; e += NTHR) {
             const int c = e >> 6, y = (e >> 3) & 7, x = e & 7;
-            const float v = act[c * PST8 + (y + 1) * WP8 + x + 1];
-            s0 = fmaf(v, hw[e], s0); s1 = fmaf(v, hw[4096 + e], s1); s2 = fmaf(v, hw[8192 + e], s2);
+            const float vv = act[c * PST8 + (y + 1) * WP8 + x + 1];
+            s0 = fmaf(vv, hw[e], s0); s1 = fmaf(vv, hw[4096 + e], s1); s2 = fmaf(vv, hw[8192 + e], s2);
         }
-        s0 = block_sum(s0, red); s1 = block_sum(s1, red); s2 = block_sum(s2, red);
+        s0 = block_sum<NW>(s0, red); s1 = block_sum<NW>(s1, red); s2 = block_sum<NW>(s2, red);
         if (tid == 0) {
             const float* hb = a.packed + a.off.head_b;
             const float x0 = tanhf(s0 + hb[0]), x1 = tanhf(s1 + hb[1]), x2 = tanhf(s2 + hb[2]);
@@ -449,13 +504,13 @@ __global__ __launch_bounds__(CNN_THREADS, (KIND == AFFNET_NET_HARDNET) ? 2 : 4) 
         for (int o = 0; o < 2; ++o)
 #pragma unroll
             for (int q = 0; q < 9; ++q) s[o][q] = 0.f;
-        for (int e = tid; e < 4096; e += CNN_THREADS) {
+        for (int e = tid; e < 4096; e += NTHR) {
             const int c = e >> 6, ky = (e >> 3) & 7, kx = e & 7;
             const float w0 = hw[e], w1 = hw[4096 + e];
 #pragma unroll
             for (int q = 0; q < 9; ++q) {
-                const float v = act[c * PST8 + (q / 3 + ky) * WP8 + (q % 3) + kx];
-                s[0][q] = fmaf(v, w0, s[0][q]); s[1][q] = fmaf(v, w1, s[1][q]);
+                const float vv = act[c * PST8 + (q / 3 + ky) * WP8 + (q % 3) + kx];
+                s[0][q] = fmaf(vv, w0, s[0][q]); s[1][q] = fmaf(vv, w1, s[1][q]);
             }
         }
         // reduce the 18 partial sums: wave shuffles, then one LDS exchange ([wave][18]) - 2 barriers in total
@@ -472,17 +527,15 @@ __global__ __launch_bounds__(CNN_THREADS, (KIND == AFFNET_NET_HARDNET) ? 2 : 4) 
                 for (int q = 0; q < 9; ++q) red2[wave * 18 + o * 9 + q] = s[o][q];
         }
         __syncthreads();
-        float t0 = 0.f, t1 = 0.f;
-        const float* hb = a.packed + a.off.head_b;
         if (tid == 0) {
+            float t0 = 0.f, t1 = 0.f;
+            const float* hb = a.packed + a.off.head_b;
 #pragma unroll
             for (int q = 0; q < 9; ++q) {
                 float r0 = 0.f, r1 = 0.f;
-                for (int wv = 0; wv < 8; ++wv) { r0 += red2[wv * 18 + q]; r1 += red2[wv * 18 + 9 + q]; }
+                for (int wv = 0; wv < NW; ++wv) { r0 += red2[wv * 18 + q]; r1 += red2[wv * 18 + 9 + q]; }
                 t0 += tanhf(r0 + hb[0]); t1 += tanhf(r1 + hb[1]);
             }
-        }
-        if (tid == 0) {
             const float yv = t0 / 9.0f, xv = t1 / 9.0f;                       // AdaptiveAvgPool2d(1)
             const float ang = atan2f(yv + 1e-8f, xv + 1e-8f);                 // architectures.py:78
             const float sn = sinf(ang), cs = cosf(ang);
@@ -587,6 +640,8 @@ void aff_fill_pyr_src(const affnet_ctx* ctx, PyrSrc* t) {
     aff_base_grid(32, t->base);
 }
 
+static unsigned long long* g_dbg_time = nullptr;   // tuning aid, see affnet_cnn32_debug_timing
+
 static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const float* patches, const float* lafs, const int32_t* ids,
                       const int32_t* count, int n_max, float* out, float* scratch, int dbg_layer, float* dbg_out, hipStream_t st,
                       bool mark_head = false) {
@@ -599,13 +654,15 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
     CnnArgs a;
     a.packed = packed; a.off = to_offsets(L); a.patches = patches; a.lafs = lafs; a.ids = ids; a.count = count; a.n_max = n_max;
     a.out = (kind == AFFNET_NET_HARDNET) ? scratch : out;
-    a.dbg_layer = dbg_layer; a.dbg_out = dbg_out;
+    a.dbg_layer = dbg_layer; a.dbg_out = dbg_out; a.dbg_time = g_dbg_time;
     PyrSrc ps;
     aff_fill_pyr_src(ctx, &ps);
-    const dim3 grid(n_max), block(CNN_THREADS);
-    if (kind == AFFNET_NET_AFFNET) hipLaunchKernelGGL(cnn32_trunk_kernel<AFFNET_NET_AFFNET>, grid, block, 0, st, a, ps);
-    else if (kind == AFFNET_NET_ORINET) hipLaunchKernelGGL(cnn32_trunk_kernel<AFFNET_NET_ORINET>, grid, block, 0, st, a, ps);
-    else hipLaunchKernelGGL(cnn32_trunk_kernel<AFFNET_NET_HARDNET>, grid, block, 0, st, a, ps);
+    const dim3 grid(n_max);
+    static const int hard_waves = []() { const char* e = getenv("AFFNET_HARDNET_WAVES"); return (e && atoi(e) == 16) ? 16 : 8; }();
+    if (kind == AFFNET_NET_AFFNET) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_AFFNET, 8>), grid, dim3(512), 0, st, a, ps);
+    else if (kind == AFFNET_NET_ORINET) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_ORINET, 8>), grid, dim3(512), 0, st, a, ps);
+    else if (hard_waves == 8) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_HARDNET, 8>), grid, dim3(512), 0, st, a, ps);
+    else hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_HARDNET, 16>), grid, dim3(1024), 0, st, a, ps);
     AFF_LAUNCH_CHECK(ctx);
     if (mark_head) aff_prof_mark(ctx, 7, st);
     if (kind == AFFNET_NET_HARDNET && dbg_layer < 0) {
@@ -634,6 +691,11 @@ extern "C" int affnet_cnn32_forward_pyr(affnet_ctx* ctx, int net_kind, const flo
 int aff_hardnet_forward_pyr_marked(affnet_ctx* ctx, const float* packed, const float* lafs, const int32_t* ids, const int32_t* count,
                                    int n_max, float* out, float* scratch, hipStream_t st) {
     return cnn_launch(ctx, AFFNET_NET_HARDNET, packed, nullptr, lafs, ids, count, n_max, out, scratch, -1, nullptr, st, true);
+}
+
+extern "C" int affnet_cnn32_debug_timing(unsigned long long* d_stamps) {
+    g_dbg_time = d_stamps;   // device buffer of n_patches * waves * 16 uint64, or NULL to switch the stamps off
+    return AFFNET_OK;
 }
 
 extern "C" int affnet_cnn32_debug_layer(affnet_ctx* ctx, int net_kind, const float* d_packed, const float* d_patch, int layer, float* d_out,

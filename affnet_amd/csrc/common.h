@@ -70,11 +70,12 @@ struct affnet_ctx {
     int32_t* st_rank = nullptr;          // partial ranks / positions of the two selection stages (cap_pre ints)
     // stage profiling (HIP events on the caller's stream)
     bool prof_on = false;
-    std::vector<hipEvent_t> prof_ev;   // ring: PROF_RING calls x (AFFNET_PROFILE_STAGES + 1) events
+    std::vector<hipEvent_t> prof_ev;   // ring: PROF_RING calls x PROF_EVENTS events
     int prof_calls = 0;
 };
 
 #define PROF_RING 256
+#define PROF_EVENTS (AFFNET_PROFILE_STAGES + 2)   // 9 stage boundaries + end-of-detector (index 9)
 // pipeline.hip / cnn32.hip: record stage boundary `idx` of the current call (no-op when disabled)
 void aff_prof_mark(affnet_ctx* ctx, int idx, hipStream_t st);
 

@@ -215,57 +215,81 @@ struct ResolveParams {
 };
 
 __global__ __launch_bounds__(1024) void octave_resolve_kernel(ResolveParams p) {
+    // Each thread keeps up to RES_PER entries of the level in registers across the count barrier, with the
+    // (independent) raw[] and octaveMap loads of all its entries in flight together; the former
+    // one-entry-at-a-time loop was a chain of ~170 dependent global round trips per octave.
+    constexpr int RES_PER = 4;
     const int o = blockIdx.x;
     __shared__ int s_pos;
     RawMax* raw = p.raw[o];
     volatile uint8_t* omap = p.omap[o];
     int n = p.cnt[CNT_RAW0 + o];
     if (n > p.raw_cap[o]) n = p.raw_cap[o];
+    const int lane = threadIdx.x & 63;
     for (int l = 1; l <= p.n_detect_levels; ++l) {
         if (threadIdx.x == 0) s_pos = 0;
         __syncthreads();
+        // ---- pass 1: v = nms * (1 - float(octaveMap)) for every entry of this level, count v > 0 ----
         int local = 0;
-        for (int i = threadIdx.x; i < n; i += 1024) {
-            if (raw[i].lvl != l) continue;
-            const float v = raw[i].val * (1.0f - (float)omap[raw[i].pix]);
-            if (v > 0.0f) ++local;
+        for (int i0 = 0; i0 < n; i0 += 1024 * RES_PER) {
+            RawMax r[RES_PER];
+            bool mine[RES_PER];
+#pragma unroll
+            for (int q = 0; q < RES_PER; ++q) {
+                const int i = i0 + q * 1024 + threadIdx.x;
+                mine[q] = i < n;
+                if (mine[q]) r[q] = raw[i];
+                mine[q] = mine[q] && r[q].lvl == l;
+            }
+#pragma unroll
+            for (int q = 0; q < RES_PER; ++q)
+                if (mine[q]) local += (r[q].val * (1.0f - (float)omap[r[q].pix])) > 0.0f;
         }
         if (local) atomicAdd(&s_pos, local);
         __syncthreads();
         const int n_pos = s_pos;
         __syncthreads();
         if (n_pos <= 1) continue;                      // HandCraftedModules.py:252-254: level skipped, octaveMap unchanged
-        for (int i0 = 0; i0 < n; i0 += 1024) {
-            const int i = i0 + threadIdx.x;
-            bool emit = false;
-            float v = 0.f;
-            RawMax r;
-            if (i < n) {
-                r = raw[i];
-                if (r.lvl == l) {
-                    const float m = (float)omap[r.pix];
-                    v = r.val * (1.0f - m);
-                    const float sum = m + v;
-                    omap[r.pix] = (uint8_t)(long long)sum;   // float -> int64 -> uint8 wrap, as torch's CPU .byte()
+        // ---- pass 2: update the octaveMap, emit accepted candidates ------------------------------------
+        for (int i0 = 0; i0 < n; i0 += 1024 * RES_PER) {
+            RawMax r[RES_PER];
+            bool mine[RES_PER];
+            float mval[RES_PER];
+#pragma unroll
+            for (int q = 0; q < RES_PER; ++q) {
+                const int i = i0 + q * 1024 + threadIdx.x;
+                mine[q] = i < n;
+                if (mine[q]) r[q] = raw[i];
+                mine[q] = mine[q] && r[q].lvl == l;
+            }
+#pragma unroll
+            for (int q = 0; q < RES_PER; ++q) mval[q] = mine[q] ? (float)omap[r[q].pix] : 0.0f;
+#pragma unroll
+            for (int q = 0; q < RES_PER; ++q) {
+                float v = 0.f;
+                bool emit = false;
+                if (mine[q]) {
+                    v = r[q].val * (1.0f - mval[q]);
+                    const float sum = mval[q] + v;
+                    omap[r[q].pix] = (uint8_t)(long long)sum;   // float -> int64 -> uint8 wrap, as torch's CPU .byte()
                     emit = v != 0.0f;
                 }
-            }
-            // one global atomic per wavefront instead of one per candidate
-            const unsigned long long bal = __ballot(emit);
-            const int lane = threadIdx.x & 63;
-            int wbase = 0;
-            if (bal) {
-                if (lane == 0) wbase = atomicAdd(&p.cnt[CNT_CAND], __popcll(bal));
-                wbase = __shfl(wbase, 0, 64);
-            }
-            if (emit) {
-                const int slot = wbase + __popcll(bal & ((1ull << lane) - 1ull));
-                if (slot < p.cand_cap) {
-                    p.cand_resp[slot] = v;
-                    p.cand_syx[3 * slot] = r.s; p.cand_syx[3 * slot + 1] = r.y; p.cand_syx[3 * slot + 2] = r.x;
-                    p.cand_ids[3 * slot] = o; p.cand_ids[3 * slot + 1] = l - 1; p.cand_ids[3 * slot + 2] = r.pix;
-                } else {
-                    atomicOr(&p.cnt[CNT_OVERFLOW], 2);
+                // one global atomic per wavefront instead of one per candidate
+                const unsigned long long bal = __ballot(emit);
+                int wbase = 0;
+                if (bal) {
+                    if (lane == 0) wbase = atomicAdd(&p.cnt[CNT_CAND], __popcll(bal));
+                    wbase = __shfl(wbase, 0, 64);
+                }
+                if (emit) {
+                    const int slot = wbase + __popcll(bal & ((1ull << lane) - 1ull));
+                    if (slot < p.cand_cap) {
+                        p.cand_resp[slot] = v;
+                        p.cand_syx[3 * slot] = r[q].s; p.cand_syx[3 * slot + 1] = r[q].y; p.cand_syx[3 * slot + 2] = r[q].x;
+                        p.cand_ids[3 * slot] = o; p.cand_ids[3 * slot + 1] = l - 1; p.cand_ids[3 * slot + 2] = r[q].pix;
+                    } else {
+                        atomicOr(&p.cnt[CNT_OVERFLOW], 2);
+                    }
                 }
             }
         }

@@ -12,13 +12,13 @@
 
 void aff_prof_mark(affnet_ctx* ctx, int idx, hipStream_t st) {
     if (!ctx->prof_on || ctx->prof_calls >= PROF_RING) return;
-    (void)hipEventRecord(ctx->prof_ev[(size_t)ctx->prof_calls * (AFFNET_PROFILE_STAGES + 1) + idx], st);
+    (void)hipEventRecord(ctx->prof_ev[(size_t)ctx->prof_calls * PROF_EVENTS + idx], st);
 }
 
 extern "C" int affnet_profile_enable(affnet_ctx* ctx, int on) {
     if (!ctx) return AFFNET_ERR_INVALID;
     if (on && ctx->prof_ev.empty()) {
-        ctx->prof_ev.resize((size_t)PROF_RING * (AFFNET_PROFILE_STAGES + 1));
+        ctx->prof_ev.resize((size_t)PROF_RING * PROF_EVENTS);
         for (auto& e : ctx->prof_ev) AFF_HIP(ctx, hipEventCreate(&e));
     }
     ctx->prof_on = on != 0;
@@ -33,8 +33,9 @@ extern "C" int affnet_profile_read(affnet_ctx* ctx, double sum_ms[AFFNET_PROFILE
     for (int c = 0; c < ctx->prof_calls; ++c)
         for (int s = 0; s < AFFNET_PROFILE_STAGES; ++s) {
             float ms = 0.f;
-            const size_t b = (size_t)c * (AFFNET_PROFILE_STAGES + 1);
-            AFF_HIP(ctx, hipEventElapsedTime(&ms, ctx->prof_ev[b + s], ctx->prof_ev[b + s + 1]));
+            const size_t b = (size_t)c * PROF_EVENTS;
+            // the detector may run on another stream than the CNN stages: its end has its own event (9)
+            AFF_HIP(ctx, hipEventElapsedTime(&ms, ctx->prof_ev[b + s], ctx->prof_ev[b + (s == 1 ? 9 : s + 1)]));
             sum_ms[s] += ms;
         }
     ctx->prof_calls = 0;
@@ -45,21 +46,29 @@ extern "C" int affnet_profile_read(affnet_ctx* ctx, double sum_ms[AFFNET_PROFILE
 int aff_hardnet_forward_pyr_marked(affnet_ctx* ctx, const float* packed, const float* lafs, const int32_t* ids, const int32_t* count,
                                    int n_max, float* out, float* scratch, hipStream_t st);
 
-extern "C" int affnet_extract_features(affnet_ctx* ctx, const affnet_nets* nets, const float* d_img, int do_ori, float* d_lafs_px,
-                                       float* d_resp, int32_t* d_ids, float* d_desc, int32_t* d_count, void* stream) {
-    if (!ctx || !ctx->ws || !nets || !d_img || !d_lafs_px || !d_resp || !d_ids || !d_count)
-        return aff_fail(ctx, AFFNET_ERR_INVALID, "extract_features: context not bound or null argument");
-    if (do_ori && !nets->d_orinet) return aff_fail(ctx, AFFNET_ERR_INVALID, "extract_features: do_ori needs OriNet weights");
-    if (d_desc && !nets->d_hardnet) return aff_fail(ctx, AFFNET_ERR_INVALID, "extract_features: descriptors need HardNet weights");
+extern "C" int affnet_detect_image(affnet_ctx* ctx, const float* d_img, void* stream) {
+    if (!ctx || !ctx->ws || !d_img) return aff_fail(ctx, AFFNET_ERR_INVALID, "detect_image: context not bound or null image");
     hipStream_t st = (hipStream_t)stream;
-    const int P = ctx->cap_pre, F = ctx->cap_final;
     aff_prof_mark(ctx, 0, st);
     int rc = affnet_pyramid_build(ctx, d_img, stream);
     if (rc) return rc;
     aff_prof_mark(ctx, 1, st);
-    int32_t* det_count = ctx->cnt + CNT_DET;
     rc = affnet_detect(ctx, ctx->st_det_resp, ctx->st_det_lafs, ctx->st_det_ids, nullptr, stream);
     if (rc) return rc;
+    aff_prof_mark(ctx, 9, st);
+    return AFFNET_OK;
+}
+
+extern "C" int affnet_describe_detected(affnet_ctx* ctx, const affnet_nets* nets, int do_ori, float* d_lafs_px, float* d_resp,
+                                        int32_t* d_ids, float* d_desc, int32_t* d_count, void* stream) {
+    if (!ctx || !ctx->ws || !nets || !d_lafs_px || !d_resp || !d_ids || !d_count)
+        return aff_fail(ctx, AFFNET_ERR_INVALID, "describe_detected: context not bound or null argument");
+    if (do_ori && !nets->d_orinet) return aff_fail(ctx, AFFNET_ERR_INVALID, "describe_detected: do_ori needs OriNet weights");
+    if (d_desc && !nets->d_hardnet) return aff_fail(ctx, AFFNET_ERR_INVALID, "describe_detected: descriptors need HardNet weights");
+    hipStream_t st = (hipStream_t)stream;
+    const int P = ctx->cap_pre, F = ctx->cap_final;
+    int rc;
+    int32_t* det_count = ctx->cnt + CNT_DET;
     aff_prof_mark(ctx, 2, st);
     if (nets->d_affnet) {
         rc = affnet_cnn32_forward_pyr(ctx, AFFNET_NET_AFFNET, nets->d_affnet, ctx->st_det_lafs, ctx->st_det_ids, det_count, P, ctx->st_A,
@@ -72,7 +81,7 @@ extern "C" int affnet_extract_features(affnet_ctx* ctx, const affnet_nets* nets,
     } else {
         aff_prof_mark(ctx, 3, st);
         // num_Baum_iters == 0: detections pass through unchanged (C == N)
-        if (F != P) return aff_fail(ctx, AFFNET_ERR_INVALID, "extract_features: without AffNet num_prefilter must equal num_features");
+        if (F != P) return aff_fail(ctx, AFFNET_ERR_INVALID, "describe_detected: without AffNet num_prefilter must equal num_features");
         AFF_HIP(ctx, hipMemcpyAsync(d_resp, ctx->st_det_resp, (size_t)F * sizeof(float), hipMemcpyDeviceToDevice, st));
         AFF_HIP(ctx, hipMemcpyAsync(ctx->st_lafs_shaped, ctx->st_det_lafs, (size_t)F * 6 * sizeof(float), hipMemcpyDeviceToDevice, st));
         AFF_HIP(ctx, hipMemcpyAsync(d_ids, ctx->st_det_ids, (size_t)F * 3 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
@@ -105,4 +114,11 @@ extern "C" int affnet_extract_features(affnet_ctx* ctx, const affnet_nets* nets,
     aff_prof_mark(ctx, 8, st);
     if (ctx->prof_on && ctx->prof_calls < PROF_RING) ++ctx->prof_calls;
     return AFFNET_OK;
+}
+
+extern "C" int affnet_extract_features(affnet_ctx* ctx, const affnet_nets* nets, const float* d_img, int do_ori, float* d_lafs_px,
+                                       float* d_resp, int32_t* d_ids, float* d_desc, int32_t* d_count, void* stream) {
+    int rc = affnet_detect_image(ctx, d_img, stream);
+    if (rc) return rc;
+    return affnet_describe_detected(ctx, nets, do_ori, d_lafs_px, d_resp, d_ids, d_desc, d_count, stream);
 }

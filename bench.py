@@ -66,7 +66,10 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=BATCH, help="images per step per rank")
-    ap.add_argument("--streams", type=int, default=int(os.environ.get("AFFNET_BENCH_STREAMS", "1")))
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("AFFNET_BENCH_STREAMS", "1")),
+                    help="independent full-path streams (each with its own context)")
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("AFFNET_BENCH_PIPELINE", "1")),
+                    help="1: detector of image i+1 on a second stream next to the CNN stages of image i")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -98,15 +101,21 @@ def main():
     seeds = [rank + world * j for j in range(args.batch)]
     imgs = [synthetic_image(H, W, s).to(dev) for s in seeds]
     S = max(1, args.streams)
+    PIPE = bool(args.pipeline) and S == 1
+    if PIPE:
+        S = 2                      # two contexts alternate; ONE CNN stream + ONE detector stream
     dets = [affnet_amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=NKP, border=5, num_Baum_iters=1, AffNet=A, OriNet=O).to(dev)
             for _ in range(S)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    det_stream = torch.cuda.Stream(device=dev) if PIPE else None
+    for d in dets:
+        d._context(imgs[0])            # create contexts / workspaces before anything is timed
 
     def step(profile=False):
         results = [None] * len(imgs)
         for i, x in enumerate(imgs):
-            with torch.cuda.stream(streams[i % S]):
-                results[i] = dets[i % S].enqueue(x, do_ori=True, desc=Hn)
+            with torch.cuda.stream(streams[0] if PIPE else streams[i % S]):
+                results[i] = dets[i % S].enqueue(x, do_ori=True, desc=Hn, det_stream=det_stream)
         for s in streams:
             s.synchronize()
         if world > 1:
@@ -160,7 +169,8 @@ def main():
             "config": {"workload": "BASELINE.json configs[2]: batch of %d synthetic 1024x768 grayscale images per GPU per step, "
                                    "2000 kp each, full path detect+AffNet+OriNet+HardNet; AffNet/OriNet shipped weights, "
                                    "HardNet seeded synthetic weights (HardNet++.pth is a missing blob)" % args.batch,
-                       "global_batch": args.batch * world, "keypoints_per_image": kp_per_img, "streams_per_gpu": S,
+                       "global_batch": args.batch * world, "keypoints_per_image": kp_per_img,
+                       "streams_per_gpu": "1 CNN stream + 1 detector stream (2 contexts alternate)" if PIPE else S,
                        "parallelism": "image-per-GPU x%d, all_gather of padded records" % world if world > 1 else "1 GPU"},
             "ms_per_image": tmax / (args.steps * args.batch) * 1e3,
             "stage_ms_per_image": dict(zip(names, [round(v, 4) for v in stage_ms])),

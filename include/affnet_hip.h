@@ -179,6 +179,11 @@ int affnet_cnn32_forward_pyr(affnet_ctx* ctx, int net_kind, const float* d_packe
 int affnet_cnn32_debug_layer(affnet_ctx* ctx, int net_kind, const float* d_packed, const float* d_patch,
                              int layer, float* d_out, void* stream);
 
+/* Tuning aid: when d_stamps != NULL every following CNN launch writes s_memtime stamps
+ * [patch][wave][16] (uint64) at its phase boundaries (0 start, 1 input ready, 2 conv0 done, then per
+ * conv layer k = 1..5: 2k+1 MFMA loop done, 2k+2 outputs stored).  NULL switches it off.  Process-global. */
+int affnet_cnn32_debug_timing(unsigned long long* d_stamps);
+
 /* ---- LAF stages ---------------------------------------------------------------------------- */
 
 /* base_A = A; new_LAF = [A * LAF_2x2 | centre]; keep rows with 1/6 < |l1/(l2+1e-8)| < 6 and
@@ -228,6 +233,16 @@ typedef struct affnet_nets {
 int affnet_extract_features(affnet_ctx* ctx, const affnet_nets* nets, const float* d_img, int do_ori,
                             float* d_lafs_px, float* d_resp, int32_t* d_ids, float* d_desc,
                             int32_t* d_count, void* stream);
+
+/* The two halves of affnet_extract_features, so that a caller can software-pipeline images over two
+ * streams (detector of image i+1 next to the CNN stages of image i; the caller orders the streams with
+ * events and must not start affnet_detect_image on a context before the previous
+ * affnet_describe_detected on it has finished):
+ *   affnet_detect_image      = pyramid + detector into the context's internal candidate list;
+ *   affnet_describe_detected = AffNet shape + filter, OriNet, denormalise, level select, HardNet. */
+int affnet_detect_image(affnet_ctx* ctx, const float* d_img, void* stream);
+int affnet_describe_detected(affnet_ctx* ctx, const affnet_nets* nets, int do_ori, float* d_lafs_px, float* d_resp,
+                             int32_t* d_ids, float* d_desc, int32_t* d_count, void* stream);
 
 /* Stage timing with HIP events recorded on the caller's stream around the stages of
  * affnet_extract_features (no host synchronisation while enabled; a ring of 256 calls).

@@ -1,0 +1,29 @@
+#!/usr/bin/env python
+"""Summarises rocprofv3 --pmc counter_collection.csv files: mean counter value per kernel.
+Usage: pmc_summary.py dir1 [dir2 ...]"""
+import collections
+import csv
+import sys
+
+
+def main(dirs):
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
+    dur = collections.defaultdict(list)
+    for d in dirs:
+        seen = set()
+        for r in csv.DictReader(open(d + "/run_counter_collection.csv")):
+            k = r["Kernel_Name"].split("(")[0][:48]
+            acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            key = (d, r["Dispatch_Id"])
+            if key not in seen:
+                seen.add(key)
+                dur[k].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    for k in sorted(acc, key=lambda k: -sum(dur[k])):
+        if "rocclr" in k or "at::" in k:
+            continue
+        print("%-48s calls/pass %4d  avg %9.1f us" % (k, len(dur[k]) // len(dirs), sum(dur[k]) / len(dur[k])))
+        print("    " + "  ".join("%s=%.4g" % (c, sum(v) / len(v)) for c, v in sorted(acc[k].items())))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:])
