@@ -50,16 +50,17 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
         self.max_keep = 16384      # row capacity in threshold mode (num = -1)
 
     # ------------------------------------------------------------------------------------------
-    def _context(self, x):
+    def _context(self, x, allow_batch=False):
         engine.require_cuda(x, "image")
-        if x.dim() != 4 or x.size(0) != 1 or x.size(1) != 1:
-            raise ValueError("expected a (1,1,H,W) image; the detector is batch-size-1 like the reference "
-                             "(HandCraftedModules.py:283-284)")
+        if x.dim() != 4 or x.size(1) != 1 or x.size(0) < 1 or (x.size(0) != 1 and not allow_batch):
+            raise ValueError("expected a (1,1,H,W) image; forward() is batch-size-1 like the reference "
+                             "(HandCraftedModules.py:283-284) - use enqueue()/run_batch() for (B,1,H,W) batches")
         pre = int(1.5 * self.num) if self.num_Baum_iters > 0 else self.num
-        key = (x.size(2), x.size(3), x.device, pre, self.num, float(self.th), self.mrSize, self.b, self.init_sigma, self.max_keep)
+        key = (x.size(0), x.size(2), x.size(3), x.device, pre, self.num, float(self.th), self.mrSize, self.b, self.init_sigma,
+               self.max_keep)
         if self._ctx is None or self._ctx_key != key:
             self._ctx = engine.Context(x.size(2), x.size(3), x.device, self.nlevels, self.init_sigma, self.b, self.mrSize,
-                                       float(self.th), self.num, pre, self.max_keep)
+                                       float(self.th), self.num, pre, self.max_keep, batch=x.size(0))
             self._ctx_key = key
         return self._ctx
 
@@ -74,21 +75,25 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
 
     def enqueue(self, x, do_ori=False, desc=None, det_stream=None):
         """Enqueues the whole fused path and returns capacity-sized device tensors plus the device row
-        count - no host synchronisation (throughput use).  With `det_stream` (a torch.cuda.Stream) the
+        counts - no host synchronisation (throughput use).  x may be a (B,1,H,W) batch of equally sized
+        images (BASELINE configs[2]; the reference loops over images in Python): every kernel launch then
+        covers the B images, results get a leading batch dimension and `count` is (B,).  With `det_stream` (a torch.cuda.Stream) the
         pyramid + detector run there and the CNN stages on the current stream, ordered by events, so that
         two extractor objects alternating over a stream of images overlap the latency-bound detector of
         image i+1 with the MFMA-bound CNN stages of image i."""
-        ctx = self._context(x)
+        ctx = self._context(x, allow_batch=True)
         dev = x.device
         if do_ori and self.OriNet is None:
             raise NotImplementedError("default OrientationDetector slot is SURVEY section 8f 'next'; pass OriNet=")
+        if not (self._native(self.AffNet) and self._native(self.OriNet)):
+            raise NotImplementedError("the fused path needs the native AffNetFast / OriNetFast slots (foreign slots: forward())")
         img = x.contiguous().float()
-        F = ctx.cap_final
-        lafs = torch.empty(F, 2, 3, dtype=torch.float32, device=dev)
-        resp = torch.empty(F, dtype=torch.float32, device=dev)
-        ids = torch.empty(F, 3, dtype=torch.int32, device=dev)
-        count = torch.zeros(1, dtype=torch.int32, device=dev)
-        dsc = torch.empty(F, 128, dtype=torch.float32, device=dev) if desc is not None else None
+        B, F = x.size(0), ctx.cap_final
+        lafs = torch.empty(B, F, 2, 3, dtype=torch.float32, device=dev)
+        resp = torch.empty(B, F, dtype=torch.float32, device=dev)
+        ids = torch.empty(B, F, 3, dtype=torch.int32, device=dev)
+        count = torch.zeros(B, dtype=torch.int32, device=dev)
+        dsc = torch.empty(B, F, 128, dtype=torch.float32, device=dev) if desc is not None else None
         nets = _lib.Nets()
         nets.d_affnet = self.AffNet.packed_weights(dev).data_ptr() if self.num_Baum_iters > 0 else None
         nets.d_orinet = self.OriNet.packed_weights(dev).data_ptr() if do_ori else None
@@ -112,7 +117,25 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
             check(rc, ctx.handle, "affnet_describe_detected")
             self._busy = torch.cuda.Event()
             self._busy.record(cur)
+        if B == 1:      # the reference's shapes
+            lafs, resp, ids, dsc = lafs[0], resp[0], ids[0], (None if dsc is None else dsc[0])
         return {"LAFs": lafs, "responses": resp, "ids": ids, "descriptors": dsc, "count": count, "_img": img}
+
+    def run_batch(self, x, do_ori=False, desc=None):
+        """(B,1,H,W) -> list of B per-image dicts (LAFs px (n_b,2,3), responses, ids, descriptors): one fused
+        enqueue for the whole batch, then ONE host read-back of the B row counts."""
+        r = self.enqueue(x, do_ori=do_ori, desc=desc)
+        ctx = self._ctx
+        ctx.read_counts()                   # surfaces capacity overflow
+        cnt = r["count"].cpu().tolist()
+        if x.size(0) == 1:
+            r = {k: (v.unsqueeze(0) if isinstance(v, torch.Tensor) and k not in ("count", "_img") else v) for k, v in r.items()}
+        out = []
+        for b, n in enumerate(cnt):
+            dsc = r["descriptors"]
+            out.append({"LAFs": r["LAFs"][b, :n], "responses": r["responses"][b, :n], "ids": r["ids"][b, :n],
+                        "descriptors": None if dsc is None else dsc[b, :n]})
+        return out
 
     def run(self, x, do_ori=False, desc=None):
         """Fused path.  Returns dict(LAFs px (N,2,3), responses (N,), ids (N,3), descriptors (N,128)|None).
@@ -199,6 +222,8 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
         if self._ctx is None or self.scale_pyr is None:
             raise RuntimeError("call forward() first: the pyramid of the last image is reused (stateful like the reference)")
         ctx = self._ctx
+        if ctx.batch != 1:
+            raise RuntimeError("extract_patches_from_pyr works on the pyramid of a single-image forward()")
         engine.require_cuda(dLAFs, "dLAFs")
         dev, st = dLAFs.device, engine.stream_of(dLAFs.device)
         lafs = dLAFs.contiguous().float()

@@ -27,7 +27,7 @@ class Config(C.Structure):
         ("level_blur", (C.c_float * (MAX_TAPS * MAX_TAPS)) * MAX_LEVELS),
         ("mr_size", C.c_float), ("threshold", C.c_float),
         ("num_features", C.c_int32), ("num_prefilter", C.c_int32),
-        ("max_raw_per_octave_div", C.c_int32), ("max_keep", C.c_int32),
+        ("max_raw_per_octave_div", C.c_int32), ("max_keep", C.c_int32), ("batch", C.c_int32),
     ]
 
 
@@ -45,6 +45,8 @@ SYMBOLS = {
     "affnet_workspace_bytes": (_SZ, [_P]),
     "affnet_bind_workspace": (_I, [_P, _P, _SZ]),
     "affnet_pyramid_level_offset": (C.c_int64, [_P, _I, _I]),
+    "affnet_pyramid_image_stride": (C.c_int64, [_P]),
+    "affnet_batch": (_I, [_P]),
     "affnet_capacity_prefilter": (_I, [_P]),
     "affnet_capacity_final": (_I, [_P]),
     "affnet_gauss_blur": (_I, [_P, _P, _P, _I, _I, C.POINTER(C.c_float), _I, _P]),

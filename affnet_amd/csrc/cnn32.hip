@@ -273,6 +273,7 @@ struct PyrSrc {            // pyramid sampling source (fused sampler)
     const float* lvl[AFFNET_MAX_OCTAVES][AFFNET_MAX_LEVELS];
     int h[AFFNET_MAX_OCTAVES], w[AFFNET_MAX_OCTAVES];
     int n_octaves, n_levels;
+    size_t img_stride;     // floats between the pyramids of consecutive images (batch)
     float base[32];        // affine_grid base coordinates for PS = 32
 };
 
@@ -330,25 +331,26 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
     float* patch = lds + TrunkLds<CB>::ACT;
     float* red = patch + TrunkLds<CB>::PATCH;
     float* w0s = red + 64;                              // [CB][12]: 9 taps, bias, 2 pad (16-byte rows)
-    const int pidx = blockIdx.x;
-    const int n = a.count ? min(*a.count, a.n_max) : a.n_max;
-    if (pidx >= n) return;
+    // grid = (n_max, batch): row blockIdx.x of image blockIdx.y; global row = image * n_max + row
+    const int n = a.count ? min(a.count[blockIdx.y], a.n_max) : a.n_max;
+    if ((int)blockIdx.x >= n) return;
+    const size_t pidx = (size_t)blockIdx.y * a.n_max + blockIdx.x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     CNN_STAMP(0);
 
     // ---- input: load or sample 1024 pixels (PPT per thread), standardise, store padded ----------------
     float v[PPT];
     if (a.patches) {
-        const float* src = a.patches + (size_t)pidx * 1024;
+        const float* src = a.patches + pidx * 1024;
 #pragma unroll
         for (int q = 0; q < PPT; ++q) v[q] = src[tid + q * NTHR];
     } else {
         int o = a.ids[3 * pidx], l = a.ids[3 * pidx + 1];
         o = o < 0 ? 0 : (o >= ps.n_octaves ? ps.n_octaves - 1 : o);
         l = l < 0 ? 0 : (l >= ps.n_levels ? ps.n_levels - 1 : l);
-        const float* img = ps.lvl[o][l];
+        const float* img = ps.lvl[o][l] + blockIdx.y * ps.img_stride;
         const int h = ps.h[o], w = ps.w[o];
-        const float* L = a.lafs + 6 * (size_t)pidx;
+        const float* L = a.lafs + 6 * pidx;
         const float m = (float)(h < w ? h : w);
         const float t00 = L[0] * m, t01 = L[1] * m, t02 = L[2] * (float)w;
         const float t10 = L[3] * m, t11 = L[4] * m, t12 = L[5] * (float)h;
@@ -463,7 +465,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         conv3x3_mfma<NW, 4 * CB, 4 * CB, 8, 1, T4M, T4N, PST8, WP8, 8>(act, a.packed + a.off.w[5], acc, wave, lane);
         CNN_STAMP(11);
         if (KIND == AFFNET_NET_HARDNET && a.dbg_layer < 0) {
-            store_tiles_global<4 * CB, T4M, T4N>(a.out + (size_t)pidx * HEAD_K, a.packed + a.off.b[5], acc, wave, lane);
+            store_tiles_global<4 * CB, T4M, T4N>(a.out + pidx * HEAD_K, a.packed + a.off.b[5], acc, wave, lane);
             return;
         }
         __syncthreads();
@@ -492,7 +494,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
             // rectifyAffineTransformationUpIsUp (LAF.py:285-291)
             const float det = sqrtf(fabsf(a00 * a11 - a10 * a01 + 1e-10f));
             const float b2a2 = sqrtf(a01 * a01 + a00 * a00);
-            float* o = a.out + 4 * (size_t)pidx;
+            float* o = a.out + 4 * pidx;
             o[0] = b2a2 / det; o[1] = 0.0f * det;
             o[2] = (a11 * a01 + a10 * a00) / (b2a2 * det); o[3] = det / b2a2;
         }
@@ -539,7 +541,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
             const float yv = t0 / 9.0f, xv = t1 / 9.0f;                       // AdaptiveAvgPool2d(1)
             const float ang = atan2f(yv + 1e-8f, xv + 1e-8f);                 // architectures.py:78
             const float sn = sinf(ang), cs = cosf(ang);
-            float* o = a.out + 4 * (size_t)pidx;
+            float* o = a.out + 4 * pidx;
             o[0] = cs; o[1] = sn; o[2] = -sn; o[3] = cs;                      // LAF.py:276-283
         }
     }
@@ -559,9 +561,11 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
 __global__ __launch_bounds__(256) void hardnet_head_kernel(const float* __restrict__ trunk, const float* __restrict__ Bw,
                                                            const int32_t* __restrict__ count, int n_max, float* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) float As[HEAD_MP * HEAD_AS];
-    const int n = count ? min(*count, n_max) : n_max;
+    const int n = count ? min(count[blockIdx.z], n_max) : n_max;      // blockIdx.z = image of the batch
     const int p0 = blockIdx.x * HEAD_MP;
     if (p0 >= n) return;
+    trunk += (size_t)blockIdx.z * n_max * HEAD_K;
+    const size_t rows_total = (size_t)gridDim.z * n_max;
     const int kbeg = blockIdx.y * (HEAD_K / HEAD_KSPLIT);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int m = lane & 15, kq = lane >> 4;
@@ -595,7 +599,7 @@ __global__ __launch_bounds__(256) void hardnet_head_kernel(const float* __restri
     }
     // acc[i][j][r]: patch p0 + 16 i + 4 (lane>>4) + r, channel 32 wave + 16 j + (lane & 15)
     const int g = lane >> 4;
-    float* dst = partial + (size_t)blockIdx.y * n_max * 128;
+    float* dst = partial + ((size_t)blockIdx.y * rows_total + (size_t)blockIdx.z * n_max) * 128;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -610,20 +614,21 @@ __global__ __launch_bounds__(256) void hardnet_head_kernel(const float* __restri
 // One wavefront per patch: sum the K-split partials in fixed order, + BN bias, L2 normalise (eps 1e-8).
 __global__ __launch_bounds__(256) void hardnet_finish_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
                                                              const int32_t* __restrict__ count, int n_max, float* __restrict__ out) {
-    const int n = count ? min(*count, n_max) : n_max;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= n) return;
+    const int n = count ? min(count[blockIdx.y], n_max) : n_max;      // blockIdx.y = image of the batch
+    const int lrow = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (lrow >= n) return;
+    const size_t rows_total = (size_t)gridDim.y * n_max, row = (size_t)blockIdx.y * n_max + lrow;
     float v0 = 0.f, v1 = 0.f;
 #pragma unroll
     for (int s = 0; s < HEAD_KSPLIT; ++s) {
-        const float* p = partial + ((size_t)s * n_max + row) * 128;
+        const float* p = partial + ((size_t)s * rows_total + row) * 128;
         v0 += p[lane]; v1 += p[64 + lane];
     }
     v0 += bias[lane]; v1 += bias[64 + lane];
     const float tot = wave_sum(v0 * v0 + v1 * v1);
     const float nrm = sqrtf(tot + 1e-8f);                                  // L2Norm (HardNet.py:15-18)
-    out[(size_t)row * 128 + lane] = v0 / nrm;
-    out[(size_t)row * 128 + 64 + lane] = v1 / nrm;
+    out[row * 128 + lane] = v0 / nrm;
+    out[row * 128 + 64 + lane] = v1 / nrm;
 }
 
 // ---- host entry points -------------------------------------------------------------------------------
@@ -631,6 +636,7 @@ void aff_fill_pyr_src(const affnet_ctx* ctx, PyrSrc* t) {
     memset(t, 0, sizeof(*t));
     if (ctx->ws) {
         t->n_octaves = ctx->cfg.n_octaves; t->n_levels = ctx->cfg.levels_per_octave;
+        t->img_stride = ctx->pyr_stride;
         for (int o = 0; o < t->n_octaves; ++o) {
             const OctaveGeom& g = ctx->oct[o];
             t->h[o] = g.h; t->w[o] = g.w;
@@ -657,7 +663,8 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
     a.dbg_layer = dbg_layer; a.dbg_out = dbg_out; a.dbg_time = g_dbg_time;
     PyrSrc ps;
     aff_fill_pyr_src(ctx, &ps);
-    const dim3 grid(n_max);
+    const int B = patches ? 1 : ctx->B;                  // patch tensors are single-"image"; pyramid sampling covers the batch
+    const dim3 grid(n_max, B);
     static const int hard_waves = []() { const char* e = getenv("AFFNET_HARDNET_WAVES"); return (e && atoi(e) == 16) ? 16 : 8; }();
     if (kind == AFFNET_NET_AFFNET) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_AFFNET, 8>), grid, dim3(512), 0, st, a, ps);
     else if (kind == AFFNET_NET_ORINET) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_ORINET, 8>), grid, dim3(512), 0, st, a, ps);
@@ -666,11 +673,11 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
     AFF_LAUNCH_CHECK(ctx);
     if (mark_head) aff_prof_mark(ctx, 7, st);
     if (kind == AFFNET_NET_HARDNET && dbg_layer < 0) {
-        float* partial = scratch + (size_t)n_max * HEAD_K;   // [HEAD_KSPLIT][n_max][128] behind the trunk output
-        hipLaunchKernelGGL(hardnet_head_kernel, dim3(aff_cdiv(n_max, HEAD_MP), HEAD_KSPLIT), dim3(256), 0, st, scratch, packed + L.head_w,
+        float* partial = scratch + (size_t)B * n_max * HEAD_K;   // [HEAD_KSPLIT][B * n_max][128] behind the trunk output
+        hipLaunchKernelGGL(hardnet_head_kernel, dim3(aff_cdiv(n_max, HEAD_MP), HEAD_KSPLIT, B), dim3(256), 0, st, scratch, packed + L.head_w,
                            count, n_max, partial);
         AFF_LAUNCH_CHECK(ctx);
-        hipLaunchKernelGGL(hardnet_finish_kernel, dim3(aff_cdiv(n_max, 4)), dim3(256), 0, st, partial, packed + L.head_b, count, n_max, out);
+        hipLaunchKernelGGL(hardnet_finish_kernel, dim3(aff_cdiv(n_max, 4), B), dim3(256), 0, st, partial, packed + L.head_b, count, n_max, out);
         AFF_LAUNCH_CHECK(ctx);
     }
     return AFFNET_OK;

@@ -46,6 +46,12 @@ struct OctaveGeom {
 struct affnet_ctx {
     int device = 0;
     affnet_config cfg;
+    // Image batch: every workspace area holds B images back to back ([image][...]); kernels take the image
+    // index from blockIdx.y / .z and offset their pointers by the per-image strides below.
+    int B = 1;
+    size_t pyr_stride = 0;             // floats between the pyramids of consecutive images
+    size_t map_stride = 0;             // bytes between octaveMaps
+    size_t raw_stride = 0;             // RawMax entries between raw lists
     std::string err;
     OctaveGeom oct[AFFNET_MAX_OCTAVES];
     // workspace layout (byte offsets from the workspace base)
@@ -63,6 +69,7 @@ struct affnet_ctx {
     float* sel_resp = nullptr; float* sel_syx = nullptr; int32_t* sel_ids = nullptr;
     // pipeline stage buffers
     float* st_det_resp = nullptr; float* st_det_lafs = nullptr; int32_t* st_det_ids = nullptr;
+    int32_t* st_det_count = nullptr;     // B contiguous detector row counts (kernels index count[image])
     float* st_A = nullptr; float* st_key = nullptr; int32_t* st_good = nullptr;
     float* st_R = nullptr; float* st_lafs_norm = nullptr; int32_t* st_lvl_ids = nullptr;
     float* st_hard_scratch = nullptr;

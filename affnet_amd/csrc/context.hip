@@ -38,6 +38,7 @@ extern "C" int affnet_host_base_grid(int ps, float* out) {  // exported for the 
 
 static int validate(affnet_ctx* ctx, const affnet_config* c) {
     if (c->height < 8 || c->width < 8) return aff_fail(ctx, AFFNET_ERR_INVALID, "image %dx%d too small", c->height, c->width);
+    if (c->batch > 4096) return aff_fail(ctx, AFFNET_ERR_INVALID, "batch=%d (max 4096)", c->batch);
     if (c->n_octaves < 1 || c->n_octaves > AFFNET_MAX_OCTAVES) return aff_fail(ctx, AFFNET_ERR_INVALID, "n_octaves=%d", c->n_octaves);
     if (c->levels_per_octave < 3 || c->levels_per_octave > AFFNET_MAX_LEVELS)
         return aff_fail(ctx, AFFNET_ERR_INVALID, "levels_per_octave=%d", c->levels_per_octave);
@@ -76,24 +77,30 @@ extern "C" int affnet_ctx_create(affnet_ctx** out, int device, const affnet_conf
         int cap = (int)((size_t)g.h * g.w / div); if (cap < 256) cap = 256;
         g.raw_off = (int64_t)raw; g.raw_cap = cap; raw += cap;
     }
+    ctx->B = c.batch > 0 ? c.batch : 1;
+    const size_t B = (size_t)ctx->B;
     ctx->pyr_floats = pyr; ctx->map_bytes = mapb; ctx->raw_total = raw; ctx->cand_cap = raw;
+    ctx->pyr_stride = aff_align(pyr * sizeof(float)) / sizeof(float);
+    ctx->map_stride = aff_align(mapb);
+    ctx->raw_stride = raw;
     const int keep = c.max_keep > 0 ? c.max_keep : 65536;
     ctx->cap_pre = c.num_prefilter > 0 ? c.num_prefilter : keep;
     ctx->cap_final = c.num_features > 0 ? c.num_features : ctx->cap_pre;
     if (ctx->cap_final > ctx->cap_pre) ctx->cap_final = ctx->cap_pre;
     size_t off = 0;
-    ctx->off_pyr = off; off += aff_align(pyr * sizeof(float));
-    ctx->off_map = off; off += aff_align(mapb);
-    ctx->off_raw = off; off += aff_align(raw * sizeof(RawMax));
-    ctx->off_cnt = off; off += aff_align(CNT_TOTAL * sizeof(int32_t));
-    ctx->off_cand = off; off += aff_align(ctx->cand_cap * 7 * sizeof(float));   // resp + syx[3] + ids[3]
-    ctx->off_sel = off; off += aff_align((size_t)ctx->cap_pre * 7 * sizeof(float));
+    ctx->off_pyr = off; off += B * ctx->pyr_stride * sizeof(float);
+    ctx->off_map = off; off += B * ctx->map_stride;
+    ctx->off_raw = off; off += aff_align(B * raw * sizeof(RawMax));
+    ctx->off_cnt = off; off += aff_align(B * CNT_TOTAL * sizeof(int32_t));
+    ctx->off_cand = off; off += aff_align(B * ctx->cand_cap * 7 * sizeof(float));   // resp + syx[3] + ids[3]
+    ctx->off_sel = off; off += aff_align(B * (size_t)ctx->cap_pre * 7 * sizeof(float));
     ctx->off_stage = off;
-    const size_t P = (size_t)ctx->cap_pre, F = (size_t)ctx->cap_final;
+    const size_t P = B * (size_t)ctx->cap_pre, F = B * (size_t)ctx->cap_final;
     off += aff_align(P * 10 * sizeof(float));          // det resp(1) + lafs(6) + ids(3)
     off += aff_align(P * 4 * sizeof(float));           // A
     off += aff_align(P * 2 * sizeof(float));           // key, good
     off += aff_align(P * sizeof(int32_t));             // rank / pos
+    off += aff_align(B * sizeof(int32_t));             // detector row counts
     off += aff_align(F * 6 * sizeof(float));           // shaped lafs (normalised)
     off += aff_align(F * 4 * sizeof(float));           // R
     off += aff_align(F * 9 * sizeof(float));           // lafs_norm(6) + lvl ids(3)
@@ -116,6 +123,9 @@ extern "C" int64_t affnet_pyramid_level_offset(const affnet_ctx* ctx, int octave
     return (int64_t)(ctx->off_pyr / sizeof(float)) + g.pyr_off + (int64_t)level * g.h * g.w;
 }
 
+extern "C" int64_t affnet_pyramid_image_stride(const affnet_ctx* ctx) { return ctx ? (int64_t)ctx->pyr_stride : 0; }
+extern "C" int affnet_batch(const affnet_ctx* ctx) { return ctx ? ctx->B : 0; }
+
 extern "C" int affnet_bind_workspace(affnet_ctx* ctx, void* d_workspace, size_t bytes) {
     if (!ctx) return AFFNET_ERR_INVALID;
     if (!d_workspace || bytes < ctx->ws_bytes)
@@ -127,10 +137,12 @@ extern "C" int affnet_bind_workspace(affnet_ctx* ctx, void* d_workspace, size_t 
     ctx->omap = (uint8_t*)(b + ctx->off_map);
     ctx->raw = (RawMax*)(b + ctx->off_raw);
     ctx->cnt = (int32_t*)(b + ctx->off_cnt);
+    const size_t B = (size_t)ctx->B;
     float* cand = (float*)(b + ctx->off_cand);
-    ctx->cand_resp = cand; ctx->cand_syx = cand + ctx->cand_cap; ctx->cand_ids = (int32_t*)(cand + 4 * ctx->cand_cap);
+    const size_t CC = B * ctx->cand_cap;
+    ctx->cand_resp = cand; ctx->cand_syx = cand + CC; ctx->cand_ids = (int32_t*)(cand + 4 * CC);
     float* sel = (float*)(b + ctx->off_sel);
-    const size_t P = (size_t)ctx->cap_pre, F = (size_t)ctx->cap_final;
+    const size_t P = B * (size_t)ctx->cap_pre, F = B * (size_t)ctx->cap_final;
     ctx->sel_resp = sel; ctx->sel_syx = sel + P; ctx->sel_ids = (int32_t*)(sel + 4 * P);
     char* s = b + ctx->off_stage;
     ctx->st_det_resp = (float*)s; ctx->st_det_lafs = (float*)s + P; ctx->st_det_ids = (int32_t*)((float*)s + 7 * P);
@@ -138,6 +150,7 @@ extern "C" int affnet_bind_workspace(affnet_ctx* ctx, void* d_workspace, size_t 
     ctx->st_A = (float*)s; s += aff_align(P * 4 * sizeof(float));
     ctx->st_key = (float*)s; ctx->st_good = (int32_t*)((float*)s + P); s += aff_align(P * 2 * sizeof(float));
     ctx->st_rank = (int32_t*)s; s += aff_align(P * sizeof(int32_t));
+    ctx->st_det_count = (int32_t*)s; s += aff_align(B * sizeof(int32_t));
     ctx->st_lafs_shaped = (float*)s; s += aff_align(F * 6 * sizeof(float));
     ctx->st_R = (float*)s; s += aff_align(F * 4 * sizeof(float));
     ctx->st_lafs_norm = (float*)s; ctx->st_lvl_ids = (int32_t*)((float*)s + 6 * F); s += aff_align(F * 9 * sizeof(float));
@@ -147,12 +160,18 @@ extern "C" int affnet_bind_workspace(affnet_ctx* ctx, void* d_workspace, size_t 
 
 extern "C" int affnet_read_counts(affnet_ctx* ctx, int32_t out[4], void* stream) {
     if (!ctx || !ctx->ws) return AFFNET_ERR_INVALID;
-    int32_t host[CNT_TOTAL];
-    AFF_HIP(ctx, hipMemcpyAsync(host, ctx->cnt, sizeof(host), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    std::vector<int32_t> all((size_t)ctx->B * CNT_TOTAL);
+    AFF_HIP(ctx, hipMemcpyAsync(all.data(), ctx->cnt, all.size() * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
     AFF_HIP(ctx, hipStreamSynchronize((hipStream_t)stream));
-    out[0] = host[CNT_DET]; out[1] = host[CNT_SHAPED]; out[2] = host[CNT_OVERFLOW];
+    int32_t host[CNT_TOTAL];
+    memset(host, 0, sizeof(host));
     int raw = 0;
-    for (int o = 0; o < ctx->cfg.n_octaves; ++o) raw += host[CNT_RAW0 + o];
+    for (int b = 0; b < ctx->B; ++b) {
+        const int32_t* h = all.data() + (size_t)b * CNT_TOTAL;
+        host[CNT_DET] += h[CNT_DET]; host[CNT_SHAPED] += h[CNT_SHAPED]; host[CNT_OVERFLOW] |= h[CNT_OVERFLOW];
+        for (int o = 0; o < ctx->cfg.n_octaves; ++o) raw += h[CNT_RAW0 + o];
+    }
+    out[0] = host[CNT_DET]; out[1] = host[CNT_SHAPED]; out[2] = host[CNT_OVERFLOW];
     out[3] = raw;
     if (host[CNT_OVERFLOW]) return aff_fail(ctx, AFFNET_ERR_CAPACITY, "a fixed-capacity detector list overflowed (flag %d)", host[CNT_OVERFLOW]);
     return AFFNET_OK;

@@ -47,6 +47,8 @@ struct HessParams {
     int raw_cap;
     int32_t* raw_cnt;
     int32_t* overflow;
+    // batch (blockIdx.z = image): per-image strides of the pyramid (floats), the raw lists (entries), the counters
+    size_t levels_stride, raw_stride;
 };
 
 __device__ __forceinline__ float hessian_at(const float* __restrict__ X, int ty, int tx, float s4, float th) {
@@ -75,6 +77,10 @@ __global__ __launch_bounds__(256) void hessian_nms_kernel(HessParams p) {
     const int h = p.h, w = p.w;
     const int x0 = blockIdx.x * HT_X, y0 = blockIdx.y * HT_Y;
     const size_t lvl_stride = (size_t)h * w;
+    p.levels += blockIdx.z * p.levels_stride;
+    p.raw += blockIdx.z * p.raw_stride;
+    p.raw_cnt += blockIdx.z * CNT_TOTAL;
+    p.overflow += blockIdx.z * CNT_TOTAL;
     for (int l = 0; l < 5; ++l) {
         const float* src = p.levels + l * lvl_stride;
         for (int i = threadIdx.x; i < HX_H * HX_W; i += 256) {
@@ -212,6 +218,7 @@ struct ResolveParams {
     int32_t* cnt;                 // counter block
     float* cand_resp; float* cand_syx; int32_t* cand_ids;
     int cand_cap;
+    size_t raw_stride, map_stride;   // batch (blockIdx.y = image)
 };
 
 __global__ __launch_bounds__(1024) void octave_resolve_kernel(ResolveParams p) {
@@ -221,8 +228,11 @@ __global__ __launch_bounds__(1024) void octave_resolve_kernel(ResolveParams p) {
     constexpr int RES_PER = 4;
     const int o = blockIdx.x;
     __shared__ int s_pos;
-    RawMax* raw = p.raw[o];
-    volatile uint8_t* omap = p.omap[o];
+    const size_t img = blockIdx.y;
+    RawMax* raw = p.raw[o] + img * p.raw_stride;
+    volatile uint8_t* omap = p.omap[o] + img * p.map_stride;
+    p.cnt += img * CNT_TOTAL;
+    p.cand_resp += img * p.cand_cap; p.cand_syx += img * p.cand_cap * 3; p.cand_ids += img * p.cand_cap * 3;
     int n = p.cnt[CNT_RAW0 + o];
     if (n > p.raw_cap[o]) n = p.raw_cap[o];
     const int lane = threadIdx.x & 63;
@@ -310,6 +320,8 @@ __global__ __launch_bounds__(1024) void select_prepare_kernel(const float* __res
                                                               int sel_cap) {
     __shared__ uint32_t hist[256];
     __shared__ uint32_t s_prefix, s_mask, s_need;
+    resp += (size_t)blockIdx.x * cand_cap;           // blockIdx.x = image
+    cnt += blockIdx.x * CNT_TOTAL;
     int n = cnt[CNT_CAND];
     if (n > cand_cap) n = cand_cap;
     if (threadIdx.x == 0) {
@@ -356,6 +368,12 @@ __global__ __launch_bounds__(1024) void select_prepare_kernel(const float* __res
 __global__ __launch_bounds__(256) void select_compact_kernel(const float* __restrict__ resp, const float* __restrict__ syx,
                                                              const int32_t* __restrict__ ids, int32_t* cnt, int cand_cap,
                                                              float* sel_resp, float* sel_syx, int32_t* sel_ids, int sel_cap) {
+    {
+        const size_t img = blockIdx.y;
+        resp += img * cand_cap; syx += img * cand_cap * 3; ids += img * cand_cap * 3;
+        cnt += img * CNT_TOTAL;
+        sel_resp += img * sel_cap; sel_syx += img * sel_cap * 3; sel_ids += img * sel_cap * 3;
+    }
     int n = cnt[CNT_CAND];
     if (n > cand_cap) n = cand_cap;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -386,6 +404,10 @@ __global__ __launch_bounds__(256) void select_rank_kernel(const float* __restric
                                                           const int32_t* __restrict__ cnt, int sel_cap, int32_t* __restrict__ rank) {
     __shared__ float t_resp[256];
     __shared__ unsigned long long t_ord[256];
+    {
+        const size_t img = blockIdx.z;
+        sel_resp += img * sel_cap; sel_ids += img * sel_cap * 3; cnt += img * CNT_TOTAL; rank += img * sel_cap;
+    }
     int n = cnt[CNT_SEL];
     if (n > sel_cap) n = sel_cap;
     const int mode = cnt[CNT_SEL_MODE];
@@ -414,6 +436,12 @@ __global__ __launch_bounds__(256) void select_emit_kernel(const float* __restric
                                                           const int32_t* __restrict__ sel_ids, int32_t* cnt, int sel_cap,
                                                           const int32_t* __restrict__ rank, float mr, float* out_resp,
                                                           float* out_lafs, int32_t* out_ids, int32_t* out_count) {
+    {
+        const size_t img = blockIdx.y;
+        sel_resp += img * sel_cap; sel_syx += img * sel_cap * 3; sel_ids += img * sel_cap * 3; cnt += img * CNT_TOTAL;
+        rank += img * sel_cap; out_resp += img * sel_cap; out_lafs += img * sel_cap * 6; out_ids += img * sel_cap * 3;
+        if (out_count) out_count += img;
+    }
     int n = cnt[CNT_SEL];
     if (n > sel_cap) n = sel_cap;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -434,9 +462,10 @@ extern "C" int affnet_detect(affnet_ctx* ctx, float* d_resp, float* d_lafs, int3
     hipStream_t st = (hipStream_t)stream;
     const affnet_config& c = ctx->cfg;
     if (c.levels_per_octave != 5) return aff_fail(ctx, AFFNET_ERR_INVALID, "detect: only nLevels=3 (5 levels per octave) is implemented");
-    AFF_HIP(ctx, hipMemsetAsync(ctx->cnt, 0, CNT_TOTAL * sizeof(int32_t), st));
-    AFF_HIP(ctx, hipMemsetAsync(ctx->omap, 0, ctx->map_bytes, st));
-    const size_t P = (size_t)ctx->cap_pre;
+    const int B = ctx->B;
+    AFF_HIP(ctx, hipMemsetAsync(ctx->cnt, 0, (size_t)B * CNT_TOTAL * sizeof(int32_t), st));
+    AFF_HIP(ctx, hipMemsetAsync(ctx->omap, 0, (size_t)B * ctx->map_stride, st));
+    const size_t P = (size_t)B * ctx->cap_pre;
     AFF_HIP(ctx, hipMemsetAsync(d_resp, 0, P * sizeof(float), st));
     AFF_HIP(ctx, hipMemsetAsync(d_lafs, 0, P * 6 * sizeof(float), st));
     AFF_HIP(ctx, hipMemsetAsync(d_ids, 0, P * 3 * sizeof(int32_t), st));
@@ -453,24 +482,26 @@ extern "C" int affnet_detect(affnet_ctx* ctx, float* d_resp, float* d_lafs, int3
         hp.border = (int)c.mr_size;
         hp.raw = ctx->raw + g.raw_off; hp.raw_cap = g.raw_cap;
         hp.raw_cnt = ctx->cnt + CNT_RAW0 + o; hp.overflow = ctx->cnt + CNT_OVERFLOW;
-        hipLaunchKernelGGL(hessian_nms_kernel, dim3(aff_cdiv(g.w, HT_X), aff_cdiv(g.h, HT_Y)), dim3(256), 0, st, hp);
+        hp.levels_stride = ctx->pyr_stride; hp.raw_stride = ctx->raw_stride;
+        hipLaunchKernelGGL(hessian_nms_kernel, dim3(aff_cdiv(g.w, HT_X), aff_cdiv(g.h, HT_Y), B), dim3(256), 0, st, hp);
         AFF_LAUNCH_CHECK(ctx);
         rp.raw[o] = hp.raw; rp.omap[o] = ctx->omap + g.map_off; rp.raw_cap[o] = g.raw_cap;
     }
     rp.n_detect_levels = 3; rp.cnt = ctx->cnt;
     rp.cand_resp = ctx->cand_resp; rp.cand_syx = ctx->cand_syx; rp.cand_ids = ctx->cand_ids; rp.cand_cap = (int)ctx->cand_cap;
-    hipLaunchKernelGGL(octave_resolve_kernel, dim3(c.n_octaves), dim3(1024), 0, st, rp);
+    rp.raw_stride = ctx->raw_stride; rp.map_stride = ctx->map_stride;
+    hipLaunchKernelGGL(octave_resolve_kernel, dim3(c.n_octaves, B), dim3(1024), 0, st, rp);
     AFF_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(select_prepare_kernel, dim3(1), dim3(1024), 0, st, ctx->cand_resp, ctx->cnt, (int)ctx->cand_cap, c.num_prefilter,
+    hipLaunchKernelGGL(select_prepare_kernel, dim3(B), dim3(1024), 0, st, ctx->cand_resp, ctx->cnt, (int)ctx->cand_cap, c.num_prefilter,
                        ctx->cap_pre);
     AFF_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(select_compact_kernel, dim3(aff_cdiv((int)ctx->cand_cap, 256)), dim3(256), 0, st, ctx->cand_resp, ctx->cand_syx,
+    hipLaunchKernelGGL(select_compact_kernel, dim3(aff_cdiv((int)ctx->cand_cap, 256), B), dim3(256), 0, st, ctx->cand_resp, ctx->cand_syx,
                        ctx->cand_ids, ctx->cnt, (int)ctx->cand_cap, ctx->sel_resp, ctx->sel_syx, ctx->sel_ids, ctx->cap_pre);
     AFF_LAUNCH_CHECK(ctx);
     const int nb = aff_cdiv(ctx->cap_pre, 256);
-    hipLaunchKernelGGL(select_rank_kernel, dim3(nb, nb), dim3(256), 0, st, ctx->sel_resp, ctx->sel_ids, ctx->cnt, ctx->cap_pre, ctx->st_rank);
+    hipLaunchKernelGGL(select_rank_kernel, dim3(nb, nb, B), dim3(256), 0, st, ctx->sel_resp, ctx->sel_ids, ctx->cnt, ctx->cap_pre, ctx->st_rank);
     AFF_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(select_emit_kernel, dim3(nb), dim3(256), 0, st, ctx->sel_resp, ctx->sel_syx, ctx->sel_ids, ctx->cnt, ctx->cap_pre,
+    hipLaunchKernelGGL(select_emit_kernel, dim3(nb, B), dim3(256), 0, st, ctx->sel_resp, ctx->sel_syx, ctx->sel_ids, ctx->cnt, ctx->cap_pre,
                        ctx->st_rank, c.mr_size, d_resp, d_lafs, d_ids, d_count);
     AFF_LAUNCH_CHECK(ctx);
     return AFFNET_OK;

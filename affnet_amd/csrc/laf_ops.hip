@@ -16,11 +16,13 @@ struct PyrTable {   // level pointers of the pyramid in the workspace
     const float* lvl[AFFNET_MAX_OCTAVES][AFFNET_MAX_LEVELS];
     int h[AFFNET_MAX_OCTAVES], w[AFFNET_MAX_OCTAVES];
     int n_octaves, n_levels;
+    size_t img_stride;   // floats between the pyramids of consecutive images (batch)
 };
 
 void aff_fill_pyr_table(const affnet_ctx* ctx, PyrTable* t) {
     memset(t, 0, sizeof(*t));
     t->n_octaves = ctx->cfg.n_octaves; t->n_levels = ctx->cfg.levels_per_octave;
+    t->img_stride = ctx->pyr_stride;
     for (int o = 0; o < t->n_octaves; ++o) {
         const OctaveGeom& g = ctx->oct[o];
         t->h[o] = g.h; t->w[o] = g.w;
@@ -36,13 +38,16 @@ __global__ __launch_bounds__(256) void grid_sample_kernel(const float* __restric
                                                           const int32_t* __restrict__ d_count, int n_max, int ps, BaseGrid bg,
                                                           float* __restrict__ out) {
     const int p = blockIdx.x;
-    const int n = d_count ? min(*d_count, n_max) : n_max;
+    const size_t bi = blockIdx.y;                     // image of the batch; rows of image bi start at bi * n_max
+    const int n = d_count ? min(d_count[bi], n_max) : n_max;
     if (p >= n) return;
+    lafs += bi * n_max * 6; out += bi * n_max * (size_t)(ps * ps);
     if (use_pyr) {
+        ids += bi * n_max * 3;
         int o = ids[3 * p], l = ids[3 * p + 1];
         o = o < 0 ? 0 : (o >= pt.n_octaves ? pt.n_octaves - 1 : o);
         l = l < 0 ? 0 : (l >= pt.n_levels ? pt.n_levels - 1 : l);
-        img = pt.lvl[o][l]; h = pt.h[o]; w = pt.w[o];
+        img = pt.lvl[o][l] + bi * pt.img_stride; h = pt.h[o]; w = pt.w[o];
     }
     const float* L = lafs + 6 * (size_t)p;
     const float m = (float)(h < w ? h : w);
@@ -64,7 +69,8 @@ static int sample_common(affnet_ctx* ctx, const float* img, int h, int w, int us
     aff_base_grid(ps, bg.v);
     PyrTable pt;
     if (use_pyr) aff_fill_pyr_table(ctx, &pt); else memset(&pt, 0, sizeof(pt));
-    hipLaunchKernelGGL(grid_sample_kernel, dim3(n), dim3(256), 0, st, img, h, w, pt, use_pyr, lafs, ids, cnt, n, ps, bg, out);
+    hipLaunchKernelGGL(grid_sample_kernel, dim3(n, use_pyr ? ctx->B : 1), dim3(256), 0, st, img, h, w, pt, use_pyr, lafs, ids, cnt, n, ps, bg,
+                       out);
     AFF_LAUNCH_CHECK(ctx);
     return AFFNET_OK;
 }
@@ -86,6 +92,10 @@ __global__ __launch_bounds__(256) void shape_filter_kernel(const float* __restri
                                                            const float* __restrict__ A, const int32_t* __restrict__ d_count,
                                                            int n_max, float* __restrict__ key, int32_t* __restrict__ good) {
     const int i = blockIdx.x * 256 + threadIdx.x;
+    {
+        const size_t bi = blockIdx.y;
+        resp += bi * n_max; lafs += bi * n_max * 6; A += bi * n_max * 4; d_count += bi; key += bi * n_max; good += bi * n_max;
+    }
     const int n = min(*d_count, n_max);
     if (i >= n_max) return;
     if (i >= n) { key[i] = 0.f; good[i] = 0; return; }
@@ -124,6 +134,7 @@ __global__ __launch_bounds__(256) void shape_filter_kernel(const float* __restri
 //   otherwise      -> stable compaction of the good rows            - nonzero branch (:154-156)
 __global__ __launch_bounds__(256) void shape_count_kernel(const int32_t* __restrict__ good, const int32_t* __restrict__ d_count, int n_max,
                                                           int32_t* cnt) {
+    good += (size_t)blockIdx.y * n_max; d_count += blockIdx.y; cnt += blockIdx.y * CNT_TOTAL;
     const int n = min(*d_count, n_max);
     const int i = blockIdx.x * 256 + threadIdx.x;
     const int g = (i < n) ? good[i] : 0;
@@ -136,6 +147,10 @@ __global__ __launch_bounds__(256) void shape_rank_kernel(const float* __restrict
                                                          const int32_t* __restrict__ cnt, int32_t* __restrict__ pos) {
     __shared__ float t_key[256];
     __shared__ int t_good[256];
+    {
+        const size_t bi = blockIdx.z;
+        key += bi * n_max; good += bi * n_max; d_count += bi; cnt += bi * CNT_TOTAL; pos += bi * n_max;
+    }
     const int n = min(*d_count, n_max);
     const int i = blockIdx.x * 256 + threadIdx.x, base = blockIdx.y * 256;
     if (blockIdx.x * 256 >= n || base >= n) return;
@@ -161,6 +176,12 @@ __global__ __launch_bounds__(256) void shape_emit_kernel(const float* __restrict
                                                          const int32_t* __restrict__ pos, const int32_t* __restrict__ d_count, int n_max,
                                                          int N, int out_cap, float* out_resp, float* out_lafs, int32_t* out_ids,
                                                          int32_t* out_count, int32_t* cnt) {
+    {
+        const size_t bi = blockIdx.y;
+        resp += bi * n_max; lafs += bi * n_max * 6; ids += bi * n_max * 3; A += bi * n_max * 4; key += bi * n_max;
+        good += bi * n_max; pos += bi * n_max; d_count += bi; cnt += bi * CNT_TOTAL;
+        out_resp += bi * out_cap; out_lafs += bi * out_cap * 6; out_ids += bi * out_cap * 3; out_count += bi;
+    }
     const int n = min(*d_count, n_max);
     const int surv = cnt[CNT_SURVIVED];
     const bool topk = (N > 0) && (surv > N);
@@ -189,22 +210,22 @@ extern "C" int affnet_shape_filter_select(affnet_ctx* ctx, const float* d_resp_i
         !d_count_out)
         return aff_fail(ctx, AFFNET_ERR_INVALID, "shape_filter_select: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    const int P = ctx->cap_pre, F = ctx->cap_final;
-    AFF_HIP(ctx, hipMemsetAsync(d_resp_out, 0, (size_t)F * sizeof(float), st));
-    AFF_HIP(ctx, hipMemsetAsync(d_lafs_out, 0, (size_t)F * 6 * sizeof(float), st));
-    AFF_HIP(ctx, hipMemsetAsync(d_ids_out, 0, (size_t)F * 3 * sizeof(int32_t), st));
-    hipLaunchKernelGGL(shape_filter_kernel, dim3(aff_cdiv(P, 256)), dim3(256), 0, st, d_resp_in, d_lafs_in, d_A, d_count_in, P, ctx->st_key,
+    const int P = ctx->cap_pre, F = ctx->cap_final, B = ctx->B;
+    AFF_HIP(ctx, hipMemsetAsync(d_resp_out, 0, (size_t)B * F * sizeof(float), st));
+    AFF_HIP(ctx, hipMemsetAsync(d_lafs_out, 0, (size_t)B * F * 6 * sizeof(float), st));
+    AFF_HIP(ctx, hipMemsetAsync(d_ids_out, 0, (size_t)B * F * 3 * sizeof(int32_t), st));
+    hipLaunchKernelGGL(shape_filter_kernel, dim3(aff_cdiv(P, 256), B), dim3(256), 0, st, d_resp_in, d_lafs_in, d_A, d_count_in, P, ctx->st_key,
                        ctx->st_good);
     AFF_LAUNCH_CHECK(ctx);
-    AFF_HIP(ctx, hipMemsetAsync(ctx->st_rank, 0, (size_t)P * sizeof(int32_t), st));
-    AFF_HIP(ctx, hipMemsetAsync(ctx->cnt + CNT_SURVIVED, 0, sizeof(int32_t), st));
+    AFF_HIP(ctx, hipMemsetAsync(ctx->st_rank, 0, (size_t)B * P * sizeof(int32_t), st));
+    AFF_HIP(ctx, hipMemset2DAsync(ctx->cnt + CNT_SURVIVED, CNT_TOTAL * sizeof(int32_t), 0, sizeof(int32_t), (size_t)B, st));
     const int nb = aff_cdiv(P, 256);
-    hipLaunchKernelGGL(shape_count_kernel, dim3(nb), dim3(256), 0, st, ctx->st_good, d_count_in, P, ctx->cnt);
+    hipLaunchKernelGGL(shape_count_kernel, dim3(nb, B), dim3(256), 0, st, ctx->st_good, d_count_in, P, ctx->cnt);
     AFF_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(shape_rank_kernel, dim3(nb, nb), dim3(256), 0, st, ctx->st_key, ctx->st_good, d_count_in, P, ctx->cfg.num_features,
+    hipLaunchKernelGGL(shape_rank_kernel, dim3(nb, nb, B), dim3(256), 0, st, ctx->st_key, ctx->st_good, d_count_in, P, ctx->cfg.num_features,
                        ctx->cnt, ctx->st_rank);
     AFF_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(shape_emit_kernel, dim3(nb), dim3(256), 0, st, d_resp_in, d_lafs_in, d_ids_in, d_A, ctx->st_key, ctx->st_good,
+    hipLaunchKernelGGL(shape_emit_kernel, dim3(nb, B), dim3(256), 0, st, d_resp_in, d_lafs_in, d_ids_in, d_A, ctx->st_key, ctx->st_good,
                        ctx->st_rank, d_count_in, P, ctx->cfg.num_features, F, d_resp_out, d_lafs_out, d_ids_out, d_count_out, ctx->cnt);
     AFF_LAUNCH_CHECK(ctx);
     return AFFNET_OK;
@@ -214,10 +235,11 @@ extern "C" int affnet_shape_filter_select(affnet_ctx* ctx, const float* d_resp_i
 __global__ void apply_rotation_kernel(float* __restrict__ lafs, const float* __restrict__ R, const int32_t* __restrict__ d_count,
                                       int n_max) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = d_count ? min(*d_count, n_max) : n_max;
+    const size_t bi = blockIdx.y;
+    const int n = d_count ? min(d_count[bi], n_max) : n_max;
     if (i >= n) return;
-    float* L = lafs + 6 * (size_t)i;
-    const float* r = R + 4 * (size_t)i;
+    float* L = lafs + 6 * (bi * n_max + i);
+    const float* r = R + 4 * (bi * n_max + i);
     const float l00 = L[0], l01 = L[1], l10 = L[3], l11 = L[4];
     L[0] = fmaf(l01, r[2], l00 * r[0]); L[1] = fmaf(l01, r[3], l00 * r[1]);
     L[3] = fmaf(l11, r[2], l10 * r[0]); L[4] = fmaf(l11, r[3], l10 * r[1]);
@@ -226,7 +248,7 @@ __global__ void apply_rotation_kernel(float* __restrict__ lafs, const float* __r
 extern "C" int affnet_apply_rotation(affnet_ctx* ctx, float* d_lafs, const float* d_R, const int32_t* d_count, int n_max, void* stream) {
     if (!ctx || !d_lafs || !d_R || n_max < 0) return aff_fail(ctx, AFFNET_ERR_INVALID, "apply_rotation: bad argument");
     if (n_max == 0) return AFFNET_OK;
-    hipLaunchKernelGGL(apply_rotation_kernel, dim3(aff_cdiv(n_max, 256)), dim3(256), 0, (hipStream_t)stream, d_lafs, d_R, d_count, n_max);
+    hipLaunchKernelGGL(apply_rotation_kernel, dim3(aff_cdiv(n_max, 256), ctx->B), dim3(256), 0, (hipStream_t)stream, d_lafs, d_R, d_count, n_max);
     AFF_LAUNCH_CHECK(ctx);
     return AFFNET_OK;
 }
@@ -234,10 +256,11 @@ extern "C" int affnet_apply_rotation(affnet_ctx* ctx, float* d_lafs, const float
 __global__ void scale_lafs_kernel(const float* __restrict__ in, float* __restrict__ out, const int32_t* __restrict__ d_count, int n_max,
                                   float c_a, float c_x, float c_y) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = d_count ? min(*d_count, n_max) : n_max;
+    const size_t bi = blockIdx.y;
+    const int n = d_count ? min(d_count[bi], n_max) : n_max;
     if (i >= n_max) return;
-    const float* L = in + 6 * (size_t)i;
-    float* O = out + 6 * (size_t)i;
+    const float* L = in + 6 * (bi * n_max + i);
+    float* O = out + 6 * (bi * n_max + i);
     if (i >= n) { O[0] = O[1] = O[2] = O[3] = O[4] = O[5] = 0.f; return; }
     O[0] = c_a * L[0]; O[1] = c_a * L[1]; O[2] = c_x * L[2];
     O[3] = c_a * L[3]; O[4] = c_a * L[4]; O[5] = c_y * L[5];
@@ -252,7 +275,7 @@ extern "C" int affnet_scale_lafs(affnet_ctx* ctx, const float* d_in, float* d_ou
     const float ca = inverse ? 1.0f / m : m;
     const float cx = inverse ? (float)(1.0 / (double)fw) : fw;
     const float cy = inverse ? (float)(1.0 / (double)fh) : fh;
-    hipLaunchKernelGGL(scale_lafs_kernel, dim3(aff_cdiv(n_max, 256)), dim3(256), 0, (hipStream_t)stream, d_in, d_out, d_count, n_max, ca, cx,
+    hipLaunchKernelGGL(scale_lafs_kernel, dim3(aff_cdiv(n_max, 256), ctx->B), dim3(256), 0, (hipStream_t)stream, d_in, d_out, d_count, n_max, ca, cx,
                        cy);
     AFF_LAUNCH_CHECK(ctx);
     return AFFNET_OK;
@@ -263,8 +286,10 @@ struct LevelTable { double sig[AFFNET_MAX_OCTAVES * AFFNET_MAX_LEVELS]; int n_oc
 __global__ void level_select_kernel(const float* __restrict__ lafs_px, const int32_t* __restrict__ d_count, int n_max, float ps,
                                     LevelTable lt, float ca, float cx, float cy, int32_t* __restrict__ ids, float* __restrict__ lafs_norm) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n = d_count ? min(*d_count, n_max) : n_max;
+    const size_t bi = blockIdx.y;
+    const int n = d_count ? min(d_count[bi], n_max) : n_max;
     if (i >= n) return;
+    lafs_px += bi * n_max * 6; ids += bi * n_max * 3; lafs_norm += bi * n_max * 6;
     const float* L = lafs_px + 6 * (size_t)i;
     // get_LAFs_scales (LAF.py:450-451) in fp32, then / PS in fp32, then float64 |a - b| argmin (cdist on 1-D points)
     const float p1 = L[0] * L[4], p2 = L[1] * L[3];
@@ -294,7 +319,7 @@ extern "C" int affnet_level_select(affnet_ctx* ctx, const float* d_lafs_px, cons
     for (int o = 0; o < lt.n_oct; ++o)
         for (int l = 0; l < lt.n_lvl; ++l) lt.sig[o * lt.n_lvl + l] = c.level_sigma_px[o][l];
     const float fw = (float)c.width, fh = (float)c.height, m = fw < fh ? fw : fh;
-    hipLaunchKernelGGL(level_select_kernel, dim3(aff_cdiv(n_max, 256)), dim3(256), 0, (hipStream_t)stream, d_lafs_px, d_count, n_max,
+    hipLaunchKernelGGL(level_select_kernel, dim3(aff_cdiv(n_max, 256), ctx->B), dim3(256), 0, (hipStream_t)stream, d_lafs_px, d_count, n_max,
                        (float)ps, lt, 1.0f / m, (float)(1.0 / (double)fw), (float)(1.0 / (double)fh), d_ids, d_lafs_norm);
     AFF_LAUNCH_CHECK(ctx);
     return AFFNET_OK;

@@ -53,7 +53,7 @@ extern "C" int affnet_detect_image(affnet_ctx* ctx, const float* d_img, void* st
     int rc = affnet_pyramid_build(ctx, d_img, stream);
     if (rc) return rc;
     aff_prof_mark(ctx, 1, st);
-    rc = affnet_detect(ctx, ctx->st_det_resp, ctx->st_det_lafs, ctx->st_det_ids, nullptr, stream);
+    rc = affnet_detect(ctx, ctx->st_det_resp, ctx->st_det_lafs, ctx->st_det_ids, ctx->st_det_count, stream);
     if (rc) return rc;
     aff_prof_mark(ctx, 9, st);
     return AFFNET_OK;
@@ -67,8 +67,9 @@ extern "C" int affnet_describe_detected(affnet_ctx* ctx, const affnet_nets* nets
     if (d_desc && !nets->d_hardnet) return aff_fail(ctx, AFFNET_ERR_INVALID, "describe_detected: descriptors need HardNet weights");
     hipStream_t st = (hipStream_t)stream;
     const int P = ctx->cap_pre, F = ctx->cap_final;
+    const size_t B = (size_t)ctx->B;
     int rc;
-    int32_t* det_count = ctx->cnt + CNT_DET;
+    int32_t* det_count = ctx->st_det_count;
     aff_prof_mark(ctx, 2, st);
     if (nets->d_affnet) {
         rc = affnet_cnn32_forward_pyr(ctx, AFFNET_NET_AFFNET, nets->d_affnet, ctx->st_det_lafs, ctx->st_det_ids, det_count, P, ctx->st_A,
@@ -82,11 +83,12 @@ extern "C" int affnet_describe_detected(affnet_ctx* ctx, const affnet_nets* nets
         aff_prof_mark(ctx, 3, st);
         // num_Baum_iters == 0: detections pass through unchanged (C == N)
         if (F != P) return aff_fail(ctx, AFFNET_ERR_INVALID, "describe_detected: without AffNet num_prefilter must equal num_features");
-        AFF_HIP(ctx, hipMemcpyAsync(d_resp, ctx->st_det_resp, (size_t)F * sizeof(float), hipMemcpyDeviceToDevice, st));
-        AFF_HIP(ctx, hipMemcpyAsync(ctx->st_lafs_shaped, ctx->st_det_lafs, (size_t)F * 6 * sizeof(float), hipMemcpyDeviceToDevice, st));
-        AFF_HIP(ctx, hipMemcpyAsync(d_ids, ctx->st_det_ids, (size_t)F * 3 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-        AFF_HIP(ctx, hipMemcpyAsync(d_count, det_count, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-        AFF_HIP(ctx, hipMemcpyAsync(ctx->cnt + CNT_SHAPED, det_count, sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        AFF_HIP(ctx, hipMemcpyAsync(d_resp, ctx->st_det_resp, B * F * sizeof(float), hipMemcpyDeviceToDevice, st));
+        AFF_HIP(ctx, hipMemcpyAsync(ctx->st_lafs_shaped, ctx->st_det_lafs, B * F * 6 * sizeof(float), hipMemcpyDeviceToDevice, st));
+        AFF_HIP(ctx, hipMemcpyAsync(d_ids, ctx->st_det_ids, B * F * 3 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        AFF_HIP(ctx, hipMemcpyAsync(d_count, det_count, B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+        AFF_HIP(ctx, hipMemcpy2DAsync(ctx->cnt + CNT_SHAPED, CNT_TOTAL * sizeof(int32_t), det_count, sizeof(int32_t), sizeof(int32_t), B,
+                                      hipMemcpyDeviceToDevice, st));
     }
     aff_prof_mark(ctx, 4, st);
     if (do_ori) {
@@ -102,7 +104,7 @@ extern "C" int affnet_describe_detected(affnet_ctx* ctx, const affnet_nets* nets
     if (d_desc) {
         rc = affnet_level_select(ctx, d_lafs_px, d_count, F, 32, ctx->st_lvl_ids, ctx->st_lafs_norm, stream);
         if (rc) return rc;
-        AFF_HIP(ctx, hipMemsetAsync(d_desc, 0, (size_t)F * 128 * sizeof(float), st));
+        AFF_HIP(ctx, hipMemsetAsync(d_desc, 0, B * F * 128 * sizeof(float), st));
         aff_prof_mark(ctx, 6, st);
         rc = aff_hardnet_forward_pyr_marked(ctx, nets->d_hardnet, ctx->st_lafs_norm, ctx->st_lvl_ids, d_count, F, d_desc,
                                             ctx->st_hard_scratch, st);

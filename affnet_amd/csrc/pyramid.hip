@@ -23,13 +23,17 @@ struct Taps { float w[K * K]; };
 
 template <int K>
 __global__ __launch_bounds__(256) void blur2d_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                     float* __restrict__ dec_out, int h, int w, int w2, Taps<K> taps) {
+                                                     float* __restrict__ dec_out, int h, int w, int w2, size_t in_stride,
+                                                     size_t out_stride, Taps<K> taps) {
     constexpr int R = K / 2;
     constexpr int LW = BT_X + 2 * R;               // tile width incl. halo
     constexpr int LS = (LW + 3) & ~3;              // row stride, multiple of 4 floats (16-B aligned rows)
     constexpr int LH = BT_Y + 2 * R;
     __shared__ __attribute__((aligned(16))) float tile[LH * LS];
     const int x0 = blockIdx.x * BT_X, y0 = blockIdx.y * BT_Y;
+    in += blockIdx.z * in_stride;                   // blockIdx.z = image of the batch
+    out += blockIdx.z * out_stride;
+    if (dec_out) dec_out += blockIdx.z * out_stride;
     for (int i = threadIdx.x; i < LH * LW; i += 256) {
         const int ty = i / LW, tx = i - ty * LW;
         int gy = y0 + ty - R, gx = x0 + tx - R;
@@ -74,26 +78,28 @@ __global__ __launch_bounds__(256) void blur2d_kernel(const float* __restrict__ i
 }
 
 template <int K>
-static void launch_blur(const float* in, float* out, float* dec, int h, int w, const float* taps, hipStream_t st) {
+static void launch_blur(const float* in, float* out, float* dec, int h, int w, int batch, size_t in_stride, size_t out_stride,
+                        const float* taps, hipStream_t st) {
     Taps<K> t;
     memcpy(t.w, taps, sizeof(float) * K * K);
-    dim3 grid(aff_cdiv(w, BT_X), aff_cdiv(h, BT_Y));
-    hipLaunchKernelGGL(blur2d_kernel<K>, grid, dim3(256), 0, st, in, out, dec, h, w, (w - 1) / 2 + 1, t);
+    dim3 grid(aff_cdiv(w, BT_X), aff_cdiv(h, BT_Y), batch);
+    hipLaunchKernelGGL(blur2d_kernel<K>, grid, dim3(256), 0, st, in, out, dec, h, w, (w - 1) / 2 + 1, in_stride, out_stride, t);
 }
 
+// batch images per launch: image b reads in + b*in_stride and writes out / dec + b*out_stride (floats)
 static int blur_dispatch(affnet_ctx* ctx, const float* in, float* out, float* dec, int h, int w, const float* taps, int k,
-                         hipStream_t st) {
+                         hipStream_t st, int batch = 1, size_t in_stride = 0, size_t out_stride = 0) {
     switch (k) {
-        case 3: launch_blur<3>(in, out, dec, h, w, taps, st); break;
-        case 5: launch_blur<5>(in, out, dec, h, w, taps, st); break;
-        case 7: launch_blur<7>(in, out, dec, h, w, taps, st); break;
-        case 9: launch_blur<9>(in, out, dec, h, w, taps, st); break;
-        case 11: launch_blur<11>(in, out, dec, h, w, taps, st); break;
-        case 13: launch_blur<13>(in, out, dec, h, w, taps, st); break;
-        case 15: launch_blur<15>(in, out, dec, h, w, taps, st); break;
-        case 17: launch_blur<17>(in, out, dec, h, w, taps, st); break;
-        case 19: launch_blur<19>(in, out, dec, h, w, taps, st); break;
-        case 21: launch_blur<21>(in, out, dec, h, w, taps, st); break;
+        case 3: launch_blur<3>(in, out, dec, h, w, batch, in_stride, out_stride, taps, st); break;
+        case 5: launch_blur<5>(in, out, dec, h, w, batch, in_stride, out_stride, taps, st); break;
+        case 7: launch_blur<7>(in, out, dec, h, w, batch, in_stride, out_stride, taps, st); break;
+        case 9: launch_blur<9>(in, out, dec, h, w, batch, in_stride, out_stride, taps, st); break;
+        case 11: launch_blur<11>(in, out, dec, h, w, batch, in_stride, out_stride, taps, st); break;
+        case 13: launch_blur<13>(in, out, dec, h, w, batch, in_stride, out_stride, taps, st); break;
+        case 15: launch_blur<15>(in, out, dec, h, w, batch, in_stride, out_stride, taps, st); break;
+        case 17: launch_blur<17>(in, out, dec, h, w, batch, in_stride, out_stride, taps, st); break;
+        case 19: launch_blur<19>(in, out, dec, h, w, batch, in_stride, out_stride, taps, st); break;
+        case 21: launch_blur<21>(in, out, dec, h, w, batch, in_stride, out_stride, taps, st); break;
         default:
             return aff_fail(ctx, AFFNET_ERR_INVALID, "unsupported Gaussian size %d (supported: odd 3..21)", k);
     }
@@ -119,16 +125,19 @@ extern "C" int affnet_pyramid_build(affnet_ctx* ctx, const float* d_img, void* s
         const size_t lvl = (size_t)g.h * g.w;
         if (o == 0) {
             if (c.first_blur_taps > 0) {
-                int rc = blur_dispatch(ctx, d_img, base, nullptr, g.h, g.w, c.first_blur, c.first_blur_taps, st);
+                int rc = blur_dispatch(ctx, d_img, base, nullptr, g.h, g.w, c.first_blur, c.first_blur_taps, st, ctx->B, lvl,
+                                       ctx->pyr_stride);
                 if (rc) return rc;
             } else {
-                AFF_HIP(ctx, hipMemcpyAsync(base, d_img, lvl * sizeof(float), hipMemcpyDeviceToDevice, st));
+                AFF_HIP(ctx, hipMemcpy2DAsync(base, ctx->pyr_stride * sizeof(float), d_img, lvl * sizeof(float), lvl * sizeof(float),
+                                              (size_t)ctx->B, hipMemcpyDeviceToDevice, st));
             }
         }
         for (int l = 1; l < L; ++l) {
             float* dec = nullptr;
             if (l == dec_level && o + 1 < c.n_octaves) dec = ctx->pyr + ctx->oct[o + 1].pyr_off;
-            int rc = blur_dispatch(ctx, base + (l - 1) * lvl, base + l * lvl, dec, g.h, g.w, c.level_blur[l], c.level_blur_taps[l], st);
+            int rc = blur_dispatch(ctx, base + (l - 1) * lvl, base + l * lvl, dec, g.h, g.w, c.level_blur[l], c.level_blur_taps[l], st,
+                                   ctx->B, ctx->pyr_stride, ctx->pyr_stride);
             if (rc) return rc;
         }
     }

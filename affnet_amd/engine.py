@@ -35,9 +35,10 @@ class Context(object):
     """One extractor instance on one device: config, workspace, pyramid views."""
 
     def __init__(self, height, width, device, n_levels, init_sigma, border, mr_size, threshold,
-                 num_features, num_prefilter, max_keep=16384):
+                 num_features, num_prefilter, max_keep=16384, batch=1):
         self.plan = PyramidPlan(height, width, n_levels, init_sigma, border)
-        self.cfg = self.plan.fill_config(mr_size, threshold, num_features, num_prefilter, max_keep)
+        self.batch = int(batch)
+        self.cfg = self.plan.fill_config(mr_size, threshold, num_features, num_prefilter, max_keep, batch=self.batch)
         self.device = device
         self.handle = C.c_void_p()
         idx = device.index if device.index is not None else torch.cuda.current_device()
@@ -50,13 +51,15 @@ class Context(object):
         self.cap_final = lib.affnet_capacity_final(self.handle)
         self._ws_f32 = self.workspace.view(torch.float32)
 
-    def pyramid_views(self):
-        """scale_pyr[o][l] as (1,1,h,w) views into the workspace (SparseImgRepresenter.py:55)."""
+    def pyramid_views(self, image=0):
+        """scale_pyr[o][l] of image `image` of the batch as (1,1,h,w) views into the workspace
+        (SparseImgRepresenter.py:55)."""
         pyr = []
+        base = image * lib.affnet_pyramid_image_stride(self.handle)
         for o, (h, w) in enumerate(self.plan.sizes):
             levels = []
             for l in range(self.plan.levels_per_octave):
-                off = lib.affnet_pyramid_level_offset(self.handle, o, l)
+                off = base + lib.affnet_pyramid_level_offset(self.handle, o, l)
                 levels.append(self._ws_f32[off:off + h * w].view(1, 1, h, w))
             pyr.append(levels)
         return pyr

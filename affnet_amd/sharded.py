@@ -29,6 +29,19 @@ def pack_records(results, n_cap, device):
     return torch.stack(rows).to(device)
 
 
+def pack_batched_records(results, n_cap):
+    """Same record layout from the batched fused path: each result dict holds (B, n_cap, ...) tensors (or
+    (n_cap, ...) for a single image) and `count` (B,).  Returns (sum of B, 1 + n_cap * 135), images in order."""
+    rows = []
+    for r in results:
+        cnt = r["count"].to(torch.float32).view(-1, 1)
+        b = cnt.size(0)
+        body = torch.cat([r["LAFs"].reshape(b, n_cap, 6), r["responses"].reshape(b, n_cap, 1), r["descriptors"].reshape(b, n_cap, 128)],
+                         dim=2)
+        rows.append(torch.cat([cnt, body.reshape(b, n_cap * 135)], dim=1))
+    return torch.cat(rows, dim=0)
+
+
 def unpack_record(row, n_cap):
     n = int(row[0].item())
     body = row[1:].view(n_cap, 135)[:n]

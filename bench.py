@@ -8,7 +8,8 @@
 A "step" = one pass of the whole hot path (pyramid -> Hessian/NMS detector -> AffNet -> filter ->
 OriNet -> level select -> HardNet) over one batch of 64 synthetic 1024x768 images, 2000 keypoints
 each (BASELINE.json configs[2], the configuration the metric is quoted on), per rank (weak scaling),
-images resident in HBM before the timed region, followed for N > 1 by the all_gather of the padded
+images resident in HBM before the timed region, processed as 4 fused library calls of 16 images (every
+kernel launch covers 16 images), followed for N > 1 by the all_gather of the padded
 (count, LAFs, responses, descriptors) records.  value = keypoints returned by all ranks / max-over-ranks time.
 
 roofline   : dominant kernel = fused HardNet trunk (cnn32_trunk_kernel<2>, fp32 MFMA).  achieved =
@@ -66,10 +67,10 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=BATCH, help="images per step per rank")
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("AFFNET_BENCH_CHUNK", "16")),
+                    help="images per fused library call (every kernel launch covers `chunk` images)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("AFFNET_BENCH_STREAMS", "1")),
-                    help="independent full-path streams (each with its own context)")
-    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("AFFNET_BENCH_PIPELINE", "1")),
-                    help="1: detector of image i+1 on a second stream next to the CNN stages of image i")
+                    help="independent streams (each with its own context) the chunks alternate over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -99,28 +100,30 @@ def main():
     A, O, Hn = load("AffNet", affnet_amd.AffNetFast), load("OriNet", affnet_amd.OriNetFast), load("HardNet", affnet_amd.HardNet)
     # global image i of a step lives on rank i % world (weak scaling: `batch` images per rank per step)
     seeds = [rank + world * j for j in range(args.batch)]
-    imgs = [synthetic_image(H, W, s).to(dev) for s in seeds]
+    CH = max(1, min(args.chunk, args.batch))
+    imgs = torch.cat([synthetic_image(H, W, s) for s in seeds], 0).to(dev)           # (batch,1,H,W) resident in HBM
+    chunks = [imgs[i:i + CH] for i in range(0, args.batch, CH)]
     S = max(1, args.streams)
-    PIPE = bool(args.pipeline) and S == 1
-    if PIPE:
-        S = 2                      # two contexts alternate; ONE CNN stream + ONE detector stream
-    dets = [affnet_amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=NKP, border=5, num_Baum_iters=1, AffNet=A, OriNet=O).to(dev)
-            for _ in range(S)]
+    # one extractor (context + workspace) per (stream, chunk size); a ragged last chunk gets its own
+    dets = {}
+    for ci, c in enumerate(chunks):
+        k = (ci % S, c.size(0))
+        if k not in dets:
+            dets[k] = affnet_amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=NKP, border=5, num_Baum_iters=1,
+                                                                AffNet=A, OriNet=O).to(dev)
+            dets[k]._context(c, allow_batch=True)  # create contexts / workspaces before anything is timed
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
-    det_stream = torch.cuda.Stream(device=dev) if PIPE else None
-    for d in dets:
-        d._context(imgs[0])            # create contexts / workspaces before anything is timed
 
-    def step(profile=False):
-        results = [None] * len(imgs)
-        for i, x in enumerate(imgs):
-            with torch.cuda.stream(streams[0] if PIPE else streams[i % S]):
-                results[i] = dets[i % S].enqueue(x, do_ori=True, desc=Hn, det_stream=det_stream)
+    def step():
+        results = [None] * len(chunks)
+        for ci, c in enumerate(chunks):
+            with torch.cuda.stream(streams[ci % S]):
+                results[ci] = dets[(ci % S, c.size(0))].enqueue(c, do_ori=True, desc=Hn)
         for s in streams:
             s.synchronize()
         if world > 1:
-            rec = sharded.pack_records(results, NKP, dev)
-            rec = sharded.gather_features(rec, len(imgs) * world)
+            rec = sharded.pack_batched_records(results, NKP)
+            rec = sharded.gather_features(rec, args.batch * world)
             torch.cuda.synchronize()
         return results
 
@@ -131,22 +134,23 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    for d in dets:
+    for d in dets.values():
         _lib.check(_lib.lib.affnet_profile_enable(d._ctx.handle, 1), d._ctx.handle, "profile_enable")
     barrier()
     t0 = time.perf_counter()
     kp = 0
     for _ in range(args.steps):
         res = step()
-        kp += int(sum(int(r["count"].item()) for r in res))   # device counts, read after the step's sync
+        kp += int(sum(int(r["count"].sum().item()) for r in res))   # device counts, read after the step's sync
     barrier()
     dt = time.perf_counter() - t0
     # stage timings recorded by HIP events on the launch streams during the timed region
-    sums, calls = [0.0] * 8, 0
-    for d in dets:
+    sums, calls, call_imgs = [0.0] * 8, 0, 0
+    for (_, nimg), d in dets.items():
         buf, n = (C.c_double * 8)(), C.c_int32(0)
         _lib.check(_lib.lib.affnet_profile_read(d._ctx.handle, C.byref(buf), C.byref(n)), d._ctx.handle, "profile_read")
         calls += n.value
+        call_imgs += n.value * nimg
         sums = [a + b for a, b in zip(sums, list(buf))]
     t_all = torch.tensor([dt], dtype=torch.float64, device=dev)
     kp_all = torch.tensor([kp], dtype=torch.float64, device=dev)
@@ -155,11 +159,12 @@ def main():
         dist.all_reduce(kp_all, op=dist.ReduceOp.SUM)
     if rank == 0:
         tmax, kps = float(t_all.item()), float(kp_all.item())
-        stage_ms = [s / max(calls, 1) for s in sums]
+        stage_ms = [s / max(call_imgs, 1) for s in sums]           # per image (rank 0's launches)
         names = ["pyramid", "detector", "affnet", "shape_filter", "orinet", "denorm_levelsel", "hardnet_trunk", "hardnet_head"]
-        trunk_ms = stage_ms[6]
+        img_per_launch = call_imgs / max(calls, 1)
+        trunk_ms = sums[6] / max(calls, 1)                          # mean duration of one HardNet trunk launch
         kp_per_img = kps / max(1, args.steps * args.batch * world)
-        flops_launch = kp_per_img * (FLOP_HARD - FLOP_HARD_HEAD)
+        flops_launch = kp_per_img * img_per_launch * (FLOP_HARD - FLOP_HARD_HEAD)
         achieved = flops_launch / (trunk_ms * 1e-3) / 1e12 if trunk_ms > 0 else 0.0
         out = {
             "metric": "keypoints/sec (detect+AffNet+OriNet+HardNet) per image, 2000 kp @1024x768",
@@ -170,7 +175,7 @@ def main():
                                    "2000 kp each, full path detect+AffNet+OriNet+HardNet; AffNet/OriNet shipped weights, "
                                    "HardNet seeded synthetic weights (HardNet++.pth is a missing blob)" % args.batch,
                        "global_batch": args.batch * world, "keypoints_per_image": kp_per_img,
-                       "streams_per_gpu": "1 CNN stream + 1 detector stream (2 contexts alternate)" if PIPE else S,
+                       "images_per_launch": CH, "streams_per_gpu": S,
                        "parallelism": "image-per-GPU x%d, all_gather of padded records" % world if world > 1 else "1 GPU"},
             "ms_per_image": tmax / (args.steps * args.batch) * 1e3,
             "stage_ms_per_image": dict(zip(names, [round(v, 4) for v in stage_ms])),

@@ -18,6 +18,10 @@
  *    returns a human readable message for the last failure on that context;
  *  - a context is not re-entrant: one thread / one stream at a time per context (the
  *    reference object is stateful in the same way, SparseImgRepresenter.py:55);
+ *  - batching: a context created with cfg->batch = B processes B equally sized images per call.  Every
+ *    per-image array then has a leading batch dimension: d_img (B,H,W); row arrays (B,cap,...) with image
+ *    b's rows at b*cap (cap = affnet_capacity_prefilter / _final as documented per entry point, or the
+ *    n_max argument); d_count (B).  Rows >= count[b] of image b are zero.  B = 1 is the reference's shape;
  *  - all image / LAF / descriptor arithmetic is IEEE fp32, compiled with
  *    -ffp-contract=off; fused multiply-adds are used only where the reference's CPU
  *    kernels use them ("bit-exact detector").
@@ -74,6 +78,9 @@ typedef struct affnet_config {
     int32_t num_prefilter;                 /* C = int(1.5 N) if Baumberg iters > 0 else N (:192-194)   */
     int32_t max_raw_per_octave_div;        /* raw-maxima capacity of octave o = h*w / div (default 4)  */
     int32_t max_keep;                      /* capacity of the selected list when N <= 0                */
+    int32_t batch;                         /* images per call, all of size height x width (<= 0: 1).
+                                            * The reference is batch-size-1 (HandCraftedModules.py:283-284) and
+                                            * loops in Python; here one launch covers the batch (BASELINE configs[2]). */
 } affnet_config;
 
 /* ---- context ------------------------------------------------------------------------------- */
@@ -92,8 +99,12 @@ const char* affnet_version(void);
  * tensors (`scale_pyr`, SparseImgRepresenter.py:55). */
 size_t affnet_workspace_bytes(const affnet_ctx* ctx);
 int affnet_bind_workspace(affnet_ctx* ctx, void* d_workspace, size_t bytes);
-/* Float offset (from the workspace base) of pyramid level (o, l); -1 if out of range. */
+/* Float offset (from the workspace base) of pyramid level (o, l) of image 0; -1 if out of range. */
 int64_t affnet_pyramid_level_offset(const affnet_ctx* ctx, int octave, int level);
+/* Floats between the pyramids of consecutive images of the batch. */
+int64_t affnet_pyramid_image_stride(const affnet_ctx* ctx);
+/* Images per call (cfg->batch). */
+int affnet_batch(const affnet_ctx* ctx);
 /* Maximum number of rows the detector / shape stages can emit (C and N capacities). */
 int affnet_capacity_prefilter(const affnet_ctx* ctx);
 int affnet_capacity_final(const affnet_ctx* ctx);
@@ -256,7 +267,8 @@ int affnet_profile_read(affnet_ctx* ctx, double sum_ms[AFFNET_PROFILE_STAGES], i
 
 /* The one optional read-back: copies counters to the host after synchronising `stream`:
  * out[0] = rows after detection, out[1] = rows after shape filter, out[2] = capacity-overflow
- * flag (non-zero => AFFNET_ERR_CAPACITY semantics), out[3] = raw maxima found. */
+ * flag (non-zero => AFFNET_ERR_CAPACITY semantics), out[3] = raw maxima found
+ * (sums / OR over the images of the batch). */
 int affnet_read_counts(affnet_ctx* ctx, int32_t out[4], void* stream);
 
 /* Host helper (no GPU): out[ps] = affine_grid base coordinates (linspace(-1,1,ps)*(ps-1))/ps with

@@ -346,6 +346,39 @@ def test_two_stream_pipelining_gives_identical_results(amd, nets):
             assert torch.equal(o[k][:n], r[k]), k
 
 
+def test_batched_launches_equal_single_image_calls(amd, nets):
+    """BASELINE configs[2] runs as (B,1,H,W) batches: every kernel launch covers the B images.  Each image of the
+    batch must come out bit-identical to its own single-image call - incl. an image with no detections at all
+    (ragged per-image row counts) and the 'fewer detections than the budget' branch."""
+    A, O, H = nets
+    imgs = [orc.synthetic_image(240, 320, s) for s in (1, 2, 3)] + [torch.zeros(1, 1, 240, 320), orc.synthetic_image(240, 320, 7)]
+    xb = torch.cat(imgs, 0).to(DEV)
+    for nfeat in (300, 4000):
+        mk = lambda: amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=nfeat, border=5, num_Baum_iters=1, AffNet=A,
+                                                        OriNet=O).to(DEV)
+        single = []
+        for x in imgs:
+            try:
+                single.append(mk().run(x.to(DEV), do_ori=True, desc=H))
+            except RuntimeError:          # flat image: the single-image API raises like the reference
+                single.append(None)
+        det = mk()
+        batched = det.run_batch(xb, do_ori=True, desc=H)
+        assert len(batched) == len(imgs)
+        for b, (one, got) in enumerate(zip(single, batched)):
+            if one is None:
+                assert got["LAFs"].shape[0] == 0
+                continue
+            assert got["LAFs"].shape == one["LAFs"].shape, (b, got["LAFs"].shape, one["LAFs"].shape)
+            for k in ("LAFs", "responses", "descriptors", "ids"):
+                assert torch.equal(got[k], one[k]), (nfeat, b, k)
+        # rows past each image's count are zero in the capacity-sized tensors
+        r = det.enqueue(xb, do_ori=True, desc=H)
+        torch.cuda.synchronize()
+        for b, n in enumerate(r["count"].cpu().tolist()):
+            assert float(r["LAFs"][b, n:].abs().sum()) == 0.0 and float(r["descriptors"][b, n:].abs().sum()) == 0.0
+
+
 def test_just_shape_config1(amd, nets, golden_dir):
     """BASELINE.json configs[0]: detect_affine_shape on a patch column (examples/just_shape)."""
     g = np.load(os.path.join(golden_dir, "just_shape_column.npz"))

@@ -53,6 +53,12 @@ def test_shard_and_gather_world2():
 def test_single_process_passthrough_and_generators_agree():
     rec = sharded.pack_records([_fake_result(0)], N_CAP, torch.device("cpu"))
     assert sharded.gather_features(rec, 1) is rec
+    # batched results (the fused path returns (B, cap, ...) tensors per library call) pack to the same records
+    rs = [_fake_result(i) for i in range(5)]
+    stack = lambda lst: {k: (torch.cat([r[k] for r in lst]) if k == "count" else torch.stack([r[k] for r in lst])) for k in lst[0]}
+    batched = sharded.pack_batched_records([stack(rs[:3]), stack(rs[3:]), ], N_CAP)
+    assert torch.equal(batched, sharded.pack_records(rs, N_CAP, torch.device("cpu")))
+    assert torch.equal(sharded.pack_batched_records([rs[0]], N_CAP), rec)
     import affnet_oracle as orc
     from affnet_amd.synthetic import synthetic_image, synthetic_hardnet_state
     assert torch.equal(synthetic_image(48, 64, 3), orc.synthetic_image(48, 64, 3))
