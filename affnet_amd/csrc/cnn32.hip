@@ -30,17 +30,32 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Plane strides (floats) of the padded 34x34 / 18x18 / 10x10 planes, all == 17 (mod 32): the 4 k-planes of
-// an A fragment (lanes 16..31 read the plane after lanes 0..15) land 17 banks apart -> at most 1 of 16 banks
-// collides inside a 32-lane half (PMC: SQ_LDS_BANK_CONFLICT was 47% of LDS cycles with stride == 5 mod 32),
-// the stride-2 layers are conflict free (even vs odd banks), and the epilogue stores (16 channels of one
-// pixel per 16 lanes) hit 16 distinct banks because 17 is odd.
-#define PST32 1169
-#define PST16 337
-#define PST8 113
+// LDS activation layout: channel-interleaved by 4.  A tensor [C][H][H] lives as C/4 "plane groups"; element
+// (c, y, x) of the zero-haloed (H+2)-square image sits at  (c/4)*PSG + ((y+1)*WP + x+1)*4 + c%4  (floats).  One
+// ds_read_b128 of lane (pixel m, kq) then delivers the A operands of FOUR MFMA k-steps (channels 4*(4G+kq)+j,
+// j = 0..3) - a quarter of the LDS instructions and half the LDS cycles of per-k-step ds_read_b32, which is what
+// kept the matrix pipe waiting: under 16-32 waves of MFMA loops an LDS read returns after several hundred cycles and
+// lgkmcnt (4 bits) cannot cover more than 15 reads in flight.  The packed weights are interleaved the same way, so a
+// B fragment is one coalesced global_load_dwordx4 per 4 k-steps (1 KB per wave instruction).
+//
+// Each buffer is written by one layer's epilogue and read by the next layer's implicit GEMM; (WP, PSG) are chosen for
+// the READER (ds_read_b128 services lanes {0-3,12-15,20-27},{4-11,16-19,28-31},... per cycle over 64 banks):
+//   stride-1 reader: 16 consecutive pixels = 64 banks; the kq = 1 lanes of a group must land on the other half:
+//                    H = 32/16: PSG == 0 (mod 64);  H = 8 (a tile = 2 rows): WP = 16, PSG == 32 (mod 64);
+//   stride-2 reader: pixels 2 apart hit banks == 0..3 (mod 8) -> PSG == 4 (mod 8) (and WP == 0 (mod 8) when a tile
+//                    spans two output rows, 16 -> 8) - these also make the epilogue's ds_write_b32 conflict free.
+template <int H_, int WP_, int PSG_>
+struct Lay {
+    static constexpr int H = H_, WP = WP_, PSG = PSG_;
+    __device__ static __forceinline__ int at(int c, int y, int x) { return (c >> 2) * PSG + ((y + 1) * WP + x + 1) * 4 + (c & 3); }
+};
+typedef Lay<32, 34, 4672> LayC0;   // conv0 out -> conv1 (stride 1)
+typedef Lay<32, 34, 4628> LayC1;   // conv1 out -> conv2 (stride 2)
+typedef Lay<16, 18, 1344> LayC2;   // conv2 out -> conv3 (stride 1)
+typedef Lay<16, 24, 1732> LayC3;   // conv3 out -> conv4 (stride 2, tile = 2 output rows)
+typedef Lay<8, 16, 672> LayC4;     // conv4 out -> conv5 (stride 1, tile = 2 rows)
+typedef Lay<8, 16, 672> LayC5;     // conv5 out -> AffNet / OriNet heads
 #define WP32 34
-#define WP16 18
-#define WP8 10
 #define HEAD_K 8192
 
 // ---- packed weight layout --------------------------------------------------------------------------
@@ -59,7 +74,7 @@ static NetLayout net_layout(int kind) {
     size_t off = 0;
     for (int i = 0; i < 6; ++i) {
         L.cin[i] = ch[i]; L.cout[i] = ch[i + 1];
-        L.w_off[i] = off; off += (size_t)9 * ch[i] * ch[i + 1];
+        L.w_off[i] = off; off += (i == 0) ? (size_t)12 * ch[1] : (size_t)9 * ch[i] * ch[i + 1];   // conv0: K = 9 padded to 12
         L.b_off[i] = off; off += ch[i + 1];
         off = (off + 3) & ~(size_t)3;
     }
@@ -90,8 +105,9 @@ extern "C" int affnet_cnn32_pack_weights(int kind, const float* const* conv_w, c
             for (int c = 0; c < ci; ++c)
                 for (int t = 0; t < 9; ++t) {
                     const float w = conv_w[i][((size_t)n * ci + c) * 9 + t] * s;
-                    if (i == 0) out[L.w_off[0] + (size_t)n * 9 + t] = w;                 // [n][tap]
-                    else out[L.w_off[i] + ((size_t)t * ci + c) * co + n] = w;           // [tap][cin][n]
+                    if (i == 0) out[L.w_off[0] + (size_t)t * co + n] = w;               // [tap (12, rows 9..11 zero)][n]
+                    else                                                                // [tap][G = c/16][kq = (c/4)%4][n][j = c%4]
+                        out[L.w_off[i] + ((((size_t)t * (ci / 16) + c / 16) * 4 + (c / 4) % 4) * co + n) * 4 + c % 4] = w;
                 }
         }
     }
@@ -123,125 +139,327 @@ static NetOffsets to_offsets(const NetLayout& L) {
 }
 
 // ---- device helpers ------------------------------------------------------------------------------
+// Wave-wide sum on the VALU only (DPP row reductions + 4 readlanes).  __shfl_xor compiles to ds_bpermute_b32,
+// i.e. six DEPENDENT trips through the LDS queue, which the MFMA loops of the co-resident waves keep hundreds of
+// requests deep: the two input-norm reductions cost ~15k cycles per patch that way (profiles/r01_s2b_cnn_phase_timing).
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v = dpp_add<0xB1>(v);     // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);     // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);    // row_half_mirror: 8 lanes
+    v = dpp_add<0x140>(v);    // row_mirror: every lane holds the sum of its row of 16
+    const int iv = __float_as_int(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(iv, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(iv, 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(iv, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(iv, 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
-// Sum `v` over the NW wavefronts of the workgroup; red must hold >= NW floats.  Two barriers.
+// Sum `v` over the NW wavefronts of the workgroup.  `slot` must hold NW floats that nothing else touches during the
+// kernel (each reduction of a kernel gets its own slot), so ONE barrier suffices.
 template <int NW>
-__device__ __forceinline__ float block_sum(float v, float* red) {
+__device__ __forceinline__ float block_sum(float v, float* slot) {
     v = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
     __syncthreads();
     float t = 0.f;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) t += red[w];
+    for (int w = 0; w < NW; ++w) t += slot[w];
     return t;
 }
 
-// Zero the 1-pixel halo of `cout` planes of an (H+2)x(H+2) padded layout.
-template <int H, int PST, int NTHR>
-__device__ __forceinline__ void zero_halo(float* act, int cout) {
-    constexpr int WP = H + 2;
-    constexpr int CELLS = 4 * (H + 1);
-    for (int i = threadIdx.x; i < cout * CELLS; i += NTHR) {
-        const int c = i / CELLS, e = i - c * CELLS;
+// Zero the 1-pixel halo of the C/4 plane groups of layout L (16-byte stores).
+template <typename L, int NTHR>
+__device__ __forceinline__ void zero_halo(float* act, int channels) {
+    constexpr int H = L::H, CELLS = 4 * (H + 1);
+    const int groups = channels >> 2;
+    for (int i = threadIdx.x; i < groups * CELLS; i += NTHR) {
+        const int g = i / CELLS, e = i - g * CELLS;
         int y, x;
-        if (e < WP) { y = 0; x = e; }
-        else if (e < 2 * WP) { y = H + 1; x = e - WP; }
-        else { const int r = e - 2 * WP; y = 1 + (r >> 1); x = (r & 1) ? H + 1 : 0; }
-        act[c * PST + y * WP + x] = 0.0f;
+        if (e < H + 2) { y = 0; x = e; }
+        else if (e < 2 * (H + 2)) { y = H + 1; x = e - (H + 2); }
+        else { const int r = e - 2 * (H + 2); y = 1 + (r >> 1); x = (r & 1) ? H + 1 : 0; }
+        *reinterpret_cast<f32x4*>(&act[g * L::PSG + (y * L::WP + x) * 4]) = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 }
 
-// Implicit-GEMM 3x3 convolution (padding 1) of the planar LDS tensor `act` ([CIN][HIN+2][HIN+2],
-// plane stride PSI) with packed weights Wg [9*CIN][COUT]; leaves the TM x TN tiles of this wave in
-// `acc` (pre-activation, no bias).  HOUT = HIN / STRIDE.
-template <int NW, int CIN, int COUT, int HOUT, int STRIDE, int TM, int TN, int PSI, int WPI, int UNROLL>
-__device__ __forceinline__ void conv3x3_mfma(const float* act, const float* __restrict__ Wg, f32x4 (&acc)[TM][TN], int wave, int lane) {
+// Plane groups (16 input channels = 4 MFMA k-steps) per pipeline chunk: grow the chunk until it holds `target`
+// MFMAs, as long as the two A register sets stay within `max_a_regs` VGPRs.
+constexpr int pick_groups(int cin, int tm, int tn, int target, int max_a_regs) {
+    int g = 1;
+    while (g * 2 <= cin / 16 && (cin / 16) % (g * 2) == 0 && 4 * tm * tn * g < target && 2 * (g * 2) * tm * 4 <= max_a_regs) g *= 2;
+    return g;
+}
+
+// Implicit-GEMM 3x3 convolution (padding 1) of the LDS tensor `act` (layout LI, CIN channels) with packed weights
+// Wg [tap][CIN/16][kq][COUT][4]; leaves the TM x TN tiles (16 px x 16 ch) of this wave in `acc` (pre-activation, no
+// bias).  HOUT = LI::H / STRIDE.  K is walked in chunks of GRP plane groups (a chunk never straddles a tap).
+// Software pipeline, one chunk deep, two statically named register sets: while the MFMAs of chunk c issue, the A
+// (ds_read_b128) and B (global_load_dwordx4) fragments of chunk c+1 are in flight; loads and MFMAs interleave per
+// plane group so that few LDS reads are outstanding at any wait (lgkmcnt has 4 bits).
+template <int GRP, int TM, int TN>
+struct Frag {
+    f32x4 a[GRP][TM];
+    f32x4 b[GRP][TN];
+};
+
+// B fragments of chunk 0 of a layer (and its bias values): they do not depend on the activations, so the kernel requests
+// them BEFORE the barriers / epilogue of the previous layer and their L2 latency (1-2k cycles under load) is hidden.
+template <int NW, int COUT, int HOUT, int TM, int TN, int GRP>
+__device__ __forceinline__ void prefetch_b0(const float* __restrict__ Wg, f32x4 (&b0)[GRP][TN], int wave, int lane) {
+    constexpr int MG = (HOUT * HOUT / 16) / TM;
+    const int ng = wave / MG, m = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int u = 0; u < GRP; ++u)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b0[u][j] = *reinterpret_cast<const f32x4*>(&Wg[u * 16 * COUT + (kq * COUT + (ng * TN + j) * 16 + m) * 4]);
+}
+template <int NW, int HOUT, int TM, int TN>
+__device__ __forceinline__ void prefetch_bias(const float* __restrict__ bias, float (&bv)[TN], int wave, int lane) {
+    constexpr int MG = (HOUT * HOUT / 16) / TM;
+    const int ng = wave / MG;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bv[j] = bias[(ng * TN + j) * 16 + (lane & 15)];
+}
+
+template <int NW, int CIN, int COUT, typename LI, int STRIDE, int TM, int TN, int GRP>
+__device__ __forceinline__ void conv3x3_mfma(const float* act, const float* __restrict__ Wg, const f32x4 (&b0)[GRP][TN],
+                                             f32x4 (&acc)[TM][TN], int wave, int lane) {
+    constexpr int HOUT = LI::H / STRIDE;
     constexpr int MT = HOUT * HOUT / 16, NT = COUT / 16;
     constexpr int MG = MT / TM, NG = NT / TN;
+    constexpr int NGRP = CIN / 16, NCHUNK = 9 * NGRP / GRP;
     static_assert(MG * NG == NW, "the waves must tile the layer exactly");
-    static_assert(CIN % 4 == 0 && (CIN / 4) % UNROLL == 0, "bad unroll");
+    static_assert(CIN % 16 == 0 && NGRP % GRP == 0, "bad chunking");
     const int mg = wave % MG, ng = wave / MG;
     const int m = lane & 15, kq = lane >> 4;
+    // lane address of tile 0 / N-tile 0; the other tiles of the wave sit at compile-time offsets (immediates)
+    static_assert(HOUT == 8 || (TM * 16) % HOUT == 0 || HOUT % (TM * 16) == 0, "tile offsets must be wave-uniform constants");
+    int a_lane;
+    {
+        const int p = mg * TM * 16 + m;
+        const int oy = p / HOUT, ox = p - oy * HOUT;
+        a_lane = kq * LI::PSG + ((oy * STRIDE) * LI::WP + ox * STRIDE) * 4;
+    }
+    const int b_lane = (kq * COUT + ng * TN * 16 + m) * 4;
     int a_base[TM], b_base[TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int p = (mg * TM + i) * 16 + m;
-        const int oy = p / HOUT, ox = p - oy * HOUT;
-        a_base[i] = kq * PSI + (oy * STRIDE) * WPI + ox * STRIDE;
-    }
+    for (int i = 0; i < TM; ++i)
+        a_base[i] = a_lane + (HOUT == 8 ? i * 2 * STRIDE * LI::WP * 4 : (((i * 16) / HOUT) * STRIDE * LI::WP + ((i * 16) % HOUT) * STRIDE) * 4);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) b_base[j] = kq * COUT + (ng * TN + j) * 16 + m;
+    for (int j = 0; j < TN; ++j) b_base[j] = b_lane + j * 64;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // K = (tap, cin) is walked in chunks of 4*UNROLL; a chunk never straddles a tap (CIN % (4*UNROLL) == 0).
-    // The B fragments (global / L2, ~1 us latency under load) of chunk c+1 are requested BEFORE the MFMAs of
-    // chunk c and consumed one iteration later; A fragments come from LDS right before use.  (Also double
-    // buffering A in registers was measured SLOWER: hipcc turns the ping-pong into 64 v_mov per chunk pair and
-    // waits for the new loads at the end of the chunk.)
-    constexpr int KSTEP = 4 * UNROLL;
-    constexpr int NCHUNK = 9 * CIN / KSTEP;
-    float bn[UNROLL][TN];
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bn[u][j] = Wg[(4 * u) * COUT + b_base[j]];
-#pragma unroll 1
-    for (int ch = 0; ch < NCHUNK; ++ch) {
-        const int k0 = ch * KSTEP;
-        const int tap = k0 / CIN, c0 = k0 - tap * CIN;
+    Frag<GRP, TM, TN> f0, f1;
+
+    auto a_chunk_off = [](int ch) {
+        const int q0 = ch * GRP;
+        const int tap = q0 / NGRP, g0 = q0 - tap * NGRP;
         const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;          // tap / 3, tap % 3 for tap < 9
-        const int a_off = c0 * PSI + ky * WPI + kx;
-        float a[UNROLL][TM], b[UNROLL][TN];
+        return g0 * 4 * LI::PSG + (ky * LI::WP + kx) * 4;
+    };
+    auto load_group = [&](Frag<GRP, TM, TN>& f, int u, int a_off, const float* w) {
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
+        for (int i = 0; i < TM; ++i) f.a[u][i] = *reinterpret_cast<const f32x4*>(&act[a_off + u * 4 * LI::PSG + a_base[i]]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) b[u][j] = bn[u][j];
-        const int kn = (ch + 1 < NCHUNK) ? k0 + KSTEP : k0;         // last chunk re-reads itself (in bounds)
-        const float* wn = Wg + (size_t)kn * COUT;
+        for (int j = 0; j < TN; ++j) f.b[u][j] = *reinterpret_cast<const f32x4*>(&w[u * 16 * COUT + b_base[j]]);
+    };
+    auto mfma_group = [&](const Frag<GRP, TM, TN>& f, int u) {
 #pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bn[u][j] = wn[(4 * u) * COUT + b_base[j]];
-        __builtin_amdgcn_sched_barrier(0);                           // keep the prefetch ahead of this chunk's MFMAs
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
-#pragma unroll
-            for (int i = 0; i < TM; ++i) a[u][i] = act[(4 * u) * PSI + a_off + a_base[i]];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u)
+        for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][i], b[u][j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[u][i][s4], f.b[u][j][s4], acc[i][j], 0, 0, 0);
+    };
+    // compute the chunk held in `cur` while loading chunk `nxt_ch` into `nxt`
+    auto stage = [&](const Frag<GRP, TM, TN>& cur, Frag<GRP, TM, TN>& nxt, int nxt_ch) {
+        const int a_off = a_chunk_off(nxt_ch);
+        const float* w = Wg + (size_t)nxt_ch * (GRP * 16 * COUT);
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) {
+            load_group(nxt, u, a_off, w);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(cur, u);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    {
+        const int a_off = a_chunk_off(0);
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) f0.a[u][i] = *reinterpret_cast<const f32x4*>(&act[a_off + u * 4 * LI::PSG + a_base[i]]);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) f0.b[u][j] = b0[u][j];
+        }
+    }
+#pragma unroll 1
+    for (int ch = 0; ch + 1 < NCHUNK; ch += 2) {
+        stage(f0, f1, ch + 1);
+        stage(f1, f0, (ch + 2 < NCHUNK) ? ch + 2 : ch + 1);         // past the end: re-read the last chunk (in bounds, unused)
+    }
+    if (NCHUNK & 1) {
+#pragma unroll
+        for (int u = 0; u < GRP; ++u) mfma_group(f0, u);
     }
 }
 
-// Epilogue: bias + ReLU, write the wave's tiles into the padded planar LDS layout of the NEXT layer.
-template <int COUT, int HOUT, int TM, int TN, int PSO>
-__device__ __forceinline__ void store_tiles_lds(float* act, const float* __restrict__ bias, const f32x4 (&acc)[TM][TN], int wave, int lane) {
+// Same contraction with ONE A register set that is reloaded in place (for TM = 8 under a 128-VGPR budget, where two
+// sets of 8 float4 do not fit): chunk = one plane group; the tiles are processed in pairs - 8 * TN MFMAs on 2 * TN
+// independent accumulators - and as soon as a pair's MFMAs have issued, its two A registers are reloaded with the next
+// chunk's data, so every load is (TM - 2) / TM of a chunk ahead of its use.  B fragments keep two sets.
+template <int NW, int CIN, int COUT, typename LI, int STRIDE, int TM, int TN>
+__device__ __forceinline__ void conv3x3_mfma_roll(const float* act, const float* __restrict__ Wg, const f32x4 (&b0)[1][TN],
+                                                  f32x4 (&acc)[TM][TN], int wave, int lane) {
+    constexpr int HOUT = LI::H / STRIDE;
+    constexpr int MT = HOUT * HOUT / 16, NT = COUT / 16;
+    constexpr int MG = MT / TM, NG = NT / TN;
+    constexpr int NGRP = CIN / 16, NCHUNK = 9 * NGRP;
+    static_assert(MG * NG == NW && TM % 2 == 0 && CIN % 16 == 0, "bad tiling");
+    const int mg = wave % MG, ng = wave / MG;
+    const int m = lane & 15, kq = lane >> 4;
+    // lane address of tile 0 / N-tile 0; the other tiles of the wave sit at compile-time offsets (immediates)
+    static_assert(HOUT == 8 || (TM * 16) % HOUT == 0 || HOUT % (TM * 16) == 0, "tile offsets must be wave-uniform constants");
+    int a_lane;
+    {
+        const int p = mg * TM * 16 + m;
+        const int oy = p / HOUT, ox = p - oy * HOUT;
+        a_lane = kq * LI::PSG + ((oy * STRIDE) * LI::WP + ox * STRIDE) * 4;
+    }
+    const int b_lane = (kq * COUT + ng * TN * 16 + m) * 4;
+    int a_base[TM], b_base[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+        a_base[i] = a_lane + (HOUT == 8 ? i * 2 * STRIDE * LI::WP * 4 : (((i * 16) / HOUT) * STRIDE * LI::WP + ((i * 16) % HOUT) * STRIDE) * 4);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_base[j] = b_lane + j * 64;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto a_chunk_off = [](int ch) {
+        const int tap = ch / NGRP, g0 = ch - tap * NGRP;
+        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+        return g0 * 4 * LI::PSG + (ky * LI::WP + kx) * 4;
+    };
+    f32x4 fa[TM], fb0[TN], fb1[TN];
+    {
+        const int a_off = a_chunk_off(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(&act[a_off + a_base[i]]);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb0[j] = b0[0][j];
+    }
+    auto chunk = [&](const f32x4 (&bc)[TN], f32x4 (&bn)[TN], int nxt_ch) {
+        const int a_off = a_chunk_off(nxt_ch);
+        const float* w = Wg + (size_t)nxt_ch * (16 * COUT);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bn[j] = *reinterpret_cast<const f32x4*>(&w[b_base[j]]);
+#pragma unroll
+        for (int ip = 0; ip < TM; ip += 2) {
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int i = ip; i < ip + 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][s4], bc[j][s4], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = ip; i < ip + 2; ++i) fa[i] = *reinterpret_cast<const f32x4*>(&act[a_off + a_base[i]]);
+        }
+    };
+#pragma unroll 1
+    for (int ch = 0; ch + 1 < NCHUNK; ch += 2) {
+        chunk(fb0, fb1, ch + 1);
+        chunk(fb1, fb0, (ch + 2 < NCHUNK) ? ch + 2 : ch + 1);
+    }
+    if (NCHUNK & 1) {
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][s4], fb0[j][s4], acc[i][j], 0, 0, 0);
+    }
+}
+
+// conv0 (1 -> COUT channels, K = 9 taps padded to 12) on the matrix cores as well: A[m][k] = the padded standardised
+// patch at (pixel m, tap k), B = packed [12][COUT] taps (rows 9..11 zero), accumulators start at the bias, so the result
+// is the fmaf chain bias, tap 0, ..., tap 8 (+ three exact fma(x, 0, acc)).  3 MFMAs per tile instead of 9 * COUT VALU
+// FMAs per pixel behind dependent LDS weight reads.
+template <int NW, int COUT, int TM, int TN>
+__device__ __forceinline__ void conv0_load_w(const float* __restrict__ W0, const float* __restrict__ bias, float (&b)[4][TN], int wave,
+                                             int lane) {
+    constexpr int MG = 64 / TM;
+    const int ng = wave / MG, m = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = (ng * TN + j) * 16 + m;
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) b[s3][j] = W0[(4 * s3 + kq) * COUT + n];
+        b[3][j] = bias[n];
+    }
+}
+
+template <int NW, int COUT, int TM, int TN>
+__device__ __forceinline__ void conv0_mfma(const float* patch, const float (&b)[4][TN], f32x4 (&acc)[TM][TN], int wave, int lane) {
+    constexpr int MT = 64, NT = COUT / 16, MG = MT / TM, NG = NT / TN;
+    static_assert(MG * NG == NW, "the waves must tile the layer exactly");
+    const int mg = wave % MG;
+    const int m = lane & 15, kq = lane >> 4;
+    int toff[3];
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+        const int t = 4 * s3 + kq;
+        toff[s3] = t < 9 ? (t / 3) * WP32 + (t % 3) : 0;            // taps 9..11: any valid address (weight is zero)
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const float bv = b[3][j];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) acc[i][j] = (f32x4){bv, bv, bv, bv};
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int p = (mg * TM + i) * 16 + m;
+        const int base = (p >> 5) * WP32 + (p & 31);
+        float av[3];
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) av[s3] = patch[base + toff[s3]];
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s3], b[s3][j], acc[i][j], 0, 0, 0);
+    }
+}
+
+// Epilogue: (+ bias,) ReLU, write the wave's tiles into the LDS layout LO read by the NEXT layer.
+template <int COUT, typename LO, int TM, int TN, bool ADD_BIAS = true>
+__device__ __forceinline__ void store_tiles_lds(float* act, const float (&bias)[TN], const f32x4 (&acc)[TM][TN], int wave, int lane) {
+    constexpr int HOUT = LO::H;
     constexpr int MT = HOUT * HOUT / 16, MG = MT / TM;
-    constexpr int WPO = HOUT + 2;
     const int mg = wave % MG, ng = wave / MG;
     const int n = lane & 15, g = lane >> 4;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int ch = (ng * TN + j) * 16 + n;
-        const float bv = bias[ch];
+        const float bv = ADD_BIAS ? bias[j] : 0.0f;
+        const int cbase = (ch >> 2) * LO::PSG + (ch & 3);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int p = (mg * TM + i) * 16 + 4 * g + r;
                 const int oy = p / HOUT, ox = p - oy * HOUT;
-                act[ch * PSO + (oy + 1) * WPO + ox + 1] = fmaxf(acc[i][j][r] + bv, 0.0f);
+                act[cbase + ((oy + 1) * LO::WP + ox + 1) * 4] = fmaxf(ADD_BIAS ? acc[i][j][r] + bv : acc[i][j][r], 0.0f);
             }
         }
     }
@@ -249,7 +467,7 @@ __device__ __forceinline__ void store_tiles_lds(float* act, const float* __restr
 
 // Same for the last trunk layer of HardNet: [c][8][8] flattened = the head GEMM's K order.
 template <int COUT, int TM, int TN>
-__device__ __forceinline__ void store_tiles_global(float* __restrict__ dst, const float* __restrict__ bias, const f32x4 (&acc)[TM][TN],
+__device__ __forceinline__ void store_tiles_global(float* __restrict__ dst, const float (&bias)[TN], const f32x4 (&acc)[TM][TN],
                                                    int wave, int lane) {
     constexpr int MT = 4, MG = MT / TM;
     const int mg = wave % MG, ng = wave / MG;
@@ -257,7 +475,7 @@ __device__ __forceinline__ void store_tiles_global(float* __restrict__ dst, cons
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int ch = (ng * TN + j) * 16 + n;
-        const float bv = bias[ch];
+        const float bv = bias[j];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int p = (mg * TM + i) * 16 + 4 * g;
@@ -298,18 +516,18 @@ struct CnnArgs {
 
 template <int CB>
 struct TrunkLds {
-    static constexpr int ACT = CB * PST32;
+    static constexpr int ACT = (CB / 4) * LayC0::PSG;   // the largest layout (conv0 output); all later ones are smaller
     static constexpr int PATCH = WP32 * WP32;
-    static constexpr int W0 = 12 * 32;                  // conv0 taps + bias, 12 floats per output channel
-    static constexpr int TOTAL = ACT + PATCH + 64 + W0;
+    static constexpr int RED = 128;                     // reduction slots (block_sum)
+    static constexpr int TOTAL = ACT + PATCH + RED;
 };
 
-template <int C, int H, int PST, int NTHR>
+template <int C, typename L, int NTHR>
 __device__ __forceinline__ void dump_planes(const float* act, float* dst) {
-    constexpr int WP = H + 2;
+    constexpr int H = L::H;
     for (int i = threadIdx.x; i < C * H * H; i += NTHR) {
         const int c = i / (H * H), r = i - c * H * H, y = r / H, x = r - y * H;
-        dst[i] = act[c * PST + (y + 1) * WP + x + 1];
+        dst[i] = act[L::at(c, y, x)];
     }
 }
 
@@ -326,17 +544,28 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
     constexpr int T1M = (CB == 16) ? 8 : 64 / NW, T1N = CB / 16;
     constexpr int T2M = (CB == 16) ? 2 : 32 / NW, T2N = 2;
     constexpr int T4M = (CB == 16) ? 2 : 32 / NW, T4N = 1;
+    // plane groups (4 k-steps each) per pipeline chunk; VGPR budget 128 at 4 waves / SIMD, 256 at 2
+    constexpr int AREG = (NW == 8 && CB == 32) ? 128 : 48;
+    constexpr bool ROLL1 = (T1M * 8 > AREG);            // conv1: two A sets of T1M float4 do not fit -> rolling single set
+    constexpr int G1 = pick_groups(CB, T1M, T1N, 32, AREG), G2 = pick_groups(CB, T2M, T2N, 32, AREG);
+    constexpr int G3 = pick_groups(2 * CB, T2M, T2N, 32, AREG), G4 = pick_groups(2 * CB, T4M, T4N, 32, AREG);
+    constexpr int G5 = pick_groups(4 * CB, T4M, T4N, 32, AREG);
+    static_assert((CB / 4) * LayC1::PSG <= TrunkLds<CB>::ACT && (CB / 2) * LayC3::PSG <= TrunkLds<CB>::ACT, "LDS layout");
     __shared__ __attribute__((aligned(16))) float lds[TrunkLds<CB>::TOTAL];
     float* act = lds;
     float* patch = lds + TrunkLds<CB>::ACT;
     float* red = patch + TrunkLds<CB>::PATCH;
-    float* w0s = red + 64;                              // [CB][12]: 9 taps, bias, 2 pad (16-byte rows)
     // grid = (n_max, batch): row blockIdx.x of image blockIdx.y; global row = image * n_max + row
     const int n = a.count ? min(a.count[blockIdx.y], a.n_max) : a.n_max;
     if ((int)blockIdx.x >= n) return;
     const size_t pidx = (size_t)blockIdx.y * a.n_max + blockIdx.x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     CNN_STAMP(0);
+    // conv0 taps + bias and the first weight chunk of conv1: requested now, consumed after the input phase
+    float w0[4][T1N];
+    conv0_load_w<NW, CB, T1M, T1N>(a.packed + a.off.w[0], a.packed + a.off.b[0], w0, wave, lane);
+    f32x4 b1[ROLL1 ? 1 : G1][T1N];
+    prefetch_b0<NW, CB, 32, T1M, T1N, (ROLL1 ? 1 : G1)>(a.packed + a.off.w[1], b1, wave, lane);
 
     // ---- input: load or sample 1024 pixels (PPT per thread), standardise, store padded ----------------
     float v[PPT];
@@ -358,13 +587,13 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         for (int q = 0; q < PPT; ++q)
             v[q] = aff_sample_bilinear(img, h, w, t00, t01, t02, t10, t11, t12, ps.base[tid & 31], ps.base[(tid >> 5) + q * RPT]);
     }
-    for (int i = tid; i < WP32 * WP32; i += NTHR) patch[i] = 0.0f;   // halo (interior overwritten below)
-    // conv0 taps + bias -> LDS once per workgroup (as uniform scalar loads inside the channel loop they cost
-    // 21-34k cycles per patch: a chain of dependent L2 round trips)
-    for (int i = tid; i < CB * 12; i += NTHR) {
-        const int c = i / 12, t = i - c * 12;
-        w0s[i] = t < 9 ? a.packed[a.off.w[0] + c * 9 + t] : (t == 9 ? a.packed[a.off.b[0] + c] : 0.0f);
+    // halo of the padded patch (4 x 33 cells) and of the CB activation planes; interiors are written below / by conv0
+    if (tid < 4 * 33) {
+        const int e = tid;
+        const int y = e < 34 ? 0 : (e < 68 ? 33 : 1 + ((e - 68) >> 1)), x = e < 34 ? e : (e < 68 ? e - 34 : ((e - 68) & 1) * 33);
+        patch[y * WP32 + x] = 0.0f;
     }
+    zero_halo<LayC0, NTHR>(act, CB);
     float sum = 0.f;
 #pragma unroll
     for (int q = 0; q < PPT; ++q) sum += v[q];
@@ -372,108 +601,112 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
     float sq = 0.f;
 #pragma unroll
     for (int q = 0; q < PPT; ++q) { v[q] -= mean; sq += v[q] * v[q]; }
-    const float var = block_sum<NW>(sq, red) * (1.0f / 1023.0f);       // torch.std: unbiased
+    const float var = block_sum<NW>(sq, red + NW) * (1.0f / 1023.0f);       // torch.std: unbiased
     const float sd = sqrtf(var) + 1e-7f;
 #pragma unroll
     for (int q = 0; q < PPT; ++q) patch[((tid >> 5) + q * RPT + 1) * WP32 + (tid & 31) + 1] = v[q] / sd;
-    zero_halo<32, PST32, NTHR>(act, CB);
     __syncthreads();
     CNN_STAMP(1);
 
-    // ---- conv0: 1 -> CB, K = 9, VALU ---------------------------------------------------------------
-    {
-        float q[PPT][9];
-#pragma unroll
-        for (int qq = 0; qq < PPT; ++qq) {
-            const int y = (tid >> 5) + qq * RPT, x = tid & 31;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) q[qq][t] = patch[(y + t / 3) * WP32 + x + t % 3];
-        }
-#pragma unroll 4
-        for (int c = 0; c < CB; ++c) {
-            const float4 wa = *reinterpret_cast<const float4*>(&w0s[c * 12]);        // broadcast reads
-            const float4 wb = *reinterpret_cast<const float4*>(&w0s[c * 12 + 4]);
-            const float4 wc = *reinterpret_cast<const float4*>(&w0s[c * 12 + 8]);
-            const float wt[9] = {wa.x, wa.y, wa.z, wa.w, wb.x, wb.y, wb.z, wb.w, wc.x};
-#pragma unroll
-            for (int qq = 0; qq < PPT; ++qq) {
-                const int y = (tid >> 5) + qq * RPT, x = tid & 31;
-                float sacc = wc.y;                                                   // bias
-#pragma unroll
-                for (int t = 0; t < 9; ++t) sacc = fmaf(q[qq][t], wt[t], sacc);
-                act[c * PST32 + (y + 1) * WP32 + x + 1] = fmaxf(sacc, 0.0f);
-            }
-        }
-    }
-    __syncthreads();
-    if (a.dbg_layer == 0) { dump_planes<CB, 32, PST32, NTHR>(act, a.dbg_out); return; }
-    CNN_STAMP(2);
-
-    // ---- conv1: CB -> CB @32x32 --------------------------------------------------------------------
+    // ---- conv0: 1 -> CB, K = 9 (padded to 12), MFMA; reads `patch`, writes `act`: no barrier in between ----
+    float bias1[T1N];
     {
         f32x4 acc[T1M][T1N];
-        conv3x3_mfma<NW, CB, CB, 32, 1, T1M, T1N, PST32, WP32, 4>(act, a.packed + a.off.w[1], acc, wave, lane);
+        conv0_mfma<NW, CB, T1M, T1N>(patch, w0, acc, wave, lane);
+        prefetch_bias<NW, 32, T1M, T1N>(a.packed + a.off.b[1], bias1, wave, lane);
+        const float nob[T1N] = {};
+        store_tiles_lds<CB, LayC0, T1M, T1N, false>(act, nob, acc, wave, lane);
+    }
+    __syncthreads();
+    if (a.dbg_layer == 0) { dump_planes<CB, LayC0, NTHR>(act, a.dbg_out); return; }
+    CNN_STAMP(2);
+
+    // Every layer: MFMA loop -> request the next layer's first weight chunk and bias -> barrier (all waves done reading
+    // the input) -> zero the halo of the OUTPUT layout, bias + ReLU + store in place -> barrier.
+    // ---- conv1: CB -> CB @32x32 --------------------------------------------------------------------
+    f32x4 b2[G2][T2N];
+    float bias2[T2N];
+    {
+        f32x4 acc[T1M][T1N];
+        if (ROLL1) conv3x3_mfma_roll<NW, CB, CB, LayC0, 1, T1M, T1N>(act, a.packed + a.off.w[1], reinterpret_cast<const f32x4 (&)[1][T1N]>(b1), acc, wave, lane);
+        else conv3x3_mfma<NW, CB, CB, LayC0, 1, T1M, T1N, G1>(act, a.packed + a.off.w[1], reinterpret_cast<const f32x4 (&)[G1][T1N]>(b1), acc, wave, lane);
         CNN_STAMP(3);
+        prefetch_b0<NW, 2 * CB, 16, T2M, T2N, G2>(a.packed + a.off.w[2], b2, wave, lane);
+        prefetch_bias<NW, 16, T2M, T2N>(a.packed + a.off.b[2], bias2, wave, lane);
         __syncthreads();
-        store_tiles_lds<CB, 32, T1M, T1N, PST32>(act, a.packed + a.off.b[1], acc, wave, lane);   // halo already zero
+        zero_halo<LayC1, NTHR>(act, CB);
+        store_tiles_lds<CB, LayC1, T1M, T1N>(act, bias1, acc, wave, lane);
         __syncthreads();
         CNN_STAMP(4);
     }
-    if (a.dbg_layer == 1) { dump_planes<CB, 32, PST32, NTHR>(act, a.dbg_out); return; }
+    if (a.dbg_layer == 1) { dump_planes<CB, LayC1, NTHR>(act, a.dbg_out); return; }
 
     // ---- conv2: CB -> 2CB, stride 2 @16x16 -----------------------------------------------------------
+    f32x4 b3[G3][T2N];
+    float bias3[T2N];
     {
         f32x4 acc[T2M][T2N];
-        conv3x3_mfma<NW, CB, 2 * CB, 16, 2, T2M, T2N, PST32, WP32, 4>(act, a.packed + a.off.w[2], acc, wave, lane);
+        conv3x3_mfma<NW, CB, 2 * CB, LayC1, 2, T2M, T2N, G2>(act, a.packed + a.off.w[2], b2, acc, wave, lane);
         CNN_STAMP(5);
+        prefetch_b0<NW, 2 * CB, 16, T2M, T2N, G3>(a.packed + a.off.w[3], b3, wave, lane);
+        prefetch_bias<NW, 16, T2M, T2N>(a.packed + a.off.b[3], bias3, wave, lane);
         __syncthreads();
-        zero_halo<16, PST16, NTHR>(act, 2 * CB);
-        store_tiles_lds<2 * CB, 16, T2M, T2N, PST16>(act, a.packed + a.off.b[2], acc, wave, lane);
+        zero_halo<LayC2, NTHR>(act, 2 * CB);
+        store_tiles_lds<2 * CB, LayC2, T2M, T2N>(act, bias2, acc, wave, lane);
         __syncthreads();
         CNN_STAMP(6);
     }
-    if (a.dbg_layer == 2) { dump_planes<2 * CB, 16, PST16, NTHR>(act, a.dbg_out); return; }
+    if (a.dbg_layer == 2) { dump_planes<2 * CB, LayC2, NTHR>(act, a.dbg_out); return; }
 
     // ---- conv3: 2CB -> 2CB @16x16 --------------------------------------------------------------------
+    f32x4 b4[G4][T4N];
+    float bias4[T4N];
     {
         f32x4 acc[T2M][T2N];
-        conv3x3_mfma<NW, 2 * CB, 2 * CB, 16, 1, T2M, T2N, PST16, WP16, 8>(act, a.packed + a.off.w[3], acc, wave, lane);
+        conv3x3_mfma<NW, 2 * CB, 2 * CB, LayC2, 1, T2M, T2N, G3>(act, a.packed + a.off.w[3], b3, acc, wave, lane);
         CNN_STAMP(7);
+        prefetch_b0<NW, 4 * CB, 8, T4M, T4N, G4>(a.packed + a.off.w[4], b4, wave, lane);
+        prefetch_bias<NW, 8, T4M, T4N>(a.packed + a.off.b[4], bias4, wave, lane);
         __syncthreads();
-        store_tiles_lds<2 * CB, 16, T2M, T2N, PST16>(act, a.packed + a.off.b[3], acc, wave, lane);
+        zero_halo<LayC3, NTHR>(act, 2 * CB);
+        store_tiles_lds<2 * CB, LayC3, T2M, T2N>(act, bias3, acc, wave, lane);
         __syncthreads();
         CNN_STAMP(8);
     }
-    if (a.dbg_layer == 3) { dump_planes<2 * CB, 16, PST16, NTHR>(act, a.dbg_out); return; }
+    if (a.dbg_layer == 3) { dump_planes<2 * CB, LayC3, NTHR>(act, a.dbg_out); return; }
 
     // ---- conv4: 2CB -> 4CB, stride 2 @8x8 --------------------------------------------------------------
+    f32x4 b5[G5][T4N];
+    float bias5[T4N];
     {
         f32x4 acc[T4M][T4N];
-        conv3x3_mfma<NW, 2 * CB, 4 * CB, 8, 2, T4M, T4N, PST16, WP16, 8>(act, a.packed + a.off.w[4], acc, wave, lane);
+        conv3x3_mfma<NW, 2 * CB, 4 * CB, LayC3, 2, T4M, T4N, G4>(act, a.packed + a.off.w[4], b4, acc, wave, lane);
         CNN_STAMP(9);
+        prefetch_b0<NW, 4 * CB, 8, T4M, T4N, G5>(a.packed + a.off.w[5], b5, wave, lane);
+        prefetch_bias<NW, 8, T4M, T4N>(a.packed + a.off.b[5], bias5, wave, lane);
         __syncthreads();
-        zero_halo<8, PST8, NTHR>(act, 4 * CB);
-        store_tiles_lds<4 * CB, 8, T4M, T4N, PST8>(act, a.packed + a.off.b[4], acc, wave, lane);
+        zero_halo<LayC4, NTHR>(act, 4 * CB);
+        store_tiles_lds<4 * CB, LayC4, T4M, T4N>(act, bias4, acc, wave, lane);
         __syncthreads();
         CNN_STAMP(10);
     }
-    if (a.dbg_layer == 4) { dump_planes<4 * CB, 8, PST8, NTHR>(act, a.dbg_out); return; }
+    if (a.dbg_layer == 4) { dump_planes<4 * CB, LayC4, NTHR>(act, a.dbg_out); return; }
 
     // ---- conv5: 4CB -> 4CB @8x8 ------------------------------------------------------------------------
     {
         f32x4 acc[T4M][T4N];
-        conv3x3_mfma<NW, 4 * CB, 4 * CB, 8, 1, T4M, T4N, PST8, WP8, 8>(act, a.packed + a.off.w[5], acc, wave, lane);
+        conv3x3_mfma<NW, 4 * CB, 4 * CB, LayC4, 1, T4M, T4N, G5>(act, a.packed + a.off.w[5], b5, acc, wave, lane);
         CNN_STAMP(11);
         if (KIND == AFFNET_NET_HARDNET && a.dbg_layer < 0) {
-            store_tiles_global<4 * CB, T4M, T4N>(a.out + pidx * HEAD_K, a.packed + a.off.b[5], acc, wave, lane);
+            store_tiles_global<4 * CB, T4M, T4N>(a.out + pidx * HEAD_K, bias5, acc, wave, lane);
             return;
         }
         __syncthreads();
-        store_tiles_lds<4 * CB, 8, T4M, T4N, PST8>(act, a.packed + a.off.b[5], acc, wave, lane);
+        store_tiles_lds<4 * CB, LayC5, T4M, T4N>(act, bias5, acc, wave, lane);   // same layout: halo stays zero
         __syncthreads();
         CNN_STAMP(12);
     }
-    if (a.dbg_layer == 5) { dump_planes<4 * CB, 8, PST8, NTHR>(act, a.dbg_out); return; }
+    if (a.dbg_layer == 5) { dump_planes<4 * CB, LayC5, NTHR>(act, a.dbg_out); return; }
 
     // ---- heads (AffNet / OriNet), VALU -----------------------------------------------------------------
     if (KIND == AFFNET_NET_AFFNET) {
@@ -483,10 +716,10 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
 #pragma unroll
         for (int e = tid; e < 4096; e += NTHR) {
             const int c = e >> 6, y = (e >> 3) & 7, x = e & 7;
-            const float vv = act[c * PST8 + (y + 1) * WP8 + x + 1];
+            const float vv = act[LayC5::at(c, y, x)];
             s0 = fmaf(vv, hw[e], s0); s1 = fmaf(vv, hw[4096 + e], s1); s2 = fmaf(vv, hw[8192 + e], s2);
         }
-        s0 = block_sum<NW>(s0, red); s1 = block_sum<NW>(s1, red); s2 = block_sum<NW>(s2, red);
+        s0 = block_sum<NW>(s0, red + 2 * NW); s1 = block_sum<NW>(s1, red + 3 * NW); s2 = block_sum<NW>(s2, red + 4 * NW);
         if (tid == 0) {
             const float* hb = a.packed + a.off.head_b;
             const float x0 = tanhf(s0 + hb[0]), x1 = tanhf(s1 + hb[1]), x2 = tanhf(s2 + hb[2]);
@@ -511,7 +744,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
             const float w0 = hw[e], w1 = hw[4096 + e];
 #pragma unroll
             for (int q = 0; q < 9; ++q) {
-                const float vv = act[c * PST8 + (q / 3 + ky) * WP8 + (q % 3) + kx];
+                const float vv = act[LayC5::at(c, q / 3 + ky - 1, (q % 3) + kx - 1)];
                 s[0][q] = fmaf(vv, w0, s[0][q]); s[1][q] = fmaf(vv, w1, s[1][q]);
             }
         }

@@ -84,15 +84,18 @@ def _unpack_trunk(kind, blob):
     off, layers = 0, []
     for i in range(6):
         ci, co = ch[i], ch[i + 1]
-        w = blob[off:off + 9 * ci * co]
-        off += 9 * ci * co
+        kk = 12 if i == 0 else 9 * ci        # conv0: K = 9 taps zero-padded to 12 (three 16x16x4 MFMA k-steps)
+        w = blob[off:off + kk * co]
+        off += kk * co
         b = blob[off:off + co]
         off += co
         off = (off + 3) & ~3
         if i == 0:
-            W = w.view(co, 1, 3, 3)
+            assert float(w.view(12, co)[9:].abs().max()) == 0.0
+            W = w.view(12, co)[:9].t().reshape(co, 1, 3, 3)
         else:
-            W = w.view(9, ci, co).permute(2, 1, 0).reshape(co, ci, 3, 3)
+            # [tap][G = c/16][kq = (c/4)%4][n][j = c%4]  (channel-interleaved by 4: one dwordx4 / ds_read_b128 = 4 k-steps)
+            W = w.view(9, ci // 16, 4, co, 4).permute(3, 1, 2, 4, 0).reshape(co, ci, 3, 3)
         layers.append((W.contiguous(), b.clone()))
     return layers, off
 

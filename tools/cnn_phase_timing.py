@@ -16,7 +16,7 @@ A = affnet_amd.AffNetFast(); A.load_state_dict(torch.load(os.path.join(ROOT, "pr
 H = affnet_amd.HardNet(); H.load_state_dict(affnet_amd.synthetic_hardnet_state(0)); H.to(dev)
 names = ["input+norm", "conv0", "conv1 mfma", "conv1 store", "conv2 mfma", "conv2 store", "conv3 mfma", "conv3 store",
          "conv4 mfma", "conv4 store", "conv5 mfma", "conv5 store"]
-for net, nm, nw in [(A, "AffNet", 8), (H, "HardNet", int(os.environ.get("AFFNET_HARDNET_WAVES", "16")))]:
+for net, nm, nw in [(A, "AffNet", 8), (H, "HardNet", int(os.environ.get("AFFNET_HARDNET_WAVES", "8")))]:
     net(p); torch.cuda.synchronize()
     st = torch.zeros(n * nw * 16, dtype=torch.int64, device=dev)
     lib.affnet_cnn32_debug_timing(ptr(st))
@@ -28,6 +28,8 @@ for net, nm, nw in [(A, "AffNet", 8), (H, "HardNet", int(os.environ.get("AFFNET_
     wg = t[:, :, :nst].max(axis=1) - t[:, :, 0:1].min(axis=1)   # per patch: boundary times relative to WG start
     print("== %s (%d waves): mean phase cycles per wave (s_memtime ticks, 100 MHz const clock?)" % (nm, nw))
     tot = (t[:, :, nst - 1].max(axis=1) - t[:, :, 0].min(axis=1)).mean()
+    span = (t[:, :, nst - 1].max() - t[:, :, 0].min())
+    print("  kernel span %.0f ticks for %d patches -> %.0f ticks / patch / CU-slot (256 CUs)" % (span, n, span / (n / 256.0)))
     for i in range(nst - 1):
         print("  %-12s mean %9.0f  max-over-waves %9.0f" % (names[i], d[:, :, i].mean(), d[:, :, i].max(axis=1).mean()))
     print("  total per patch (WG) %.0f ticks" % tot)
