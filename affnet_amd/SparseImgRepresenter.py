@@ -73,14 +73,16 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
     def _native(slot):
         return slot is None or isinstance(slot, _HipPatchNet)
 
-    def enqueue(self, x, do_ori=False, desc=None, det_stream=None):
+    def enqueue(self, x, do_ori=False, desc=None, det_stream=None, input_ready=None):
         """Enqueues the whole fused path and returns capacity-sized device tensors plus the device row
         counts - no host synchronisation (throughput use).  x may be a (B,1,H,W) batch of equally sized
         images (BASELINE configs[2]; the reference loops over images in Python): every kernel launch then
         covers the B images, results get a leading batch dimension and `count` is (B,).  With `det_stream` (a torch.cuda.Stream) the
         pyramid + detector run there and the CNN stages on the current stream, ordered by events, so that
         two extractor objects alternating over a stream of images overlap the latency-bound detector of
-        image i+1 with the MFMA-bound CNN stages of image i."""
+        image i+1 with the MFMA-bound CNN stages of image i.  `input_ready`: None = the detector stream first waits for
+        everything enqueued so far on the current stream (safe default: x may still be in flight there); a
+        torch.cuda.Event = wait for that event only; False = x is already resident (no wait)."""
         ctx = self._context(x, allow_batch=True)
         dev = x.device
         if do_ori and self.OriNet is None:
@@ -104,7 +106,10 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
             check(rc, ctx.handle, "affnet_extract_features")
         else:
             cur = torch.cuda.current_stream(dev)
-            det_stream.wait_stream(cur)                      # image upload / previous users of x
+            if input_ready is None:
+                det_stream.wait_stream(cur)                  # image upload / previous users of x
+            elif input_ready is not False:
+                det_stream.wait_event(input_ready)
             if getattr(self, "_busy", None) is not None:
                 det_stream.wait_event(self._busy)            # workspace still read by the previous describe
             rc = lib.affnet_detect_image(ctx.handle, ptr(img), C.c_void_p(det_stream.cuda_stream))

@@ -37,6 +37,23 @@ FLOP_HARD_HEAD = 2.0 * 8192 * 128
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
 
 
+def pmc_traffic(images_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
+    in separate passes, tools/gpu_full.sh + tools/pmc_traffic.py; counters cannot be read from inside this process)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json")))
+    if not files:
+        return None, None
+    d = json.load(open(files[-1]))
+    k = d["kernels"].get("void cnn32_trunk_kernel<2, 8>")
+    if not k:
+        return None, None
+    scale = images_per_launch / float(d["images_per_launch"])
+    note = ("%s: 2 x FETCH_SIZE (gfx950 correction for wide reads; the sampler's narrow gathers are uncalibrated, raw = %.3g B) "
+            "+ WRITE_SIZE, scaled to %d images per launch" % (os.path.basename(files[-1]), k["fetch_bytes_raw"] * scale, images_per_launch))
+    return k["hbm_bytes"] * scale, note
+
+
 def cpu_baseline(n_timed=2):
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import affnet_oracle as orc
@@ -71,6 +88,9 @@ def main():
                     help="images per fused library call (every kernel launch covers `chunk` images)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("AFFNET_BENCH_STREAMS", "1")),
                     help="independent streams (each with its own context) the chunks alternate over")
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("AFFNET_BENCH_PIPELINE", "1")),
+                    help="1 (with --streams 1): pyramid + detector of chunk i+1 run on a second stream next to the CNN stages of "
+                         "chunk i (two contexts alternate); the CNN kernels stay serialised on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -104,6 +124,9 @@ def main():
     imgs = torch.cat([synthetic_image(H, W, s) for s in seeds], 0).to(dev)           # (batch,1,H,W) resident in HBM
     chunks = [imgs[i:i + CH] for i in range(0, args.batch, CH)]
     S = max(1, args.streams)
+    PIPE = bool(args.pipeline) and S == 1
+    if PIPE:
+        S = 2                          # two contexts alternate; ONE CNN stream + ONE detector stream
     # one extractor (context + workspace) per (stream, chunk size); a ragged last chunk gets its own
     dets = {}
     for ci, c in enumerate(chunks):
@@ -113,12 +136,13 @@ def main():
                                                                 AffNet=A, OriNet=O).to(dev)
             dets[k]._context(c, allow_batch=True)  # create contexts / workspaces before anything is timed
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
+    det_stream = torch.cuda.Stream(device=dev) if PIPE else None
 
     def step():
         results = [None] * len(chunks)
         for ci, c in enumerate(chunks):
-            with torch.cuda.stream(streams[ci % S]):
-                results[ci] = dets[(ci % S, c.size(0))].enqueue(c, do_ori=True, desc=Hn)
+            with torch.cuda.stream(streams[0] if PIPE else streams[ci % S]):
+                results[ci] = dets[(ci % S, c.size(0))].enqueue(c, do_ori=True, desc=Hn, det_stream=det_stream, input_ready=False)
         for s in streams:
             s.synchronize()
         if world > 1:
@@ -166,6 +190,7 @@ def main():
         kp_per_img = kps / max(1, args.steps * args.batch * world)
         flops_launch = kp_per_img * img_per_launch * (FLOP_HARD - FLOP_HARD_HEAD)
         achieved = flops_launch / (trunk_ms * 1e-3) / 1e12 if trunk_ms > 0 else 0.0
+        traffic, traffic_note = pmc_traffic(img_per_launch)
         out = {
             "metric": "keypoints/sec (detect+AffNet+OriNet+HardNet) per image, 2000 kp @1024x768",
             "value": kps / tmax, "unit": "keypoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -175,13 +200,14 @@ def main():
                                    "2000 kp each, full path detect+AffNet+OriNet+HardNet; AffNet/OriNet shipped weights, "
                                    "HardNet seeded synthetic weights (HardNet++.pth is a missing blob)" % args.batch,
                        "global_batch": args.batch * world, "keypoints_per_image": kp_per_img,
-                       "images_per_launch": CH, "streams_per_gpu": S,
+                       "images_per_launch": CH,
+                       "streams_per_gpu": "1 CNN stream + 1 detector stream (2 contexts alternate)" if PIPE else S,
                        "parallelism": "image-per-GPU x%d, all_gather of padded records" % world if world > 1 else "1 GPU"},
             "ms_per_image": tmax / (args.steps * args.batch) * 1e3,
             "stage_ms_per_image": dict(zip(names, [round(v, 4) for v in stage_ms])),
             "roofline": {"kernel": "cnn32_trunk_kernel<HardNet> (fp32 MFMA 16x16x4, fused sampler+norm+6 convs)", "bound": "mfma",
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
-                         "traffic": None, "flops_per_launch": flops_launch, "launch_ms": trunk_ms,
+                         "traffic": traffic, "traffic_source": traffic_note, "flops_per_launch": flops_launch, "launch_ms": trunk_ms,
                          "all_cnn_tflops": kp_per_img * (1.5 * FLOP_AFF + FLOP_ORI + FLOP_HARD) /
                                            (max(stage_ms[2] + stage_ms[4] + stage_ms[6] + stage_ms[7], 1e-9) * 1e-3) / 1e12},
         }
