@@ -44,6 +44,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 //                    H = 32/16: PSG == 0 (mod 64);  H = 8 (a tile = 2 rows): WP = 16, PSG == 32 (mod 64);
 //   stride-2 reader: pixels 2 apart hit banks == 0..3 (mod 8) -> PSG == 4 (mod 8) (and WP == 0 (mod 8) when a tile
 //                    spans two output rows, 16 -> 8) - these also make the epilogue's ds_write_b32 conflict free.
+//
+// Operand roles: the WEIGHTS are the MFMA "A" operand (rows = 16 output channels) and the ACTIVATIONS the "B" operand
+// (columns = 16 pixels), i.e. each 16x16 tile is out^T[channel][pixel].  A lane then owns FOUR CONSECUTIVE CHANNELS of one
+// pixel (rows 4g..4g+3 of column lane&15) = exactly one float4 of the interleaved layout, so the epilogue is one
+// conflict-free ds_write_b128 per tile instead of four 4-way-conflicting ds_write_b32.
 template <int H_, int WP_, int PSG_>
 struct Lay {
     static constexpr int H = H_, WP = WP_, PSG = PSG_;
@@ -116,7 +121,9 @@ extern "C" int affnet_cnn32_pack_weights(int kind, const float* const* conv_w, c
         for (int n = 0; n < 128; ++n) {
             const float s = 1.0f / sqrtf(head_bn_var[n] + 1e-5f);
             out[L.head_b + n] = -head_bn_mean[n] * s;
-            for (int k = 0; k < HEAD_K; ++k) out[L.head_w + (size_t)k * 128 + n] = head_w[(size_t)n * HEAD_K + k] * s;
+            // K order of the head GEMM = the trunk kernel's output order [pixel p][channel c] (float4 = 4 channels)
+            for (int c = 0; c < 128; ++c)
+                for (int pp = 0; pp < 64; ++pp) out[L.head_w + ((size_t)pp * 128 + c) * 128 + n] = head_w[(size_t)n * HEAD_K + c * 64 + pp] * s;
         }
     } else {
         const int no = kind == AFFNET_NET_AFFNET ? 3 : 2;
@@ -217,11 +224,11 @@ __device__ __forceinline__ void prefetch_b0(const float* __restrict__ Wg, f32x4 
         for (int j = 0; j < TN; ++j) b0[u][j] = *reinterpret_cast<const f32x4*>(&Wg[u * 16 * COUT + (kq * COUT + (ng * TN + j) * 16 + m) * 4]);
 }
 template <int NW, int HOUT, int TM, int TN>
-__device__ __forceinline__ void prefetch_bias(const float* __restrict__ bias, float (&bv)[TN], int wave, int lane) {
+__device__ __forceinline__ void prefetch_bias(const float* __restrict__ bias, f32x4 (&bv)[TN], int wave, int lane) {
     constexpr int MG = (HOUT * HOUT / 16) / TM;
     const int ng = wave / MG;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) bv[j] = bias[(ng * TN + j) * 16 + (lane & 15)];
+    for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const f32x4*>(&bias[(ng * TN + j) * 16 + 4 * (lane >> 4)]);   // channels 4g..4g+3
 }
 
 template <int NW, int CIN, int COUT, typename LI, int STRIDE, int TM, int TN, int GRP>
@@ -275,7 +282,7 @@ __device__ __forceinline__ void conv3x3_mfma(const float* act, const float* __re
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.a[u][i][s4], f.b[u][j][s4], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.b[u][j][s4], f.a[u][i][s4], acc[i][j], 0, 0, 0);   // W^T x act
     };
     // compute the chunk held in `cur` while loading chunk `nxt_ch` into `nxt`
     auto stage = [&](const Frag<GRP, TM, TN>& cur, Frag<GRP, TM, TN>& nxt, int nxt_ch) {
@@ -370,7 +377,7 @@ __device__ __forceinline__ void conv3x3_mfma_roll(const float* act, const float*
                 for (int i = ip; i < ip + 2; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][s4], bc[j][s4], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bc[j][s4], fa[i][s4], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = ip; i < ip + 2; ++i) fa[i] = *reinterpret_cast<const f32x4*>(&act[a_off + a_base[i]]);
@@ -387,7 +394,7 @@ __device__ __forceinline__ void conv3x3_mfma_roll(const float* act, const float*
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i][s4], fb0[j][s4], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb0[j][s4], fa[i][s4], acc[i][j], 0, 0, 0);
     }
 }
 
@@ -396,8 +403,8 @@ __device__ __forceinline__ void conv3x3_mfma_roll(const float* act, const float*
 // is the fmaf chain bias, tap 0, ..., tap 8 (+ three exact fma(x, 0, acc)).  3 MFMAs per tile instead of 9 * COUT VALU
 // FMAs per pixel behind dependent LDS weight reads.
 template <int NW, int COUT, int TM, int TN>
-__device__ __forceinline__ void conv0_load_w(const float* __restrict__ W0, const float* __restrict__ bias, float (&b)[4][TN], int wave,
-                                             int lane) {
+__device__ __forceinline__ void conv0_load_w(const float* __restrict__ W0, const float* __restrict__ bias, float (&b)[3][TN],
+                                             f32x4 (&bv)[TN], int wave, int lane) {
     constexpr int MG = 64 / TM;
     const int ng = wave / MG, m = lane & 15, kq = lane >> 4;
 #pragma unroll
@@ -405,12 +412,13 @@ __device__ __forceinline__ void conv0_load_w(const float* __restrict__ W0, const
         const int n = (ng * TN + j) * 16 + m;
 #pragma unroll
         for (int s3 = 0; s3 < 3; ++s3) b[s3][j] = W0[(4 * s3 + kq) * COUT + n];
-        b[3][j] = bias[n];
+        bv[j] = *reinterpret_cast<const f32x4*>(&bias[(ng * TN + j) * 16 + 4 * kq]);     // accumulator rows 4g..4g+3 = channels
     }
 }
 
 template <int NW, int COUT, int TM, int TN>
-__device__ __forceinline__ void conv0_mfma(const float* patch, const float (&b)[4][TN], f32x4 (&acc)[TM][TN], int wave, int lane) {
+__device__ __forceinline__ void conv0_mfma(const float* patch, const float (&b)[3][TN], const f32x4 (&bv)[TN], f32x4 (&acc)[TM][TN],
+                                           int wave, int lane) {
     constexpr int MT = 64, NT = COUT / 16, MG = MT / TM, NG = NT / TN;
     static_assert(MG * NG == NW, "the waves must tile the layer exactly");
     const int mg = wave % MG;
@@ -422,11 +430,9 @@ __device__ __forceinline__ void conv0_mfma(const float* patch, const float (&b)[
         toff[s3] = t < 9 ? (t / 3) * WP32 + (t % 3) : 0;            // taps 9..11: any valid address (weight is zero)
     }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const float bv = b[3][j];
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][j] = (f32x4){bv, bv, bv, bv};
-    }
+        for (int i = 0; i < TM; ++i) acc[i][j] = bv[j];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int p = (mg * TM + i) * 16 + m;
@@ -437,52 +443,48 @@ __device__ __forceinline__ void conv0_mfma(const float* patch, const float (&b)[
 #pragma unroll
         for (int s3 = 0; s3 < 3; ++s3)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s3], b[s3][j], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s3][j], av[s3], acc[i][j], 0, 0, 0);
     }
 }
 
-// Epilogue: (+ bias,) ReLU, write the wave's tiles into the LDS layout LO read by the NEXT layer.
+// Epilogue: (+ bias,) ReLU, write the wave's tiles into the LDS layout LO read by the NEXT layer: lane (n = pixel of the
+// tile, g) holds channels 4g..4g+3 -> one float4 of plane group (N-tile * 4 + g).
 template <int COUT, typename LO, int TM, int TN, bool ADD_BIAS = true>
-__device__ __forceinline__ void store_tiles_lds(float* act, const float (&bias)[TN], const f32x4 (&acc)[TM][TN], int wave, int lane) {
+__device__ __forceinline__ void store_tiles_lds(float* act, const f32x4 (&bias)[TN], const f32x4 (&acc)[TM][TN], int wave, int lane) {
     constexpr int HOUT = LO::H;
     constexpr int MT = HOUT * HOUT / 16, MG = MT / TM;
     const int mg = wave % MG, ng = wave / MG;
     const int n = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int ch = (ng * TN + j) * 16 + n;
-        const float bv = ADD_BIAS ? bias[j] : 0.0f;
-        const int cbase = (ch >> 2) * LO::PSG + (ch & 3);
+    for (int i = 0; i < TM; ++i) {
+        const int p = (mg * TM + i) * 16 + n;
+        const int oy = p / HOUT, ox = p - oy * HOUT;
+        const int pbase = ((oy + 1) * LO::WP + ox + 1) * 4;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int p = (mg * TM + i) * 16 + 4 * g + r;
-                const int oy = p / HOUT, ox = p - oy * HOUT;
-                act[cbase + ((oy + 1) * LO::WP + ox + 1) * 4] = fmaxf(ADD_BIAS ? acc[i][j][r] + bv : acc[i][j][r], 0.0f);
-            }
+        for (int j = 0; j < TN; ++j) {
+            f32x4 v = acc[i][j];
+            if (ADD_BIAS) v += bias[j];
+            v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+            *reinterpret_cast<f32x4*>(&act[((ng * TN + j) * 4 + g) * LO::PSG + pbase]) = v;
         }
     }
 }
 
-// Same for the last trunk layer of HardNet: [c][8][8] flattened = the head GEMM's K order.
+// Same for the last trunk layer of HardNet: global [pixel p][channel c] = the head GEMM's K order (float4 = 4 channels).
 template <int COUT, int TM, int TN>
-__device__ __forceinline__ void store_tiles_global(float* __restrict__ dst, const float (&bias)[TN], const f32x4 (&acc)[TM][TN],
+__device__ __forceinline__ void store_tiles_global(float* __restrict__ dst, const f32x4 (&bias)[TN], const f32x4 (&acc)[TM][TN],
                                                    int wave, int lane) {
     constexpr int MT = 4, MG = MT / TM;
     const int mg = wave % MG, ng = wave / MG;
     const int n = lane & 15, g = lane >> 4;
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int ch = (ng * TN + j) * 16 + n;
-        const float bv = bias[j];
+    for (int i = 0; i < TM; ++i) {
+        const int p = (mg * TM + i) * 16 + n;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int p = (mg * TM + i) * 16 + 4 * g;
-            float4 v;
-            v.x = fmaxf(acc[i][j][0] + bv, 0.f); v.y = fmaxf(acc[i][j][1] + bv, 0.f);
-            v.z = fmaxf(acc[i][j][2] + bv, 0.f); v.w = fmaxf(acc[i][j][3] + bv, 0.f);
-            *reinterpret_cast<float4*>(dst + ch * 64 + p) = v;
+        for (int j = 0; j < TN; ++j) {
+            f32x4 v = acc[i][j] + bias[j];
+            v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+            *reinterpret_cast<f32x4*>(dst + p * COUT + (ng * TN + j) * 16 + 4 * g) = v;
         }
     }
 }
@@ -506,12 +508,12 @@ struct CnnArgs {
     float* out;            // AffNet/OriNet: (n,2,2); HardNet: trunk output (n,8192)
     int dbg_layer;         // >= 0: dump activations after this trunk layer of patch 0 and exit
     float* dbg_out;
-    unsigned long long* dbg_time;   // != NULL: s_memtime stamps [patch][wave][16] at the phase boundaries (tuning aid)
+    unsigned long long* dbg_time;   // != NULL: s_memtime stamps [patch][wave][32] at the phase boundaries (tuning aid)
 };
 
 #define CNN_STAMP(k)                                                                                     \
     do {                                                                                                 \
-        if (a.dbg_time && lane == 0) a.dbg_time[((size_t)pidx * NW + wave) * 16 + (k)] = __builtin_readcyclecounter(); \
+        if (a.dbg_time && lane == 0) a.dbg_time[((size_t)pidx * NW + wave) * 32 + (k)] = __builtin_readcyclecounter(); \
     } while (0)
 
 template <int CB>
@@ -560,10 +562,22 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
     if ((int)blockIdx.x >= n) return;
     const size_t pidx = (size_t)blockIdx.y * a.n_max + blockIdx.x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // Issue priority (HardNet only, one workgroup per CU): the short latency-bound phases (input, conv0, epilogues) run at
+    // priority 3, the MFMA loops at 0: +2% (130 -> 133 TFLOP/s).  For AffNet / OriNet (two workgroups per CU) it is
+    // zero-sum: the non-MFMA phases of one workgroup get 2x faster (with equal priorities the arbiter prefers the OLDER
+    // waves, so a young workgroup next to an older one in its MFMA loop crawls: 3.7k vs 0.5k cycles per block reduction),
+    // but their VALU instructions then displace the other workgroup's MFMA issue slots (-5% overall), so it stays off.
+    constexpr bool PRIO = (KIND == AFFNET_NET_HARDNET);
+    if (PRIO) __builtin_amdgcn_s_setprio(3);
     CNN_STAMP(0);
+    if (a.dbg_time && lane == 0) {      // where this workgroup runs (tuning aid: per-CU timelines)
+        a.dbg_time[((size_t)pidx * NW + wave) * 32 + 14] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
+        a.dbg_time[((size_t)pidx * NW + wave) * 32 + 15] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
+    }
     // conv0 taps + bias and the first weight chunk of conv1: requested now, consumed after the input phase
-    float w0[4][T1N];
-    conv0_load_w<NW, CB, T1M, T1N>(a.packed + a.off.w[0], a.packed + a.off.b[0], w0, wave, lane);
+    float w0[3][T1N];
+    f32x4 bias0[T1N];
+    conv0_load_w<NW, CB, T1M, T1N>(a.packed + a.off.w[0], a.packed + a.off.b[0], w0, bias0, wave, lane);
     f32x4 b1[ROLL1 ? 1 : G1][T1N];
     prefetch_b0<NW, CB, 32, T1M, T1N, (ROLL1 ? 1 : G1)>(a.packed + a.off.w[1], b1, wave, lane);
 
@@ -587,6 +601,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         for (int q = 0; q < PPT; ++q)
             v[q] = aff_sample_bilinear(img, h, w, t00, t01, t02, t10, t11, t12, ps.base[tid & 31], ps.base[(tid >> 5) + q * RPT]);
     }
+    CNN_STAMP(16);
     // halo of the padded patch (4 x 33 cells) and of the CB activation planes; interiors are written below / by conv0
     if (tid < 4 * 33) {
         const int e = tid;
@@ -598,24 +613,27 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
 #pragma unroll
     for (int q = 0; q < PPT; ++q) sum += v[q];
     const float mean = block_sum<NW>(sum, red) * (1.0f / 1024.0f);
+    CNN_STAMP(17);
     float sq = 0.f;
 #pragma unroll
     for (int q = 0; q < PPT; ++q) { v[q] -= mean; sq += v[q] * v[q]; }
     const float var = block_sum<NW>(sq, red + NW) * (1.0f / 1023.0f);       // torch.std: unbiased
     const float sd = sqrtf(var) + 1e-7f;
+    CNN_STAMP(18);
 #pragma unroll
     for (int q = 0; q < PPT; ++q) patch[((tid >> 5) + q * RPT + 1) * WP32 + (tid & 31) + 1] = v[q] / sd;
     __syncthreads();
     CNN_STAMP(1);
 
     // ---- conv0: 1 -> CB, K = 9 (padded to 12), MFMA; reads `patch`, writes `act`: no barrier in between ----
-    float bias1[T1N];
+    f32x4 bias1[T1N];
     {
         f32x4 acc[T1M][T1N];
-        conv0_mfma<NW, CB, T1M, T1N>(patch, w0, acc, wave, lane);
+        conv0_mfma<NW, CB, T1M, T1N>(patch, w0, bias0, acc, wave, lane);
+        CNN_STAMP(19);
         prefetch_bias<NW, 32, T1M, T1N>(a.packed + a.off.b[1], bias1, wave, lane);
-        const float nob[T1N] = {};
-        store_tiles_lds<CB, LayC0, T1M, T1N, false>(act, nob, acc, wave, lane);
+        store_tiles_lds<CB, LayC0, T1M, T1N, false>(act, bias0, acc, wave, lane);
+        CNN_STAMP(20);
     }
     __syncthreads();
     if (a.dbg_layer == 0) { dump_planes<CB, LayC0, NTHR>(act, a.dbg_out); return; }
@@ -625,17 +643,21 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
     // the input) -> zero the halo of the OUTPUT layout, bias + ReLU + store in place -> barrier.
     // ---- conv1: CB -> CB @32x32 --------------------------------------------------------------------
     f32x4 b2[G2][T2N];
-    float bias2[T2N];
+    f32x4 bias2[T2N];
     {
         f32x4 acc[T1M][T1N];
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
         if (ROLL1) conv3x3_mfma_roll<NW, CB, CB, LayC0, 1, T1M, T1N>(act, a.packed + a.off.w[1], reinterpret_cast<const f32x4 (&)[1][T1N]>(b1), acc, wave, lane);
         else conv3x3_mfma<NW, CB, CB, LayC0, 1, T1M, T1N, G1>(act, a.packed + a.off.w[1], reinterpret_cast<const f32x4 (&)[G1][T1N]>(b1), acc, wave, lane);
+        if (PRIO) __builtin_amdgcn_s_setprio(3);
         CNN_STAMP(3);
         prefetch_b0<NW, 2 * CB, 16, T2M, T2N, G2>(a.packed + a.off.w[2], b2, wave, lane);
         prefetch_bias<NW, 16, T2M, T2N>(a.packed + a.off.b[2], bias2, wave, lane);
         __syncthreads();
+        CNN_STAMP(21);
         zero_halo<LayC1, NTHR>(act, CB);
         store_tiles_lds<CB, LayC1, T1M, T1N>(act, bias1, acc, wave, lane);
+        CNN_STAMP(22);
         __syncthreads();
         CNN_STAMP(4);
     }
@@ -643,10 +665,12 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
 
     // ---- conv2: CB -> 2CB, stride 2 @16x16 -----------------------------------------------------------
     f32x4 b3[G3][T2N];
-    float bias3[T2N];
+    f32x4 bias3[T2N];
     {
         f32x4 acc[T2M][T2N];
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
         conv3x3_mfma<NW, CB, 2 * CB, LayC1, 2, T2M, T2N, G2>(act, a.packed + a.off.w[2], b2, acc, wave, lane);
+        if (PRIO) __builtin_amdgcn_s_setprio(3);
         CNN_STAMP(5);
         prefetch_b0<NW, 2 * CB, 16, T2M, T2N, G3>(a.packed + a.off.w[3], b3, wave, lane);
         prefetch_bias<NW, 16, T2M, T2N>(a.packed + a.off.b[3], bias3, wave, lane);
@@ -660,10 +684,12 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
 
     // ---- conv3: 2CB -> 2CB @16x16 --------------------------------------------------------------------
     f32x4 b4[G4][T4N];
-    float bias4[T4N];
+    f32x4 bias4[T4N];
     {
         f32x4 acc[T2M][T2N];
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
         conv3x3_mfma<NW, 2 * CB, 2 * CB, LayC2, 1, T2M, T2N, G3>(act, a.packed + a.off.w[3], b3, acc, wave, lane);
+        if (PRIO) __builtin_amdgcn_s_setprio(3);
         CNN_STAMP(7);
         prefetch_b0<NW, 4 * CB, 8, T4M, T4N, G4>(a.packed + a.off.w[4], b4, wave, lane);
         prefetch_bias<NW, 8, T4M, T4N>(a.packed + a.off.b[4], bias4, wave, lane);
@@ -677,10 +703,12 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
 
     // ---- conv4: 2CB -> 4CB, stride 2 @8x8 --------------------------------------------------------------
     f32x4 b5[G5][T4N];
-    float bias5[T4N];
+    f32x4 bias5[T4N];
     {
         f32x4 acc[T4M][T4N];
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
         conv3x3_mfma<NW, 2 * CB, 4 * CB, LayC3, 2, T4M, T4N, G4>(act, a.packed + a.off.w[4], b4, acc, wave, lane);
+        if (PRIO) __builtin_amdgcn_s_setprio(3);
         CNN_STAMP(9);
         prefetch_b0<NW, 4 * CB, 8, T4M, T4N, G5>(a.packed + a.off.w[5], b5, wave, lane);
         prefetch_bias<NW, 8, T4M, T4N>(a.packed + a.off.b[5], bias5, wave, lane);
@@ -695,10 +723,13 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
     // ---- conv5: 4CB -> 4CB @8x8 ------------------------------------------------------------------------
     {
         f32x4 acc[T4M][T4N];
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
         conv3x3_mfma<NW, 4 * CB, 4 * CB, LayC4, 1, T4M, T4N, G5>(act, a.packed + a.off.w[5], b5, acc, wave, lane);
+        if (PRIO) __builtin_amdgcn_s_setprio(3);
         CNN_STAMP(11);
         if (KIND == AFFNET_NET_HARDNET && a.dbg_layer < 0) {
             store_tiles_global<4 * CB, T4M, T4N>(a.out + pidx * HEAD_K, bias5, acc, wave, lane);
+            CNN_STAMP(13);
             return;
         }
         __syncthreads();
@@ -719,8 +750,14 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
             const float vv = act[LayC5::at(c, y, x)];
             s0 = fmaf(vv, hw[e], s0); s1 = fmaf(vv, hw[4096 + e], s1); s2 = fmaf(vv, hw[8192 + e], s2);
         }
-        s0 = block_sum<NW>(s0, red + 2 * NW); s1 = block_sum<NW>(s1, red + 3 * NW); s2 = block_sum<NW>(s2, red + 4 * NW);
+        s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
+        float* hred = red + 2 * NW;                                    // [wave][4]: own slot, one barrier
+        if (lane == 0) { hred[4 * wave] = s0; hred[4 * wave + 1] = s1; hred[4 * wave + 2] = s2; }
+        __syncthreads();
         if (tid == 0) {
+            s0 = s1 = s2 = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < NW; ++wv) { s0 += hred[4 * wv]; s1 += hred[4 * wv + 1]; s2 += hred[4 * wv + 2]; }
             const float* hb = a.packed + a.off.head_b;
             const float x0 = tanhf(s0 + hb[0]), x1 = tanhf(s1 + hb[1]), x2 = tanhf(s2 + hb[2]);
             const float a00 = 1.0f + x0, a01 = 0.0f * x0, a10 = x1, a11 = 1.0f + x2;
@@ -778,6 +815,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
             o[0] = cs; o[1] = sn; o[2] = -sn; o[3] = cs;                      // LAF.py:276-283
         }
     }
+    CNN_STAMP(13);
 }
 
 // ---- HardNet head: (n x 8192) x (8192 x 128) GEMM + BN bias + L2 normalisation ----------------------

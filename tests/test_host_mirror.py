@@ -115,7 +115,7 @@ def test_packed_weights_reproduce_the_network(kind, name, weights):
     if kind == 2:
         Bw = blob[off:off + 8192 * 128].view(8192, 128)
         bias = blob[off + 8192 * 128: off + 8192 * 128 + 128]
-        y = x.reshape(6, -1) @ Bw + bias
+        y = x.permute(0, 2, 3, 1).reshape(6, -1) @ Bw + bias      # head K order = [pixel][channel] (the trunk kernel's store order)
         got = y / torch.sqrt((y * y).sum(1, keepdim=True) + 1e-8)
         want = orc.hardnet_forward(sd, p)
     elif kind == 0:

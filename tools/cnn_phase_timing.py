@@ -18,11 +18,11 @@ names = ["input+norm", "conv0", "conv1 mfma", "conv1 store", "conv2 mfma", "conv
          "conv4 mfma", "conv4 store", "conv5 mfma", "conv5 store"]
 for net, nm, nw in [(A, "AffNet", 8), (H, "HardNet", int(os.environ.get("AFFNET_HARDNET_WAVES", "8")))]:
     net(p); torch.cuda.synchronize()
-    st = torch.zeros(n * nw * 16, dtype=torch.int64, device=dev)
+    st = torch.zeros(n * nw * 32, dtype=torch.int64, device=dev)
     lib.affnet_cnn32_debug_timing(ptr(st))
     net(p); torch.cuda.synchronize()
     lib.affnet_cnn32_debug_timing(None)
-    t = st.cpu().numpy().reshape(n, nw, 16).astype(np.float64)
+    t = st.cpu().numpy().reshape(n, nw, 32).astype(np.float64)
     nst = 12 if nm == "HardNet" else 13
     d = np.diff(t[:, :, :nst], axis=2)              # cycles per phase per wave
     wg = t[:, :, :nst].max(axis=1) - t[:, :, 0:1].min(axis=1)   # per patch: boundary times relative to WG start
@@ -33,3 +33,39 @@ for net, nm, nw in [(A, "AffNet", 8), (H, "HardNet", int(os.environ.get("AFFNET_
     for i in range(nst - 1):
         print("  %-12s mean %9.0f  max-over-waves %9.0f" % (names[i], d[:, :, i].mean(), d[:, :, i].max(axis=1).mean()))
     print("  total per patch (WG) %.0f ticks" % tot)
+    ti = st.cpu().numpy().reshape(n, nw, 32)
+    start, end = ti[:, :, 0].min(axis=1).astype(np.float64), ti[:, :, 13].max(axis=1).astype(np.float64)
+    print("  last phase stamp -> kernel end (head / global store): %.0f ticks" % (ti[:, :, 13] - ti[:, :, nst - 1]).mean())
+    hw, xcc = ti[:, 0, 14], ti[:, 0, 15] & 0xF
+    cu = ((hw >> 8) & 0xF) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5) | (xcc << 8)
+    util, gaps = [], []
+    for c in np.unique(cu):
+        idx = np.where(cu == c)[0]
+        s_, e_ = start[idx], end[idx]
+        o = np.argsort(s_)
+        s_, e_ = s_[o], e_[o]
+        span = e_.max() - s_.min()
+        util.append((e_ - s_).sum() / span)
+        # gap between a WG ending and the next WG starting on this CU (slot-agnostic: sorted ends vs later starts)
+        ends = np.sort(e_)
+        for k in range(len(s_)):
+            prev = ends[ends <= s_[k]]
+            if len(prev):
+                gaps.append(s_[k] - prev.max())
+    sub = t[:, :, [0, 16, 17, 18, 1, 19, 20, 2]]
+    ds = np.diff(sub, axis=2).mean(axis=(0, 1))
+    print("  input: load %.0f | halo+sum1 %.0f | sum2 %.0f | patch write+barrier %.0f || conv0: mfma %.0f | stores %.0f | barrier %.0f" % tuple(ds))
+    sub = t[:, :, [3, 21, 22, 4]]
+    ds = np.diff(sub, axis=2).mean(axis=(0, 1))
+    print("  conv1 epilogue: barrier1 %.0f | halo+stores %.0f | barrier2 %.0f" % tuple(ds))
+    print("  CUs seen %d; mean resident WGs per CU %.2f; median end->next-start gap %.0f ticks (p90 %.0f)" %
+          (len(util), np.mean(util), np.median(gaps), np.percentile(gaps, 90)))
+    # wall time of the same launch without stamps
+    lib.affnet_cnn32_debug_timing(None)
+    big = (torch.rand(48000, 1, 32, 32) * 255).to(dev)
+    net(big); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); net(big); e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
+    fl = {"AffNet": 19193856.0, "HardNet": 78184448.0}[nm]
+    print("  48000 contiguous patches: %.3f ms -> %.1f TFLOP/s (incl. head / allocation)" % (ms, 48000 * fl / ms / 1e9))
