@@ -65,6 +65,11 @@ SYMBOLS = {
     "affnet_apply_rotation": (_I, [_P, _P, _P, _P, _I, _P]),
     "affnet_scale_lafs": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "affnet_level_select": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
+    "affnet_match_scratch_bytes": (_SZ, [_I, _I]),
+    "affnet_distance_matrix": (_I, [_P, _P, _I, _P, _I, _I, _P, _P, _P]),
+    "affnet_match_snn": (_I, [_P, _P, _I, _P, _I, _I, C.c_float, _P, _P, _P, _P, _P, _P, _P]),
+    "affnet_reproject_lafs": (_I, [_P, _P, _I, C.POINTER(C.c_float), _P, _P]),
+    "affnet_centre_nn": (_I, [_P, _P, _I, _P, _I, _P, _P, _P]),
     "affnet_extract_features": (_I, [_P, C.POINTER(Nets), _P, _I, _P, _P, _P, _P, _P, _P]),
     "affnet_detect_image": (_I, [_P, _P, _P]),
     "affnet_describe_detected": (_I, [_P, C.POINTER(Nets), _I, _P, _P, _P, _P, _P, _P]),

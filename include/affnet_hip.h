@@ -224,6 +224,34 @@ int affnet_scale_lafs(affnet_ctx* ctx, const float* d_in, float* d_out, const in
 int affnet_level_select(affnet_ctx* ctx, const float* d_lafs_px, const int32_t* d_count, int n_max,
                         int ps, int32_t* d_ids, float* d_lafs_norm, void* stream);
 
+/* ---- descriptor matching ------------------------------------------ */
+
+/* Bytes of device scratch affnet_match_snn / affnet_distance_matrix need for n1 x n2 descriptors. */
+size_t affnet_match_scratch_bytes(int n1, int n2);
+
+/* Full distance matrix sqrt(|a|^2 + |b|^2 - 2 a.b + 1e-6): d_out (n1, n2).  Replaces Losses.py:5-13
+ * (distance_matrix_vector).  dim must be 128. */
+int affnet_distance_matrix(affnet_ctx* ctx, const float* d_desc1, int n1, const float* d_desc2, int n2, int dim, float* d_out,
+                           void* d_scratch, void* stream);
+
+/* Nearest / "second nearest" neighbour ratio test exactly as train_AffNet_test_on_graffity.py:292-300 does it (the second
+ * minimum runs over the columns that are nobody's nearest neighbour: dist_matrix[:, idxs_in_2] = 100000); the distance
+ * matrix is never materialised.  Outputs: d_min_dist (n1), d_idx (n1), d_min2_dist (n1), d_tent (n1,2) int32 = the pairs
+ * (i, idx[i]) with min/(min2+1e-8) <= snn_threshold in row order, d_count (1). */
+int affnet_match_snn(affnet_ctx* ctx, const float* d_desc1, int n1, const float* d_desc2, int n2, int dim, float snn_threshold,
+                     float* d_min_dist, int32_t* d_idx, float* d_min2_dist, int32_t* d_tent, int32_t* d_count, void* d_scratch,
+                     void* stream);
+
+/* Pixel LAFs (n,2,3) through the homography h_H (HOST pointer, 9 floats row-major): centre = H x / z, shape = linH(H, x) A.
+ * Replaces ReprojectionStuff.py:9-40 (linH, reprojectLAFs). */
+int affnet_reproject_lafs(affnet_ctx* ctx, const float* d_lafs, int n, const float* h_H, float* d_out, void* stream);
+
+/* For every query LAF (image-1 LAFs): nearest reference LAF centre (reprojected image-2 LAFs), distance computed like
+ * ReprojectionStuff.py:78-86 on the 2-D centres (sqrt(| |a|^2 + |p|^2 - 2 p.a | + 1e-12), fp32).
+ * Replaces the distance / min part of ReprojectionStuff.py:126-137 (get_GT_correspondence_indexes). */
+int affnet_centre_nn(affnet_ctx* ctx, const float* d_query_lafs, int nq, const float* d_ref_lafs, int nr, float* d_min_dist,
+                     int32_t* d_idx, void* stream);
+
 /* ---- fused pipeline ------------------------------------------------------------------------ */
 
 typedef struct affnet_nets {

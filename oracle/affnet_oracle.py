@@ -561,3 +561,89 @@ def synthetic_image(h, w, seed):
         s *= 2
     acc = (acc - acc.min()) / (acc.max() - acc.min()) * 255.0
     return acc.float().contiguous()
+
+
+# ----------------------------------------------------------------------------------------
+# descriptor matching (first consumer of the descriptors)
+# ----------------------------------------------------------------------------------------
+
+
+def distance_matrix_vector(anchor, positive):
+    """(n1,d),(n2,d) -> (n1,n2) sqrt(|a|^2 + |b|^2 - 2 a.b + 1e-6).  Losses.py:5-13."""
+    d1_sq = torch.sum(anchor * anchor, dim=1).unsqueeze(-1)
+    d2_sq = torch.sum(positive * positive, dim=1).unsqueeze(-1)
+    eps = 1e-6
+    return torch.sqrt((d1_sq.repeat(1, positive.size(0)) + torch.t(d2_sq.repeat(1, anchor.size(0)))
+                       - 2.0 * torch.bmm(anchor.unsqueeze(0), torch.t(positive).unsqueeze(0)).squeeze(0)) + eps)
+
+
+def match_snn(desc1, desc2, snn_threshold=0.8):
+    """Second-nearest-neighbour ratio test exactly as train_AffNet_test_on_graffity.py:292-300 does it:
+    the "second nearest" is the minimum over the columns that are NOBODY's nearest neighbour
+    (`dist_matrix[:, idxs_in_2] = 100000` masks whole columns for every row).
+    Returns (min_dist, idx_in_2, min_2nd_dist, tent_in_1, tent_in_2)."""
+    dist = distance_matrix_vector(desc1, desc2)
+    min_dist, idxs_in_2 = torch.min(dist, 1)
+    dist[:, idxs_in_2] = 100000
+    min_2nd_dist, _ = torch.min(dist, 1)
+    mask = (min_dist / (min_2nd_dist + 1e-8)) <= snn_threshold
+    tent_in_1 = torch.arange(0, idxs_in_2.size(0))[mask].long()
+    tent_in_2 = idxs_in_2[mask].long()
+    return min_dist, idxs_in_2, min_2nd_dist, tent_in_1, tent_in_2
+
+
+def lin_h(H, x, y):
+    """Local affine approximation of a homography at (x, y).  ReprojectionStuff.py:9-21."""
+    A = torch.zeros(x.size(0), 2, 2)
+    den = x * H[2, 0] + y * H[2, 1] + H[2, 2]
+    num1_densq = (x * H[0, 0] + y * H[0, 1] + H[0, 2]) / (den * den)
+    num2_densq = (x * H[1, 0] + y * H[1, 1] + H[1, 2]) / (den * den)
+    A[:, 0, 0] = H[0, 0] / den - num1_densq * H[2, 0]
+    A[:, 0, 1] = H[0, 1] / den - num1_densq * H[2, 1]
+    A[:, 1, 0] = H[1, 0] / den - num2_densq * H[2, 0]
+    A[:, 1, 1] = H[1, 1] / den - num2_densq * H[2, 1]
+    return A
+
+
+def reproject_lafs(lafs1, H1to2):
+    """Pixel LAFs (n,2,3) through a homography.  ReprojectionStuff.py:23-40 + LAF.py:91-95."""
+    n = lafs1.size(0)
+    lhf = torch.cat([lafs1, torch.Tensor([0, 0, 1]).unsqueeze(0).unsqueeze(0).repeat(n, 1, 1)], dim=1)
+    xy1 = torch.bmm(H1to2.expand(n, 3, 3), lhf[:, :, 2:])
+    xy1 = xy1 / xy1[:, 2:, :].expand(n, 3, 1)
+    As = lin_h(H1to2, lafs1[:, 0, 2], lafs1[:, 1, 2])
+    AF = torch.bmm(As, lhf[:, 0:2, 0:2])
+    return torch.cat([AF, xy1[:, :2, :]], dim=2)
+
+
+def distance_matrix_vector_reproj(anchor, positive):
+    """ReprojectionStuff.py:78-86 - NOT the Losses.py function of the same name: the result is (n_positive, n_anchor),
+    with abs() under the root and eps = 1e-12."""
+    d1_sq = torch.sum(anchor * anchor, dim=1)
+    d2_sq = torch.sum(positive * positive, dim=1)
+    eps = 1e-12
+    return torch.sqrt(torch.abs((d1_sq.expand(positive.size(0), anchor.size(0)) +
+                                 torch.t(d2_sq.expand(anchor.size(0), positive.size(0)))
+                                 - 2.0 * torch.bmm(positive.unsqueeze(0), torch.t(anchor).unsqueeze(0)).squeeze(0)) + eps))
+
+
+def get_gt_correspondence_indexes(lafs1, lafs2, H1to2, dist_threshold=4):
+    """ReprojectionStuff.py:126-137: centres of lafs2 reprojected into image 1; for every lafs1 centre the nearest
+    reprojected centre (ReprojectionStuff's own distance_matrix_vector returns (n1, n2), so torch.min(dist, 1) runs over
+    the reprojected set; the |a|^2+|b|^2-2ab expansion in fp32 is only good to ~0.1 px at ~800 px coordinates), kept if
+    <= dist_threshold."""
+    lafs2_in_1 = reproject_lafs(lafs2, torch.inverse(H1to2))
+    c1 = lafs1[:, :, 2]
+    c2 = lafs2_in_1[:, 0:2, 2]
+    dist = distance_matrix_vector_reproj(c2, c1)
+    min_dist, idxs_in_2 = torch.min(dist, 1)
+    plain = torch.arange(0, idxs_in_2.size(0))
+    mask = min_dist <= dist_threshold
+    return min_dist[mask], plain[mask], idxs_in_2[mask]
+
+
+def match_and_verify(lafs1, desc1, lafs2, desc2, H1to2, snn_threshold=0.8, dist_threshold=6):
+    """The evaluation of train_AffNet_test_on_graffity.py:290-305 (test()): tentatives + homography-consistent matches."""
+    md, idx, md2, t1, t2 = match_snn(desc1, desc2, snn_threshold)
+    gd, plain, in2 = get_gt_correspondence_indexes(lafs1[t1], lafs2[t2], H1to2, dist_threshold)
+    return dict(min_dist=md, idx=idx, min_2nd=md2, tent1=t1, tent2=t2, gt_dist=gd, gt_plain=plain, gt_idx=in2)

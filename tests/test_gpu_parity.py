@@ -379,6 +379,59 @@ def test_batched_launches_equal_single_image_calls(amd, nets):
             assert float(r["LAFs"][b, n:].abs().sum()) == 0.0 and float(r["descriptors"][b, n:].abs().sum()) == 0.0
 
 
+def test_matching_snn_and_homography_check(amd, golden_dir):
+    """SURVEY section 8f row 1 (test() of train_AffNet_test_on_graffity.py:290-305): MFMA distance / SNN ratio kernel and the
+    homography consistency check against the reference's golden outputs and the oracle."""
+    from affnet_amd import Losses, ReprojectionStuff as RS
+    g = np.load(os.path.join(golden_dir, "match_graf16_n500.npz"))
+    L1, D1, L2, D2, H = (torch.from_numpy(g[k]) for k in ("LAFs1", "desc1", "LAFs2", "desc2", "H"))
+    d1, d2 = D1.to(DEV), D2.to(DEV)
+    # full distance matrix vs the oracle (fp32 MFMA vs sgemm summation order)
+    full = Losses.distance_matrix_vector(d1, d2).cpu()
+    want = orc.distance_matrix_vector(D1, D2)
+    _report("distance matrix", full.numpy(), want.numpy())
+    assert float((full - want).abs().max()) < 2e-6 * 2 + 1e-5
+    t1, t2, md, md2 = RS.match_snn(d1, d2, 0.8)
+    assert np.abs(md.cpu().numpy() - g["min_dist"]).max() < 1e-5 and np.abs(md2.cpu().numpy() - g["min_2nd"]).max() < 1e-5
+    got = set(zip(t1.tolist(), t2.tolist()))
+    ref = set(zip(g["tent1"].tolist(), g["tent2"].tolist()))
+    print("tentatives: %d (reference %d), common %d" % (len(got), len(ref), len(got & ref)))
+    assert len(got & ref) >= len(ref) - 1 and abs(len(got) - len(ref)) <= 1
+    assert t1.tolist() == sorted(t1.tolist())                          # row order, like boolean-mask indexing
+    # homography check on the reference's own tentatives: identical rows
+    rt1, rt2 = torch.from_numpy(g["tent1"]), torch.from_numpy(g["tent2"])
+    rp = RS.reprojectLAFs(L2[rt2].to(DEV), torch.inverse(H)).cpu().numpy()
+    err = np.abs(rp - g["reproj"]).reshape(len(rp), -1).max(axis=1)
+    scale = np.abs(g["reproj"]).reshape(len(rp), -1).max(axis=1)
+    print("reprojectLAFs: worst abs err %.3g, worst err / row scale %.3g" % (err.max(), (err / scale).max()))
+    assert (err <= 1e-4 + 1e-5 * scale).all()      # fp32: linH subtracts nearly equal terms; coordinates reach ~7000 px
+    gd, plain, in2 = RS.get_GT_correspondence_indexes(L1[rt1].to(DEV), L2[rt2].to(DEV), H, dist_threshold=6)
+    assert np.array_equal(plain.cpu().numpy(), g["gt_plain"]) and np.array_equal(in2.cpu().numpy(), g["gt_idx"])
+    assert np.abs(gd.cpu().numpy() - g["gt_dist"]).max() < 0.05
+    # ragged / edge sizes: n1 not a multiple of 64, n2 not a multiple of 16, a single row, zero rows
+    gen = torch.Generator().manual_seed(5)
+    for n1, n2 in ((1, 17), (67, 33), (130, 1), (0, 5)):
+        a = torch.nn.functional.normalize(torch.randn(n1, 128, generator=gen), dim=1)
+        b = torch.nn.functional.normalize(torch.randn(n2, 128, generator=gen), dim=1)
+        t1, t2, md, md2 = RS.match_snn(a.to(DEV), b.to(DEV), 0.9)
+        if n1 == 0:
+            assert t1.numel() == 0
+            continue
+        w = orc.match_snn(a, b, 0.9)
+        assert np.abs(md.cpu().numpy() - w[0].numpy()).max() < 1e-5 and np.array_equal(torch.stack([t1, t2]).cpu().numpy(), torch.stack([w[3], w[4]]).numpy())
+    # size-independent property at the benchmark size: matching a set against a shuffled copy of itself recovers the
+    # permutation at distance ~sqrt(1e-6).  (For identical vectors |a|^2 + |b|^2 - 2 a.b can round below -1e-6: sqrt gives
+    # NaN, which torch.min - and this kernel - propagate; allow a handful of such rows.)
+    x = torch.nn.functional.normalize(torch.randn(3000, 128, generator=gen), dim=1)
+    perm = torch.randperm(3000, generator=gen)
+    t1, t2, md, _ = RS.match_snn(x.to(DEV), x[perm].to(DEV), 0.8)
+    md = md.cpu()
+    ok = ~torch.isnan(md)
+    assert int((~ok).sum()) <= 6 and float(md[ok].max()) < 2e-3
+    inv = torch.empty_like(perm); inv[perm] = torch.arange(3000)
+    assert torch.equal(t2.cpu(), inv[t1.cpu()]) and t1.numel() >= 3000 - 6
+
+
 def test_just_shape_config1(amd, nets, golden_dir):
     """BASELINE.json configs[0]: detect_affine_shape on a patch column (examples/just_shape)."""
     g = np.load(os.path.join(golden_dir, "just_shape_column.npz"))

@@ -94,3 +94,25 @@ def test_edge_cases():
     plan = orc.pyramid_plan(768, 1024)
     assert [(o["h"], o["w"]) for o in plan["octaves"]] == [(768, 1024), (384, 512), (192, 256), (96, 128), (48, 64), (24, 32)]
     assert len(orc.pyramid_plan(2160, 3840)["octaves"]) == 8
+
+
+def test_matching_restatement_vs_reference_golden(golden_dir):
+    """distance matrix, the reference's SNN ratio test (whole-column masking) and the homography
+    check of test() - the restatement must reproduce the UNMODIFIED reference's outputs (tests/golden/make_golden_match.py).
+    The descriptor distance goes through an sgemm whose blocking differs between hosts, so distances get 1e-5."""
+    import numpy as np
+    import torch
+    g = np.load(os.path.join(golden_dir, "match_graf16_n500.npz"))
+    L1, D1, L2, D2, H = (torch.from_numpy(g[k]) for k in ("LAFs1", "desc1", "LAFs2", "desc2", "H"))
+    r = orc.match_and_verify(L1, D1, L2, D2, H, 0.8, 6)
+    assert np.abs(r["min_dist"].numpy() - g["min_dist"]).max() < 1e-5 and np.abs(r["min_2nd"].numpy() - g["min_2nd"]).max() < 1e-5
+    assert (r["idx"].numpy() == g["idx"]).mean() > 0.995
+    same_t = set(zip(r["tent1"].tolist(), r["tent2"].tolist())) & set(zip(g["tent1"].tolist(), g["tent2"].tolist()))
+    assert len(same_t) >= len(g["tent1"]) - 1 and abs(len(r["tent1"]) - len(g["tent1"])) <= 1
+    assert np.abs(orc.distance_matrix_vector(D1[:8], D2[:8]).numpy() - g["dist_head"]).max() < 1e-5
+    rp = orc.reproject_lafs(L2[torch.from_numpy(g["tent2"])], torch.inverse(H)).numpy()
+    assert np.abs(rp - g["reproj"]).max() < 1e-3 * max(1.0, np.abs(g["reproj"]).max())
+    # with the reference's own tentatives the homography check must reproduce the reference's rows exactly
+    gd, plain, in2 = orc.get_gt_correspondence_indexes(L1[torch.from_numpy(g["tent1"])], L2[torch.from_numpy(g["tent2"])], H, 6)
+    assert np.array_equal(plain.numpy(), g["gt_plain"]) and np.array_equal(in2.numpy(), g["gt_idx"])
+    assert np.abs(gd.numpy() - g["gt_dist"]).max() < 0.05      # the fp32 |a|^2+|b|^2-2ab expansion is that noisy at ~800 px
