@@ -48,6 +48,30 @@ def unpack_record(row, n_cap):
     return {"LAFs": body[:, :6].reshape(n, 2, 3), "responses": body[:, 6], "descriptors": body[:, 7:]}
 
 
+def gather_features_async(local_records, n_total, group=None):
+    """Starts the all-gather and returns a `finish()` callable that waits for it and returns the records in global image
+    order - lets the caller overlap the exchange of step k with the compute of step k+1 (bench.py)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return lambda: local_records
+    world = dist.get_world_size(group)
+    per_rank = -(-n_total // world)
+    if local_records.size(0) < per_rank:
+        pad = torch.zeros(per_rank - local_records.size(0), local_records.size(1), dtype=local_records.dtype, device=local_records.device)
+        local_records = torch.cat([local_records, pad])
+    dev = local_records.device
+    if dist.get_backend(group) == "gloo" and local_records.is_cuda:
+        local_records = local_records.cpu()
+    local_records = local_records.contiguous()
+    out = torch.empty((world * per_rank, local_records.size(1)), dtype=local_records.dtype, device=local_records.device)
+    work = dist.all_gather_into_tensor(out, local_records, group=group, async_op=True)
+
+    def finish():
+        work.wait()
+        keep = local_records  # noqa: F841  (input must stay alive until the collective has finished)
+        return out.view(world, per_rank, -1).transpose(0, 1).reshape(per_rank * world, -1)[:n_total].to(dev)
+    return finish
+
+
 def gather_features(local_records, n_total, group=None):
     """all_gather of the padded records; returns (n_total, record) in global image order.
     Every rank must hold ceil-divided shards of equal length (pad with zero rows otherwise)."""
@@ -58,7 +82,10 @@ def gather_features(local_records, n_total, group=None):
     if local_records.size(0) < per_rank:
         pad = torch.zeros(per_rank - local_records.size(0), local_records.size(1), dtype=local_records.dtype, device=local_records.device)
         local_records = torch.cat([local_records, pad])
-    bufs = [torch.empty_like(local_records) for _ in range(world)]
-    dist.all_gather(bufs, local_records.contiguous(), group=group)
-    stacked = torch.stack(bufs, dim=1).reshape(per_rank * world, -1)   # row j*world + r = item j of rank r = global item j*world + r
-    return stacked[:n_total]
+    dev = local_records.device
+    if dist.get_backend(group) == "gloo" and local_records.is_cuda:
+        local_records = local_records.cpu()          # gloo has no CUDA all_gather (CPU tests / single-GPU dry runs of bench.py)
+    out = torch.empty((world * per_rank, local_records.size(1)), dtype=local_records.dtype, device=local_records.device)
+    dist.all_gather_into_tensor(out, local_records.contiguous(), group=group)      # one RCCL all-gather on backend "nccl"
+    stacked = out.view(world, per_rank, -1).transpose(0, 1).reshape(per_rank * world, -1)   # row j*world + r = item j of rank r = global item j*world + r
+    return stacked[:n_total].to(dev)

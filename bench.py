@@ -101,7 +101,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        # AFFNET_BENCH_BACKEND=gloo + AFFNET_BENCH_ONE_DEVICE=1: dry run of the N > 1 code path on a single-GPU box
+        dist.init_process_group(os.environ.get("AFFNET_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+    if os.environ.get("AFFNET_BENCH_ONE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -138,6 +141,8 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     det_stream = torch.cuda.Stream(device=dev) if PIPE else None
 
+    pending = [None]                   # finish() of the previous step's all-gather (overlaps with this step's compute)
+
     def step():
         results = [None] * len(chunks)
         for ci, c in enumerate(chunks):
@@ -146,18 +151,30 @@ def main():
         for s in streams:
             s.synchronize()
         if world > 1:
+            if pending[0] is not None:
+                pending[0]()                                    # records of the previous step have arrived
             rec = sharded.pack_batched_records(results, NKP)
-            rec = sharded.gather_features(rec, args.batch * world)
             torch.cuda.synchronize()
+            pending[0] = sharded.gather_features_async(rec, args.batch * world)
         return results
+
+    def drain():
+        if pending[0] is not None:
+            pending[0]()
+            pending[0] = None
+            torch.cuda.synchronize()
 
     def barrier():
         if world > 1:
-            dist.barrier()
+            if dist.get_backend() == "nccl":
+                dist.barrier(device_ids=[local_rank])
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
+    drain()
     for d in dets.values():
         _lib.check(_lib.lib.affnet_profile_enable(d._ctx.handle, 1), d._ctx.handle, "profile_enable")
     barrier()
@@ -166,6 +183,7 @@ def main():
     for _ in range(args.steps):
         res = step()
         kp += int(sum(int(r["count"].sum().item()) for r in res))   # device counts, read after the step's sync
+    drain()                            # the last step's gather completes inside the timed region
     barrier()
     dt = time.perf_counter() - t0
     # stage timings recorded by HIP events on the launch streams during the timed region

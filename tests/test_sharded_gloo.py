@@ -31,6 +31,7 @@ def _worker(rank, world, port, out):
     rec = sharded.pack_records([_fake_result(i) for i in mine], N_CAP, torch.device("cpu"))
     full = sharded.gather_features(rec, N_IMG)
     ok = full.shape == (N_IMG, 1 + N_CAP * 135)
+    ok &= torch.equal(sharded.gather_features_async(rec, N_IMG)(), full)     # the overlapped form bench.py uses
     for i in range(N_IMG):
         want, got = _fake_result(i), sharded.unpack_record(full[i], N_CAP)
         n = int(want["count"])
