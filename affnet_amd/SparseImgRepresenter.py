@@ -37,8 +37,6 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
             raise NotImplementedError("custom RespNet slot: only the built-in HessianResp is implemented in HIP")
         if nlevels != 3:
             raise NotImplementedError("the HIP detector is specialised for nlevels=3 (5 levels per octave)")
-        if num_Baum_iters > 1:
-            raise NotImplementedError("num_Baum_iters > 1 (iterated AffNet with re-extraction) is not implemented")
         if num_Baum_iters > 0 and AffNet is None:
             raise NotImplementedError("default AffineShapeEstimator (Baumberg) slot is SURVEY section 8f 'next'; pass AffNet=")
         self.OriNet = OriNet
@@ -57,10 +55,10 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
                              "(HandCraftedModules.py:283-284) - use enqueue()/run_batch() for (B,1,H,W) batches")
         pre = int(1.5 * self.num) if self.num_Baum_iters > 0 else self.num
         key = (x.size(0), x.size(2), x.size(3), x.device, pre, self.num, float(self.th), self.mrSize, self.b, self.init_sigma,
-               self.max_keep)
+               self.max_keep, self.num_Baum_iters)
         if self._ctx is None or self._ctx_key != key:
             self._ctx = engine.Context(x.size(2), x.size(3), x.device, self.nlevels, self.init_sigma, self.b, self.mrSize,
-                                       float(self.th), self.num, pre, self.max_keep, batch=x.size(0))
+                                       float(self.th), self.num, pre, self.max_keep, batch=x.size(0), baum_iters=self.num_Baum_iters)
             self._ctx_key = key
         return self._ctx
 
@@ -175,6 +173,8 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
         ctx.read_counts()
         if n == 0:
             raise RuntimeError("no keypoints detected (the reference raises in torch.cat, SparseImgRepresenter.py:100)")
+        if self.num_Baum_iters > 1:
+            raise NotImplementedError("num_Baum_iters > 1 with a foreign AffNet slot: use the native AffNetFast (fused path)")
         if self.num_Baum_iters > 0:
             PS = self.AffNet.PS
             patches = torch.empty(n, 1, PS, PS, dtype=torch.float32, device=dev)

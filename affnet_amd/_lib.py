@@ -27,7 +27,7 @@ class Config(C.Structure):
         ("level_blur", (C.c_float * (MAX_TAPS * MAX_TAPS)) * MAX_LEVELS),
         ("mr_size", C.c_float), ("threshold", C.c_float),
         ("num_features", C.c_int32), ("num_prefilter", C.c_int32),
-        ("max_raw_per_octave_div", C.c_int32), ("max_keep", C.c_int32), ("batch", C.c_int32),
+        ("max_raw_per_octave_div", C.c_int32), ("max_keep", C.c_int32), ("batch", C.c_int32), ("baum_iters", C.c_int32),
     ]
 
 

@@ -71,6 +71,7 @@ struct affnet_ctx {
     float* st_det_resp = nullptr; float* st_det_lafs = nullptr; int32_t* st_det_ids = nullptr;
     int32_t* st_det_count = nullptr;     // B contiguous detector row counts (kernels index count[image])
     float* st_A = nullptr; float* st_key = nullptr; int32_t* st_good = nullptr;
+    float* st_A2 = nullptr; float* st_lafs_iter = nullptr;   // AffNet iterations > 1: current A, re-extraction LAFs
     float* st_R = nullptr; float* st_lafs_norm = nullptr; int32_t* st_lvl_ids = nullptr;
     float* st_hard_scratch = nullptr;
     float* st_lafs_shaped = nullptr;

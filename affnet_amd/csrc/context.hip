@@ -98,6 +98,7 @@ extern "C" int affnet_ctx_create(affnet_ctx** out, int device, const affnet_conf
     const size_t P = B * (size_t)ctx->cap_pre, F = B * (size_t)ctx->cap_final;
     off += aff_align(P * 10 * sizeof(float));          // det resp(1) + lafs(6) + ids(3)
     off += aff_align(P * 4 * sizeof(float));           // A
+    off += aff_align(P * 10 * sizeof(float));          // A of the current iteration (4) + re-extraction LAFs (6)
     off += aff_align(P * 2 * sizeof(float));           // key, good
     off += aff_align(P * sizeof(int32_t));             // rank / pos
     off += aff_align(B * sizeof(int32_t));             // detector row counts
@@ -148,6 +149,7 @@ extern "C" int affnet_bind_workspace(affnet_ctx* ctx, void* d_workspace, size_t 
     ctx->st_det_resp = (float*)s; ctx->st_det_lafs = (float*)s + P; ctx->st_det_ids = (int32_t*)((float*)s + 7 * P);
     s += aff_align(P * 10 * sizeof(float));
     ctx->st_A = (float*)s; s += aff_align(P * 4 * sizeof(float));
+    ctx->st_A2 = (float*)s; ctx->st_lafs_iter = (float*)s + 4 * P; s += aff_align(P * 10 * sizeof(float));
     ctx->st_key = (float*)s; ctx->st_good = (int32_t*)((float*)s + P); s += aff_align(P * 2 * sizeof(float));
     ctx->st_rank = (int32_t*)s; s += aff_align(P * sizeof(int32_t));
     ctx->st_det_count = (int32_t*)s; s += aff_align(B * sizeof(int32_t));

@@ -231,6 +231,39 @@ extern "C" int affnet_shape_filter_select(affnet_ctx* ctx, const float* d_resp_i
     return AFFNET_OK;
 }
 
+// ---- AffNet iterations (num_Baum_iters > 1, SparseImgRepresenter.py:127-146) ------------------------------------
+// mode 0: lafs_out = [base * LAF_2x2 | centre]                         (new_LAFs for the re-extraction, :137)
+// mode 1: base = A * base (bmm, k ascending, fused accumulate), then lafs_out as above   (:136-137)
+__global__ __launch_bounds__(256) void shape_iterate_kernel(const float* __restrict__ A, float* __restrict__ base, const float* __restrict__ lafs,
+                                                            const int32_t* __restrict__ d_count, int n_max, int mode,
+                                                            float* __restrict__ lafs_out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const size_t bi = blockIdx.y;
+    const int n = min(d_count[bi], n_max);
+    if (i >= n) return;
+    const size_t r = bi * n_max + i;
+    float b00 = base[4 * r], b01 = base[4 * r + 1], b10 = base[4 * r + 2], b11 = base[4 * r + 3];
+    if (mode == 1) {
+        const float a00 = A[4 * r], a01 = A[4 * r + 1], a10 = A[4 * r + 2], a11 = A[4 * r + 3];
+        const float n00 = fmaf(a01, b10, a00 * b00), n01 = fmaf(a01, b11, a00 * b01);
+        const float n10 = fmaf(a11, b10, a10 * b00), n11 = fmaf(a11, b11, a10 * b01);
+        b00 = n00; b01 = n01; b10 = n10; b11 = n11;
+        base[4 * r] = b00; base[4 * r + 1] = b01; base[4 * r + 2] = b10; base[4 * r + 3] = b11;
+    }
+    const float* L = lafs + 6 * r;
+    float* O = lafs_out + 6 * r;
+    O[0] = fmaf(b01, L[3], b00 * L[0]); O[1] = fmaf(b01, L[4], b00 * L[1]); O[2] = L[2];
+    O[3] = fmaf(b11, L[3], b10 * L[0]); O[4] = fmaf(b11, L[4], b10 * L[1]); O[5] = L[5];
+}
+
+int aff_shape_iterate(affnet_ctx* ctx, const float* A, float* base, const float* lafs, const int32_t* count, int mode, float* lafs_out,
+                      hipStream_t st) {
+    hipLaunchKernelGGL(shape_iterate_kernel, dim3(aff_cdiv(ctx->cap_pre, 256), ctx->B), dim3(256), 0, st, A, base, lafs, count, ctx->cap_pre, mode,
+                       lafs_out);
+    AFF_LAUNCH_CHECK(ctx);
+    return AFFNET_OK;
+}
+
 // ---- small elementwise LAF kernels ---------------------------------------------------------------
 __global__ void apply_rotation_kernel(float* __restrict__ lafs, const float* __restrict__ R, const int32_t* __restrict__ d_count,
                                       int n_max) {

@@ -42,6 +42,10 @@ extern "C" int affnet_profile_read(affnet_ctx* ctx, double sum_ms[AFFNET_PROFILE
     return AFFNET_OK;
 }
 
+// AffNet iterations > 1 (laf_ops.hip)
+int aff_shape_iterate(affnet_ctx* ctx, const float* A, float* base, const float* lafs, const int32_t* count, int mode, float* lafs_out,
+                      hipStream_t st);
+
 // HardNet with a stage mark between trunk and head (cnn32.hip)
 int aff_hardnet_forward_pyr_marked(affnet_ctx* ctx, const float* packed, const float* lafs, const int32_t* ids, const int32_t* count,
                                    int n_max, float* out, float* scratch, hipStream_t st);
@@ -75,6 +79,18 @@ extern "C" int affnet_describe_detected(affnet_ctx* ctx, const affnet_nets* nets
         rc = affnet_cnn32_forward_pyr(ctx, AFFNET_NET_AFFNET, nets->d_affnet, ctx->st_det_lafs, ctx->st_det_ids, det_count, P, ctx->st_A,
                                       nullptr, stream);
         if (rc) return rc;
+        // num_Baum_iters > 1 (SparseImgRepresenter.py:127-146): base_A = A_i * base_A, patches re-extracted from
+        // [base_A * LAF | centre] on the same pyramid level.  st_A holds base_A (= A_0 after the first pass: bmm(A, I) = A).
+        const int iters = ctx->cfg.baum_iters > 0 ? ctx->cfg.baum_iters : 1;
+        for (int it = 1; it < iters; ++it) {
+            rc = aff_shape_iterate(ctx, nullptr, ctx->st_A, ctx->st_det_lafs, det_count, 0, ctx->st_lafs_iter, st);
+            if (rc) return rc;
+            rc = affnet_cnn32_forward_pyr(ctx, AFFNET_NET_AFFNET, nets->d_affnet, ctx->st_lafs_iter, ctx->st_det_ids, det_count, P, ctx->st_A2,
+                                          nullptr, stream);
+            if (rc) return rc;
+            rc = aff_shape_iterate(ctx, ctx->st_A2, ctx->st_A, ctx->st_det_lafs, det_count, 1, ctx->st_lafs_iter, st);
+            if (rc) return rc;
+        }
         aff_prof_mark(ctx, 3, st);
         rc = affnet_shape_filter_select(ctx, ctx->st_det_resp, ctx->st_det_lafs, ctx->st_det_ids, ctx->st_A, det_count, d_resp,
                                         ctx->st_lafs_shaped, d_ids, d_count, stream);

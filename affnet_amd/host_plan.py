@@ -57,7 +57,7 @@ class PyramidPlan(object):
         self.n_octaves = len(self.sizes)
         self.levels_per_octave = n_levels + 2
 
-    def fill_config(self, mr_size, threshold, num_features, num_prefilter, max_keep=16384, raw_div=4, batch=1):
+    def fill_config(self, mr_size, threshold, num_features, num_prefilter, max_keep=16384, raw_div=4, batch=1, baum_iters=0):
         if self.n_octaves > _lib.MAX_OCTAVES or self.levels_per_octave > _lib.MAX_LEVELS:
             raise ValueError("pyramid too deep for the library limits")
         c = _lib.Config()
@@ -85,4 +85,5 @@ class PyramidPlan(object):
         c.num_features, c.num_prefilter = int(num_features), int(num_prefilter)
         c.max_raw_per_octave_div, c.max_keep = int(raw_div), int(max_keep)
         c.batch = int(batch)
+        c.baum_iters = int(baum_iters)
         return c

@@ -81,6 +81,8 @@ typedef struct affnet_config {
     int32_t batch;                         /* images per call, all of size height x width (<= 0: 1).
                                             * The reference is batch-size-1 (HandCraftedModules.py:283-284) and
                                             * loops in Python; here one launch covers the batch (BASELINE configs[2]). */
+    int32_t baum_iters;                    /* num_Baum_iters (ctor kwarg, SparseImgRepresenter.py:22): AffNet shape iterations with
+                                            * re-extraction (:127-146); <= 0: 1 when AffNet weights are passed, else none    */
 } affnet_config;
 
 /* ---- context ------------------------------------------------------------------------------- */

@@ -379,6 +379,29 @@ def test_batched_launches_equal_single_image_calls(amd, nets):
             assert float(r["LAFs"][b, n:].abs().sum()) == 0.0 and float(r["descriptors"][b, n:].abs().sum()) == 0.0
 
 
+@pytest.mark.parametrize("iters", [2, 3])
+def test_iterated_affnet_shape(amd, nets, weights, iters):
+    """num_Baum_iters > 1 (SparseImgRepresenter.py:127-146): base_A = A_i * base_A with patches re-extracted from
+    [base_A * LAF | centre] between the AffNet passes."""
+    A, O, H = nets
+    x = orc.synthetic_image(240, 320, 1)
+    det = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=iters, AffNet=A, OriNet=O).to(DEV)
+    res = det.run(x.to(DEV), do_ori=True, desc=H)
+    ex = orc.OracleExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=iters, affnet_sd=weights["AffNet"],
+                             orinet_sd=weights["OriNet"])
+    Lw, rw, Pw, Dw = orc.describe(x, ex, weights["HardNet"], do_ori=True, ps=32)
+    gi, wi = _match(res["ids"].cpu().numpy(), ex.keys.numpy())
+    row_err = np.abs(res["LAFs"].cpu().numpy()[gi] - Lw.numpy()[wi]).reshape(len(gi), -1).max(axis=1)
+    dd = np.abs(res["descriptors"].cpu().numpy()[gi] - Dw.numpy()[wi]).max()
+    print("iters %d: matched %d / %d, LAF worst %.3g px, rows within 1e-3 px %.4f, descriptor worst %.3g" %
+          (iters, len(gi), len(ex.keys), row_err.max(), (row_err < 1e-3).mean(), dd))
+    assert len(gi) >= 0.99 * len(ex.keys) and (row_err < 1e-3).mean() >= 0.99 and dd < 1e-3
+    # differs from the single-iteration result (the iteration really happened)
+    one = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=1, AffNet=A, OriNet=O).to(DEV)
+    L1, _ = one(x.to(DEV), do_ori=True)
+    assert L1.shape != res["LAFs"].shape or float((L1 - res["LAFs"]).abs().max()) > 1e-3
+
+
 def test_matching_snn_and_homography_check(amd, golden_dir):
     """SURVEY section 8f row 1 (test() of train_AffNet_test_on_graffity.py:290-305): MFMA distance / SNN ratio kernel and the
     homography consistency check against the reference's golden outputs and the oracle."""
