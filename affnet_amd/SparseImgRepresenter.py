@@ -8,8 +8,9 @@ libaffnet_hip.so.
 * foreign slots (any callable with the reference's slot signature): the same
   stages are driven one by one through the C ABI and the slot is called on device tensors.
 
-Not built (SURVEY.md section 8f "next"): the hand-crafted default slot fillers AffineShapeEstimator /
-OrientationDetector and a custom RespNet; asking for them raises NotImplementedError.
+Default slots as in the reference (SparseImgRepresenter.py:42-49): OriNet=None -> OrientationDetector(patch_size=19),
+AffNet=None -> AffineShapeEstimator(patch_size=19) (affnet_amd.HandCraftedModules, csrc/handcrafted.hip).  Not built: a
+custom RespNet and nlevels != 3; asking for them raises NotImplementedError.
 """
 import ctypes as C
 
@@ -19,6 +20,7 @@ import torch.nn as nn
 from . import _lib, engine
 from ._lib import lib, check, ptr
 from .architectures import _HipPatchNet
+from .HandCraftedModules import AffineShapeEstimator, OrientationDetector, _HipHandCrafted
 
 
 class ScaleSpaceAffinePatchExtractor(nn.Module):
@@ -37,10 +39,8 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
             raise NotImplementedError("custom RespNet slot: only the built-in HessianResp is implemented in HIP")
         if nlevels != 3:
             raise NotImplementedError("the HIP detector is specialised for nlevels=3 (5 levels per octave)")
-        if num_Baum_iters > 0 and AffNet is None:
-            raise NotImplementedError("default AffineShapeEstimator (Baumberg) slot is SURVEY section 8f 'next'; pass AffNet=")
-        self.OriNet = OriNet
-        self.AffNet = AffNet
+        self.OriNet = OriNet if OriNet is not None else OrientationDetector(patch_size=19)       # SparseImgRepresenter.py:42-45
+        self.AffNet = AffNet if AffNet is not None else AffineShapeEstimator(patch_size=19)      # :46-49
         self.scale_pyr = self.sigmas = self.pix_dists = None
         self._ctx = None
         self._ctx_key = None
@@ -69,7 +69,7 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
 
     @staticmethod
     def _native(slot):
-        return slot is None or isinstance(slot, _HipPatchNet)
+        return slot is None or isinstance(slot, (_HipPatchNet, _HipHandCrafted))
 
     def enqueue(self, x, do_ori=False, desc=None, det_stream=None, input_ready=None):
         """Enqueues the whole fused path and returns capacity-sized device tensors plus the device row
@@ -83,8 +83,6 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
         torch.cuda.Event = wait for that event only; False = x is already resident (no wait)."""
         ctx = self._context(x, allow_batch=True)
         dev = x.device
-        if do_ori and self.OriNet is None:
-            raise NotImplementedError("default OrientationDetector slot is SURVEY section 8f 'next'; pass OriNet=")
         if not (self._native(self.AffNet) and self._native(self.OriNet)):
             raise NotImplementedError("the fused path needs the native AffNetFast / OriNetFast slots (foreign slots: forward())")
         img = x.contiguous().float()
@@ -95,8 +93,16 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
         count = torch.zeros(B, dtype=torch.int32, device=dev)
         dsc = torch.empty(B, F, 128, dtype=torch.float32, device=dev) if desc is not None else None
         nets = _lib.Nets()
-        nets.d_affnet = self.AffNet.packed_weights(dev).data_ptr() if self.num_Baum_iters > 0 else None
-        nets.d_orinet = self.OriNet.packed_weights(dev).data_ptr() if do_ori else None
+        if self.num_Baum_iters > 0:
+            if isinstance(self.AffNet, _HipHandCrafted):
+                nets.h_baumberg_window = C.cast(self.AffNet.window(), C.c_void_p)
+            else:
+                nets.d_affnet = self.AffNet.packed_weights(dev).data_ptr()
+        if do_ori:
+            if isinstance(self.OriNet, _HipHandCrafted):
+                nets.h_orientation_window = C.cast(self.OriNet.window(), C.c_void_p)
+            else:
+                nets.d_orinet = self.OriNet.packed_weights(dev).data_ptr()
         nets.d_hardnet = desc.packed_weights(dev).data_ptr() if desc is not None else None
         if det_stream is None:
             rc = lib.affnet_extract_features(ctx.handle, C.byref(nets), ptr(img), int(bool(do_ori)), ptr(lafs), ptr(resp), ptr(ids),

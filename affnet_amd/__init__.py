@@ -6,7 +6,7 @@ from . import _lib  # noqa: F401  (raises ImportError when libaffnet_hip.so is m
 from .SparseImgRepresenter import ScaleSpaceAffinePatchExtractor, get_geometry_and_descriptors  # noqa: F401
 from .architectures import AffNetFast, OriNetFast  # noqa: F401
 from .HardNet import HardNet  # noqa: F401
-from . import LAF  # noqa: F401
+from . import LAF, HandCraftedModules, Losses, ReprojectionStuff  # noqa: F401
 from .synthetic import synthetic_image, synthetic_hardnet_state  # noqa: F401
 
 __version__ = "0.1.0"

@@ -32,7 +32,8 @@ class Config(C.Structure):
 
 
 class Nets(C.Structure):
-    _fields_ = [("d_affnet", C.c_void_p), ("d_orinet", C.c_void_p), ("d_hardnet", C.c_void_p)]
+    _fields_ = [("d_affnet", C.c_void_p), ("d_orinet", C.c_void_p), ("d_hardnet", C.c_void_p),
+                ("h_orientation_window", C.c_void_p), ("h_baumberg_window", C.c_void_p)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/affnet_hip.h
@@ -65,6 +66,8 @@ SYMBOLS = {
     "affnet_apply_rotation": (_I, [_P, _P, _P, _P, _I, _P]),
     "affnet_scale_lafs": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "affnet_level_select": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
+    "affnet_handcrafted_forward": (_I, [_P, _I, _P, _I, _P, _P, _P, _P]),
+    "affnet_handcrafted_forward_pyr": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P]),
     "affnet_match_scratch_bytes": (_SZ, [_I, _I]),
     "affnet_distance_matrix": (_I, [_P, _P, _I, _P, _I, _I, _P, _P, _P]),
     "affnet_match_snn": (_I, [_P, _P, _I, _P, _I, _I, C.c_float, _P, _P, _P, _P, _P, _P, _P]),

@@ -108,6 +108,15 @@ int aff_fail(affnet_ctx* ctx, int code, const char* fmt, ...);
 static inline size_t aff_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 static inline int aff_cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// Level pointers of the pyramid of image 0 in the workspace (+ img_stride floats per further image of the batch).
+struct PyrTable {
+    const float* lvl[AFFNET_MAX_OCTAVES][AFFNET_MAX_LEVELS];
+    int h[AFFNET_MAX_OCTAVES], w[AFFNET_MAX_OCTAVES];
+    int n_octaves, n_levels;
+    size_t img_stride;
+};
+void aff_fill_pyr_table(const affnet_ctx* ctx, PyrTable* t);
+
 // ---- sampler math shared by sampler.hip and cnn32.hip -------------------------------------------
 // Host: fills base[ps] = (linspace(-1,1,ps) * (ps-1)) / ps exactly as torch does on CPU
 // (linspace = fma(step, i, start) / fma(-step, ps-1-i, end); verified bit-for-bit in

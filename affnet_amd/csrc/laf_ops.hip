@@ -12,13 +12,6 @@
 
 struct BaseGrid { float v[MAX_PS]; };
 
-struct PyrTable {   // level pointers of the pyramid in the workspace
-    const float* lvl[AFFNET_MAX_OCTAVES][AFFNET_MAX_LEVELS];
-    int h[AFFNET_MAX_OCTAVES], w[AFFNET_MAX_OCTAVES];
-    int n_octaves, n_levels;
-    size_t img_stride;   // floats between the pyramids of consecutive images (batch)
-};
-
 void aff_fill_pyr_table(const affnet_ctx* ctx, PyrTable* t) {
     memset(t, 0, sizeof(*t));
     t->n_octaves = ctx->cfg.n_octaves; t->n_levels = ctx->cfg.levels_per_octave;

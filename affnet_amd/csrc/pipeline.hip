@@ -46,6 +46,10 @@ extern "C" int affnet_profile_read(affnet_ctx* ctx, double sum_ms[AFFNET_PROFILE
 int aff_shape_iterate(affnet_ctx* ctx, const float* A, float* base, const float* lafs, const int32_t* count, int mode, float* lafs_out,
                       hipStream_t st);
 
+// hand-crafted slot fillers (handcrafted.hip)
+int aff_handcrafted_launch(affnet_ctx* ctx, int kind, const float* patches, const float* lafs, const int32_t* ids, const int32_t* count,
+                           int n_max, const float* h_weights, float* out, float* out_angle, hipStream_t st);
+
 // HardNet with a stage mark between trunk and head (cnn32.hip)
 int aff_hardnet_forward_pyr_marked(affnet_ctx* ctx, const float* packed, const float* lafs, const int32_t* ids, const int32_t* count,
                                    int n_max, float* out, float* scratch, hipStream_t st);
@@ -67,7 +71,8 @@ extern "C" int affnet_describe_detected(affnet_ctx* ctx, const affnet_nets* nets
                                         int32_t* d_ids, float* d_desc, int32_t* d_count, void* stream) {
     if (!ctx || !ctx->ws || !nets || !d_lafs_px || !d_resp || !d_ids || !d_count)
         return aff_fail(ctx, AFFNET_ERR_INVALID, "describe_detected: context not bound or null argument");
-    if (do_ori && !nets->d_orinet) return aff_fail(ctx, AFFNET_ERR_INVALID, "describe_detected: do_ori needs OriNet weights");
+    if (do_ori && !nets->d_orinet && !nets->h_orientation_window)
+        return aff_fail(ctx, AFFNET_ERR_INVALID, "describe_detected: do_ori needs OriNet weights or the OrientationDetector window");
     if (d_desc && !nets->d_hardnet) return aff_fail(ctx, AFFNET_ERR_INVALID, "describe_detected: descriptors need HardNet weights");
     hipStream_t st = (hipStream_t)stream;
     const int P = ctx->cap_pre, F = ctx->cap_final;
@@ -75,9 +80,16 @@ extern "C" int affnet_describe_detected(affnet_ctx* ctx, const affnet_nets* nets
     int rc;
     int32_t* det_count = ctx->st_det_count;
     aff_prof_mark(ctx, 2, st);
-    if (nets->d_affnet) {
-        rc = affnet_cnn32_forward_pyr(ctx, AFFNET_NET_AFFNET, nets->d_affnet, ctx->st_det_lafs, ctx->st_det_ids, det_count, P, ctx->st_A,
-                                      nullptr, stream);
+    const bool baumberg = !nets->d_affnet && nets->h_baumberg_window && ctx->cfg.baum_iters > 0;
+    // one shape pass: AffNetFast (32x32 patches, MFMA) or the hand-crafted AffineShapeEstimator (19x19 patches)
+    auto shape_pass = [&](const float* lafs, float* A_out) -> int {
+        if (baumberg)
+            return aff_handcrafted_launch(ctx, AFFNET_HC_BAUMBERG, nullptr, lafs, ctx->st_det_ids, det_count, P, nets->h_baumberg_window, A_out,
+                                          nullptr, st);
+        return affnet_cnn32_forward_pyr(ctx, AFFNET_NET_AFFNET, nets->d_affnet, lafs, ctx->st_det_ids, det_count, P, A_out, nullptr, stream);
+    };
+    if (nets->d_affnet || baumberg) {
+        rc = shape_pass(ctx->st_det_lafs, ctx->st_A);
         if (rc) return rc;
         // num_Baum_iters > 1 (SparseImgRepresenter.py:127-146): base_A = A_i * base_A, patches re-extracted from
         // [base_A * LAF | centre] on the same pyramid level.  st_A holds base_A (= A_0 after the first pass: bmm(A, I) = A).
@@ -85,8 +97,7 @@ extern "C" int affnet_describe_detected(affnet_ctx* ctx, const affnet_nets* nets
         for (int it = 1; it < iters; ++it) {
             rc = aff_shape_iterate(ctx, nullptr, ctx->st_A, ctx->st_det_lafs, det_count, 0, ctx->st_lafs_iter, st);
             if (rc) return rc;
-            rc = affnet_cnn32_forward_pyr(ctx, AFFNET_NET_AFFNET, nets->d_affnet, ctx->st_lafs_iter, ctx->st_det_ids, det_count, P, ctx->st_A2,
-                                          nullptr, stream);
+            rc = shape_pass(ctx->st_lafs_iter, ctx->st_A2);
             if (rc) return rc;
             rc = aff_shape_iterate(ctx, ctx->st_A2, ctx->st_A, ctx->st_det_lafs, det_count, 1, ctx->st_lafs_iter, st);
             if (rc) return rc;
@@ -108,8 +119,12 @@ extern "C" int affnet_describe_detected(affnet_ctx* ctx, const affnet_nets* nets
     }
     aff_prof_mark(ctx, 4, st);
     if (do_ori) {
-        rc = affnet_cnn32_forward_pyr(ctx, AFFNET_NET_ORINET, nets->d_orinet, ctx->st_lafs_shaped, d_ids, d_count, F, ctx->st_R, nullptr,
-                                      stream);
+        if (nets->d_orinet)
+            rc = affnet_cnn32_forward_pyr(ctx, AFFNET_NET_ORINET, nets->d_orinet, ctx->st_lafs_shaped, d_ids, d_count, F, ctx->st_R, nullptr,
+                                          stream);
+        else
+            rc = aff_handcrafted_launch(ctx, AFFNET_HC_ORIENTATION, nullptr, ctx->st_lafs_shaped, d_ids, d_count, F, nets->h_orientation_window,
+                                        ctx->st_R, nullptr, st);
         if (rc) return rc;
         rc = affnet_apply_rotation(ctx, ctx->st_lafs_shaped, ctx->st_R, d_count, F, stream);
         if (rc) return rc;

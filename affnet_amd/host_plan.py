@@ -87,3 +87,24 @@ class PyramidPlan(object):
         c.batch = int(batch)
         c.baum_iters = int(baum_iters)
         return c
+
+
+def circular_gauss_kernel(kernlen=None, circ_zeros=False, sigma=None, norm=True):
+    """Utils.py:92-114 (CircularGaussKernel) under Python-3 semantics: the window of the hand-crafted
+    OrientationDetector / AffineShapeEstimator slots, computed on the host and handed to the kernels as a table."""
+    if kernlen is None:
+        kernlen = int(2.0 * 3.0 * sigma + 1.0)
+        if kernlen % 2 == 0:
+            kernlen = kernlen + 1
+    half = kernlen / 2
+    r2 = float(half * half)
+    sigma2 = 0.9 * r2 if sigma is None else 2.0 * sigma * sigma
+    x = np.linspace(-half, half, kernlen)
+    xv, yv = np.meshgrid(x, x, sparse=False, indexing="xy")
+    distsq = xv ** 2 + yv ** 2
+    kernel = np.exp(-(distsq / sigma2))
+    if circ_zeros:
+        kernel *= (distsq <= r2).astype(np.float32)
+    if norm:
+        kernel /= np.sum(kernel)
+    return kernel

@@ -197,6 +197,21 @@ int affnet_cnn32_debug_layer(affnet_ctx* ctx, int net_kind, const float* d_packe
  * conv layer k = 1..5: 2k+1 MFMA loop done, 2k+2 outputs stored).  NULL switches it off.  Process-global. */
 int affnet_cnn32_debug_timing(unsigned long long* d_stamps);
 
+/* ---- hand-crafted slot fillers --------------------------------------- */
+
+#define AFFNET_HC_ORIENTATION 0   /* HandCraftedModules.py:133-192 OrientationDetector(patch_size=19)    */
+#define AFFNET_HC_BAUMBERG 1      /* HandCraftedModules.py:81-132  AffineShapeEstimator(patch_size=19)   */
+
+/* n 19x19 patches (d_patches (n,19,19) fp32) -> d_out (n,2,2): rotation matrix [[cos,sin],[-sin,cos]] of the dominant
+ * gradient orientation (kind 0; d_angles (n) optional) or the rectified Baumberg shape matrix (kind 1).
+ * h_weights: HOST pointer to the 19x19 Gaussian window (kind 0: 10 * CircularGaussKernel(kernlen=19); kind 1:
+ * CircularGaussKernel(kernlen=19, sigma=19/2/3), Utils.py:92-114 - computed by the host mirror). */
+int affnet_handcrafted_forward(affnet_ctx* ctx, int kind, const float* d_patches, int n, const float* h_weights, float* d_out,
+                               float* d_angles, void* stream);
+/* Same, each patch sampled from the pyramid in the workspace (rows < d_count[image]). */
+int affnet_handcrafted_forward_pyr(affnet_ctx* ctx, int kind, const float* d_lafs, const int32_t* d_ids, const int32_t* d_count,
+                                   int n_max, const float* h_weights, float* d_out, void* stream);
+
 /* ---- LAF stages ---------------------------------------------------------------------------- */
 
 /* base_A = A; new_LAF = [A * LAF_2x2 | centre]; keep rows with 1/6 < |l1/(l2+1e-8)| < 6 and
@@ -260,6 +275,9 @@ typedef struct affnet_nets {
     const float* d_affnet;   /* packed AffNet weights, NULL => num_Baum_iters = 0            */
     const float* d_orinet;   /* packed OriNet weights, NULL => do_ori must be 0              */
     const float* d_hardnet;  /* packed HardNet weights, NULL => no descriptors               */
+    /* The reference's default slot fillers (SparseImgRepresenter.py:42-49), used when the CNN of the slot is NULL:       */
+    const float* h_orientation_window;  /* HOST, 361 floats: OrientationDetector(19) when do_ori and d_orinet == NULL     */
+    const float* h_baumberg_window;     /* HOST, 361 floats: AffineShapeEstimator(19) when baum_iters > 0, d_affnet NULL   */
 } affnet_nets;
 
 /* Whole path, image resident -> results resident, zero host synchronisation:

@@ -430,8 +430,12 @@ def synthetic_hardnet_state(seed=0):
 
 class OracleExtractor(object):
     """Restates ScaleSpaceAffinePatchExtractor (SparseImgRepresenter.py:14-209) for the
-    configuration the hot path uses: RespNet = HessianResp, AffNet = AffNetFast state dict
-    (or None -> num_Baum_iters must be 0), OriNet = OriNetFast state dict."""
+    configuration the hot path uses: RespNet = HessianResp, AffNet = AffNetFast state dict, OriNet = OriNetFast state
+    dict.  Without a state dict the reference's default slot fillers are used (SparseImgRepresenter.py:42-49):
+    OrientationDetector(patch_size=19) and AffineShapeEstimator(patch_size=19) - the latter called as
+    `AffNet(patches)`: as shipped, batched_forward passes a kwargs dict positionally (Utils.py:54) which
+    AffineShapeEstimator.forward(self, x) rejects with a TypeError, so the Baumberg path is pinned against the reference
+    class behind a one-line `forward(self, x, *ignored)` shim (tests/golden/make_golden_handcrafted.py)."""
 
     def __init__(self, border=16, num_features=500, patch_size=32, mrSize=3.0, nlevels=3,
                  num_Baum_iters=0, init_sigma=1.6, th=None, affnet_sd=None, orinet_sd=None,
@@ -452,15 +456,17 @@ class OracleExtractor(object):
     def _affine_shape(self, det, n_out):
         """SparseImgRepresenter.py:113-165 for num_Baum_iters == 1 ... k."""
         resp, lafs, octs, levs, pixs = det["resp"], det["lafs"], det["oct"], det["lev"], det["pix"]
-        patches = extract_from_pyramid(self.scale_pyr, octs, levs, lafs, self.PS)
+        ps = self.PS if self.aff is not None else 19
+        shape = (lambda p: affnet_batched(self.aff, p, 256)) if self.aff is not None else affine_shape_estimator
+        patches = extract_from_pyramid(self.scale_pyr, octs, levs, lafs, ps)
         base = torch.eye(2).unsqueeze(0).expand(lafs.size(0), 2, 2)
         new = lafs
         for i in range(self.iters):
-            A = affnet_batched(self.aff, patches, 256)
+            A = shape(patches)
             base = torch.bmm(A, base)
             new = torch.cat([torch.bmm(base, lafs[:, :, 0:2]), lafs[:, :, 2:]], dim=2)
             if i != self.iters - 1:
-                patches = extract_from_pyramid(self.scale_pyr, octs, levs, new, self.PS)
+                patches = extract_from_pyramid(self.scale_pyr, octs, levs, new, ps)
         l1, l2 = eig2x2(base)
         ratio = torch.abs(l1 / (l2 + 1e-8))
         good = ((ratio < 6.0) & (ratio > (1.0 / 6.0))) & inside_image(new)
@@ -475,11 +481,12 @@ class OracleExtractor(object):
 
     def _orientation(self, lafs, octs, levs):
         """SparseImgRepresenter.py:167-180."""
-        patches = extract_from_pyramid(self.scale_pyr, octs, levs, lafs, self.PS)
-        R = orinet_forward(self.ori, patches)
+        ps = self.PS if self.ori is not None else 19
+        patches = extract_from_pyramid(self.scale_pyr, octs, levs, lafs, ps)
+        R = orinet_forward(self.ori, patches) if self.ori is not None else angles_to_rotation(orientation_detector(patches))
         lafs = torch.cat([torch.bmm(lafs[:, :, :2], R), lafs[:, :, 2:]], dim=2)
         if self.waste:  # :178-179, result discarded by the reference
-            extract_from_pyramid(self.scale_pyr, octs, levs, lafs, self.PS)
+            extract_from_pyramid(self.scale_pyr, octs, levs, lafs, ps)
         return lafs
 
     def forward(self, x, do_ori=False):
@@ -647,3 +654,92 @@ def match_and_verify(lafs1, desc1, lafs2, desc2, H1to2, snn_threshold=0.8, dist_
     md, idx, md2, t1, t2 = match_snn(desc1, desc2, snn_threshold)
     gd, plain, in2 = get_gt_correspondence_indexes(lafs1[t1], lafs2[t2], H1to2, dist_threshold)
     return dict(min_dist=md, idx=idx, min_2nd=md2, tent1=t1, tent2=t2, gt_dist=gd, gt_plain=plain, gt_idx=in2)
+
+
+# ----------------------------------------------------------------------------------------
+# the hand-crafted default slot fillers
+# ----------------------------------------------------------------------------------------
+
+
+def circular_gauss_kernel(kernlen=None, circ_zeros=False, sigma=None, norm=True):
+    """Utils.py:92-114 under Python 3 (`kernlen / 2` is a true division)."""
+    if kernlen is None:
+        kernlen = int(2.0 * 3.0 * sigma + 1.0)
+        if kernlen % 2 == 0:
+            kernlen = kernlen + 1
+    half = kernlen / 2
+    r2 = float(half * half)
+    sigma2 = 0.9 * r2 if sigma is None else 2.0 * sigma * sigma
+    x = np.linspace(-half, half, kernlen)
+    xv, yv = np.meshgrid(x, x, sparse=False, indexing="xy")
+    distsq = xv ** 2 + yv ** 2
+    kernel = np.exp(-(distsq / sigma2))
+    if circ_zeros:
+        kernel *= (distsq <= r2).astype(np.float32)
+    if norm:
+        kernel /= np.sum(kernel)
+    return kernel
+
+
+def orientation_detector(x, num_ang_bins=36):
+    """Dominant gradient orientation of (n,1,PS,PS) patches -> angles (n,).  HandCraftedModules.py:133-192
+    (OrientationDetector.forward): only the lower bin bo0 is accumulated (with weight (1 - wo1) * mag), the smoothing conv1d
+    zero-pads (not circular), argmax -> angle = -(2 pi idx / 36 - pi)."""
+    ps = x.size(2)
+    wx = torch.tensor([[[[0.5, 0, -0.5]]]])
+    wy = torch.tensor([[[[0.5], [0], [-0.5]]]])
+    gk = 10.0 * torch.from_numpy(circular_gauss_kernel(kernlen=ps).astype(np.float32))
+    gx = F.conv2d(F.pad(x, (1, 1, 0, 0), "replicate"), wx)
+    gy = F.conv2d(F.pad(x, (0, 0, 1, 1), "replicate"), wy)
+    mag = torch.sqrt(gx * gx + gy * gy + 1e-10)
+    mag = mag * gk.unsqueeze(0).unsqueeze(0).expand_as(mag)
+    ori = torch.atan2(gy, gx)
+    o_big = float(num_ang_bins) * (ori + 1.0 * math.pi) / (2.0 * math.pi)
+    bo0 = torch.floor(o_big)
+    wo1 = o_big - bo0
+    bo0 = bo0 % num_ang_bins
+    wo0 = (1.0 - wo1) * mag
+    bins = [F.adaptive_avg_pool2d((bo0 == i).float() * wo0, (1, 1)) for i in range(num_ang_bins)]
+    bins = torch.cat(bins, 1).view(-1, 1, num_ang_bins)
+    bins = F.conv1d(bins, torch.tensor([[[0.33, 0.34, 0.33]]]), padding=1)
+    _, idx = bins.view(-1, num_ang_bins).max(1)
+    return -((2.0 * float(np.pi) * idx.float() / float(num_ang_bins)) - float(math.pi))
+
+
+def angles_to_rotation(angles):
+    """LAF.py:306-311 (angles2A)."""
+    c, s = torch.cos(angles).view(-1, 1, 1), torch.sin(angles).view(-1, 1, 1)
+    return torch.cat([torch.cat([c, s], dim=2), torch.cat([-s, c], dim=2)], dim=1)
+
+
+def affine_shape_estimator(x):
+    """Baumberg second-moment shape of (n,1,PS,PS) patches -> rectified (n,2,2).  HandCraftedModules.py:81-132
+    (AffineShapeEstimator.forward + invSqrt) + LAF.py:299-302 (abc2A) + :285-291 (rectify)."""
+    ps = x.size(2)
+    wx = torch.tensor([[[[-1.0, 0, 1.0]]]])
+    wy = torch.tensor([[[[-1.0], [0], [1.0]]]])
+    gk = torch.from_numpy(circular_gauss_kernel(kernlen=ps, sigma=(ps / 2) / 3.0).astype(np.float32))
+    gx = F.conv2d(F.pad(x, (1, 1, 0, 0), "replicate"), wx)
+    gy = F.conv2d(F.pad(x, (0, 0, 1, 1), "replicate"), wy)
+    g = gk.unsqueeze(0).unsqueeze(0).expand_as(gx)
+    a = (gx * gx * g).view(x.size(0), -1).mean(dim=1)
+    b = (gx * gy * g).view(x.size(0), -1).mean(dim=1)
+    c = (gy * gy * g).view(x.size(0), -1).mean(dim=1)
+    eps = 1e-12
+    mask = (b != 0).float()
+    r1 = mask * (c - a) / (2.0 * b + eps)
+    t1 = torch.sign(r1) / (torch.abs(r1) + torch.sqrt(1.0 + r1 * r1))
+    r = 1.0 / torch.sqrt(1.0 + t1 * t1)
+    t = t1 * r
+    r = r * mask + 1.0 * (1.0 - mask)
+    t = t * mask
+    xx = 1.0 / torch.sqrt(r * r * a - 2.0 * r * t * b + t * t * c)
+    zz = 1.0 / torch.sqrt(t * t * a + 2.0 * r * t * b + r * r * c)
+    d = torch.sqrt(xx * zz)
+    xx = xx / d
+    zz = zz / d
+    na = r * r * xx + t * t * zz
+    nb = -r * t * xx + t * r * zz
+    nc = t * t * xx + r * r * zz
+    A = torch.cat([torch.cat([na.view(-1, 1, 1), nb.view(-1, 1, 1)], dim=2), torch.cat([nb.view(-1, 1, 1), nc.view(-1, 1, 1)], dim=2)], dim=1)
+    return rectify_up_is_up(A)

@@ -402,6 +402,38 @@ def test_iterated_affnet_shape(amd, nets, weights, iters):
     assert L1.shape != res["LAFs"].shape or float((L1 - res["LAFs"]).abs().max()) > 1e-3
 
 
+def test_handcrafted_default_slots(amd, nets, golden_dir):
+    """OrientationDetector / AffineShapeEstimator kernels against the unmodified reference classes
+    (golden) - unit level, the default-constructed extractor, and 4 Baumberg iterations."""
+    from affnet_amd.HandCraftedModules import OrientationDetector, AffineShapeEstimator
+    g = np.load(os.path.join(golden_dir, "handcrafted_slots.npz"))
+    p = torch.from_numpy(g["patches"]).to(DEV)
+    ang = OrientationDetector(patch_size=19)(p).cpu().numpy()
+    same = np.abs(ang - g["ori_angles"]) < 1e-6
+    print("orientation: %d / %d angles identical" % (same.sum(), len(same)))
+    assert same.mean() >= 0.95                    # argmax over 36 smoothed bins: only near-ties may flip (summation order)
+    R = OrientationDetector(patch_size=19)(p, return_rot_matrix=True).cpu()
+    assert np.abs(R.numpy()[same] - orc.angles_to_rotation(torch.from_numpy(g["ori_angles"])).numpy()[same]).max() < 1e-6
+    A = AffineShapeEstimator(patch_size=19)(p).cpu().numpy()
+    _report("Baumberg shape", A, g["baum_A"])
+    assert np.abs(A - g["baum_A"]).max() < 2e-5
+    x = orc.synthetic_image(240, 320, 1).to(DEV)
+    det = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=0).to(DEV)     # default slots
+    L, r = det(x, do_ori=True)
+    assert np.array_equal(r.cpu().numpy(), g["default_resp"])
+    row_err = np.abs(L.cpu().numpy() - g["default_LAFs"]).reshape(len(L), -1).max(axis=1)
+    print("default extractor: rows within 1e-3 px %.4f (a flipped orientation bin rotates the frame)" % (row_err < 1e-3).mean())
+    assert (row_err < 1e-3).mean() >= 0.97
+    # frames that differ must differ by a pure rotation: same centre, same determinant
+    assert np.abs(L.cpu().numpy()[:, :, 2] - g["default_LAFs"][:, :, 2]).max() < 1e-3
+    det = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=4).to(DEV)
+    L, r = det(x, do_ori=False)
+    assert L.shape == g["baum4_LAFs"].shape and np.array_equal(r.cpu().numpy(), g["baum4_resp"])
+    row_err = np.abs(L.cpu().numpy() - g["baum4_LAFs"]).reshape(len(L), -1).max(axis=1)
+    print("Baumberg x4: worst row %.3g px, rows within 1e-3 px %.4f" % (row_err.max(), (row_err < 1e-3).mean()))
+    assert (row_err < 1e-3).mean() >= 0.99
+
+
 def test_matching_snn_and_homography_check(amd, golden_dir):
     """SURVEY section 8f row 1 (test() of train_AffNet_test_on_graffity.py:290-305): MFMA distance / SNN ratio kernel and the
     homography consistency check against the reference's golden outputs and the oracle."""

@@ -153,14 +153,28 @@ def test_no_cpu_fallback_and_unbuilt_slots_fail_loudly(weights):
     det = affnet_amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=100, border=5, num_Baum_iters=1, AffNet=A)
     with pytest.raises(RuntimeError, match="no CPU path"):
         det(torch.zeros(1, 1, 64, 64))
+    dflt = affnet_amd.ScaleSpaceAffinePatchExtractor(num_Baum_iters=1)    # default slots as in SparseImgRepresenter.py:42-49
+    assert type(dflt.AffNet).__name__ == "AffineShapeEstimator" and type(dflt.OriNet).__name__ == "OrientationDetector"
+    assert dflt.AffNet.PS == 19 and dflt.OriNet.PS == 19
     with pytest.raises(NotImplementedError):
-        affnet_amd.ScaleSpaceAffinePatchExtractor(num_Baum_iters=1)           # Baumberg default slot: section 8f
+        affnet_amd.HandCraftedModules.OrientationDetector()                   # reference default PS = 32: kernels are for 19
     with pytest.raises(NotImplementedError):
         affnet_amd.ScaleSpaceAffinePatchExtractor(RespNet=lambda x, s: x)
+    with pytest.raises(NotImplementedError):
+        affnet_amd.ScaleSpaceAffinePatchExtractor(nlevels=4)
     d = affnet_amd.ScaleSpaceAffinePatchExtractor(th=28.41)
     assert d.num == -1                                                        # SparseImgRepresenter.py:33-35
     with pytest.raises(RuntimeError, match="forward"):
         d.extract_patches_from_pyr(torch.zeros(1, 2, 3))
+
+
+def test_handcrafted_windows_match_the_reference_formula():
+    """The Gaussian windows of the hand-crafted slots are host tables: they must equal the oracle's CircularGaussKernel."""
+    from affnet_amd.HandCraftedModules import OrientationDetector, AffineShapeEstimator
+    w = np.array(list(OrientationDetector(patch_size=19).window()), dtype=np.float32)
+    assert np.array_equal(w, (10.0 * orc.circular_gauss_kernel(kernlen=19)).astype(np.float32).reshape(-1))
+    w = np.array(list(AffineShapeEstimator(patch_size=19).window()), dtype=np.float32)
+    assert np.array_equal(w, orc.circular_gauss_kernel(kernlen=19, sigma=(19 / 2) / 3.0).astype(np.float32).reshape(-1))
 
 
 def test_exact_arithmetic_spec_of_the_blur():

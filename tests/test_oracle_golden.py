@@ -116,3 +116,20 @@ def test_matching_restatement_vs_reference_golden(golden_dir):
     gd, plain, in2 = orc.get_gt_correspondence_indexes(L1[torch.from_numpy(g["tent1"])], L2[torch.from_numpy(g["tent2"])], H, 6)
     assert np.array_equal(plain.numpy(), g["gt_plain"]) and np.array_equal(in2.numpy(), g["gt_idx"])
     assert np.abs(gd.numpy() - g["gt_dist"]).max() < 0.05      # the fp32 |a|^2+|b|^2-2ab expansion is that noisy at ~800 px
+
+
+def test_handcrafted_slot_fillers_vs_reference_golden(golden_dir):
+    """OrientationDetector / AffineShapeEstimator restatements and the default-constructed extractor
+    (no AffNet / OriNet arguments) against the unmodified reference classes (tests/golden/make_golden_handcrafted.py)."""
+    g = np.load(os.path.join(golden_dir, "handcrafted_slots.npz"))
+    p = torch.from_numpy(g["patches"])
+    with torch.no_grad():
+        assert np.array_equal(orc.orientation_detector(p).numpy(), g["ori_angles"])
+        assert np.abs(orc.affine_shape_estimator(p).numpy() - g["baum_A"]).max() < 1e-6
+    x = orc.synthetic_image(240, 320, 1)
+    ex = orc.OracleExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=0)
+    L, r = ex(x, do_ori=True)
+    assert np.array_equal(r.numpy(), g["default_resp"]) and np.abs(L.numpy() - g["default_LAFs"]).max() < 1e-4
+    ex = orc.OracleExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=4)
+    L, r = ex(x, do_ori=False)
+    assert np.array_equal(r.numpy(), g["baum4_resp"]) and np.abs(L.numpy() - g["baum4_LAFs"]).max() < 1e-3
