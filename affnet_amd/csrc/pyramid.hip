@@ -8,15 +8,19 @@
 // result (DESIGN.md "bit-exact detector"); a separable blur would be ~6x fewer MACs but moves
 // levels by ~2e-4 and flips keypoints.
 //
-// Layout: one workgroup = 256 threads = 64 x 16 output tile; each thread owns 4 consecutive
-// output columns of one row and slides a (K+3)-wide register window over the LDS tile
-// (16-byte LDS reads), so one LDS row read feeds 4 x K fmaf.  Taps arrive as a by-value kernel
-// argument (scalar loads -> SGPR operands of v_fmac_f32).  Optional fused stride-2 decimation
-// writes the next octave's level 0 (F.avg_pool2d(k=1, s=2), HandCraftedModules.py:46-47).
+// Layout: one workgroup = 256 threads = 64 x 64 output tile; each thread owns a 4 (columns) x 4 (rows) register tile and
+// walks the 4 + K - 1 input rows it needs once: one (K+3)-wide register window per input row (16-byte LDS reads) feeds
+// up to 4 x 4 x K fmaf.  Input rows arrive in ascending order, so every output pixel still accumulates its taps in
+// row-major order - the chain is unchanged, only shared loads are reused (the 1-row version was LDS-bound: 1.45 LDS bytes per
+// fmaf, SQ_LDS_BANK_CONFLICT 62 % of LDS cycles; this one reads a quarter of that and its row stride == 0 (mod 16 floats)
+// is conflict free for ds_read_b128).  Taps arrive as a by-value kernel argument (scalar loads -> SGPR operands of
+// v_fmac_f32).  Optional fused stride-2 decimation writes the next octave's level 0 (F.avg_pool2d(k=1, s=2),
+// HandCraftedModules.py:46-47).
 #include "common.h"
 
 #define BT_X 64
-#define BT_Y 16
+#define BT_Y 64
+#define BT_R 4          // output rows per thread
 
 template <int K>
 struct Taps { float w[K * K]; };
@@ -27,14 +31,15 @@ __global__ __launch_bounds__(256) void blur2d_kernel(const float* __restrict__ i
                                                      size_t out_stride, Taps<K> taps) {
     constexpr int R = K / 2;
     constexpr int LW = BT_X + 2 * R;               // tile width incl. halo
-    constexpr int LS = (LW + 3) & ~3;              // row stride, multiple of 4 floats (16-B aligned rows)
+    constexpr int LS = (LW + 15) & ~15;            // row stride: multiple of 16 floats (16-B aligned rows, conflict-free b128)
     constexpr int LH = BT_Y + 2 * R;
     __shared__ __attribute__((aligned(16))) float tile[LH * LS];
     const int x0 = blockIdx.x * BT_X, y0 = blockIdx.y * BT_Y;
     in += blockIdx.z * in_stride;                   // blockIdx.z = image of the batch
     out += blockIdx.z * out_stride;
     if (dec_out) dec_out += blockIdx.z * out_stride;
-    for (int i = threadIdx.x; i < LH * LW; i += 256) {
+    const int rows_needed = min(LH, h - y0 + 2 * R);           // tiles at the bottom edge: skip rows nobody reads
+    for (int i = threadIdx.x; i < rows_needed * LW; i += 256) {
         const int ty = i / LW, tx = i - ty * LW;
         int gy = y0 + ty - R, gx = x0 + tx - R;
         gy = gy < 0 ? 0 : (gy >= h ? h - 1 : gy);   // replicate padding
@@ -42,13 +47,17 @@ __global__ __launch_bounds__(256) void blur2d_kernel(const float* __restrict__ i
         tile[ty * LS + tx] = in[(size_t)gy * w + gx];
     }
     __syncthreads();
-    const int tx = (threadIdx.x & 15) * 4, ty = threadIdx.x >> 4;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const int tx = (threadIdx.x & 15) * 4, ty = (threadIdx.x >> 4) * BT_R;
+    if (y0 + ty >= h) return;
+    float acc[BT_R][4];
+#pragma unroll
+    for (int rr = 0; rr < BT_R; ++rr)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[rr][q] = 0.f;
     constexpr int NV = (K + 3 + 3) / 4;            // float4 loads covering K+3 values
-    // Row loop stays rolled: one (K+3)-wide register window + K scalar taps per iteration keeps the kernel
-    // at <= 64 VGPRs (8 waves/SIMD); fully unrolled it needed 255 VGPRs and ran at 1 wave/SIMD.
+    // Input-row loop stays rolled (register window + K scalar taps per (row, output row) pair).
 #pragma unroll 1
-    for (int i = 0; i < K; ++i) {
+    for (int i = 0; i < BT_R + K - 1; ++i) {
         float r[NV * 4];
         const float4* row = reinterpret_cast<const float4*>(&tile[(ty + i) * LS + tx]);
 #pragma unroll
@@ -57,22 +66,38 @@ __global__ __launch_bounds__(256) void blur2d_kernel(const float* __restrict__ i
             r[4 * v] = q.x; r[4 * v + 1] = q.y; r[4 * v + 2] = q.z; r[4 * v + 3] = q.w;
         }
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const float wt = taps.w[i * K + j];
-            a0 = fmaf(r[j], wt, a0);
-            a1 = fmaf(r[j + 1], wt, a1);
-            a2 = fmaf(r[j + 2], wt, a2);
-            a3 = fmaf(r[j + 3], wt, a3);
+        for (int rr = 0; rr < BT_R; ++rr) {
+            const int ti = i - rr;                  // tap row for output row rr (uniform across the workgroup)
+            if (ti < 0 || ti >= K) continue;
+#pragma unroll
+            for (int j = 0; j < K; ++j) {
+                const float wt = taps.w[ti * K + j];
+                acc[rr][0] = fmaf(r[j], wt, acc[rr][0]);
+                acc[rr][1] = fmaf(r[j + 1], wt, acc[rr][1]);
+                acc[rr][2] = fmaf(r[j + 2], wt, acc[rr][2]);
+                acc[rr][3] = fmaf(r[j + 3], wt, acc[rr][3]);
+            }
         }
     }
-    const int y = y0 + ty, x = x0 + tx;
-    if (y >= h) return;
-    const float res[4] = {a0, a1, a2, a3};
+    const int x = x0 + tx;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        if (x + q < w) {
-            out[(size_t)y * w + x + q] = res[q];
-            if (dec_out && !(y & 1) && !((x + q) & 1)) dec_out[(size_t)(y >> 1) * w2 + ((x + q) >> 1)] = res[q];
+    for (int rr = 0; rr < BT_R; ++rr) {
+        const int y = y0 + ty + rr;
+        if (y >= h) break;
+        if (x + 3 < w && (w & 3) == 0 && ((size_t)out & 15) == 0) {
+            *reinterpret_cast<float4*>(&out[(size_t)y * w + x]) = make_float4(acc[rr][0], acc[rr][1], acc[rr][2], acc[rr][3]);
+            if (dec_out && !(y & 1)) {
+                dec_out[(size_t)(y >> 1) * w2 + (x >> 1)] = acc[rr][0];
+                dec_out[(size_t)(y >> 1) * w2 + (x >> 1) + 1] = acc[rr][2];
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if (x + q < w) {
+                    out[(size_t)y * w + x + q] = acc[rr][q];
+                    if (dec_out && !(y & 1) && !((x + q) & 1)) dec_out[(size_t)(y >> 1) * w2 + ((x + q) >> 1)] = acc[rr][q];
+                }
+            }
         }
     }
 }
