@@ -47,6 +47,18 @@ def normalizeLAFs(LAFs, w, h):
     return _scale(LAFs, w, h, 1)
 
 
+def LAFs2ellT(LAFs):
+    """(n,2,3) cuda pixel LAFs -> (n,5) Oxford ellipses on the device (LAF.py:35-51, closed-form 2x2 SVD :106-144)."""
+    engine.require_cuda(LAFs, "LAFs")
+    lafs = LAFs.contiguous().float()
+    n = lafs.size(0)
+    out = torch.zeros(n, 5, dtype=torch.float32, device=lafs.device)
+    if n:
+        ctx = engine.utility_ctx(lafs.device)
+        check(lib.affnet_lafs_to_ellipses(ctx, ptr(lafs), None, n, ptr(out), engine.stream_of(lafs.device)), ctx, "affnet_lafs_to_ellipses")
+    return out
+
+
 def convertLAFs_to_A23format(LAFs):
     sh = LAFs.shape
     if len(sh) == 3 and sh[1] == 2 and sh[2] == 3:

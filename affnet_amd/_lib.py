@@ -65,6 +65,7 @@ SYMBOLS = {
     "affnet_shape_filter_select": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "affnet_apply_rotation": (_I, [_P, _P, _P, _P, _I, _P]),
     "affnet_scale_lafs": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "affnet_lafs_to_ellipses": (_I, [_P, _P, _P, _I, _P, _P]),
     "affnet_level_select": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     "affnet_handcrafted_forward": (_I, [_P, _I, _P, _I, _P, _P, _P, _P]),
     "affnet_handcrafted_forward_pyr": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P]),

@@ -350,3 +350,43 @@ extern "C" int affnet_level_select(affnet_ctx* ctx, const float* d_lafs_px, cons
     AFF_LAUNCH_CHECK(ctx);
     return AFFNET_OK;
 }
+
+// ---- LAF -> Oxford ellipse on the device ----------------------------------------------------
+// Replaces LAF.py:35-51 (LAFs2ellT) + :106-144 (bsvd2x2, closed-form batched 2x2 SVD), operation by operation in fp32.
+__global__ void lafs2ell_kernel(const float* __restrict__ lafs, const int32_t* __restrict__ d_count, int n_max, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t bi = blockIdx.y;
+    const int n = d_count ? min(d_count[bi], n_max) : n_max;
+    if (i >= n_max) return;
+    float* E = out + 5 * (bi * n_max + i);
+    if (i >= n) { E[0] = E[1] = E[2] = E[3] = E[4] = 0.f; return; }
+    const float* L = lafs + 6 * (bi * n_max + i);
+    const float scale = sqrtf((L[0] * L[4] - L[1] * L[3]) + 1e-10f);
+    const float a00 = L[0] / scale, a01 = L[1] / scale, a10 = L[3] / scale, a11 = L[4] / scale;
+    // Su = As * As^T (bmm: k ascending, fused accumulate)
+    const float su00 = fmaf(a01, a01, a00 * a00), su01 = fmaf(a01, a11, a00 * a10), su10 = fmaf(a11, a01, a10 * a00),
+                su11 = fmaf(a11, a11, a10 * a10);
+    const float phi = 0.5f * atan2f((su01 + su10) + 1e-12f, (su00 - su11) + 1e-12f);
+    const float cp = cosf(phi), sp = sinf(phi);                       // U = [[cp, -sp], [sp, cp]]
+    const float susum = su00 + su11;
+    const float dif = su00 - su11;
+    const float sudif = sqrtf((dif * dif + (4.0f * su01) * su10) + 1e-12f);
+    const float sig0 = sqrtf((susum + sudif) / 2.0f), sig1 = sqrtf((susum - sudif) / 2.0f);
+    // W' = diag(1 / (scale^2 sig^2));  A = U W' U^T
+    const float w0 = 1.0f / ((scale * scale) * (sig0 * sig0)), w1 = 1.0f / ((scale * scale) * (sig1 * sig1));
+    // (U W')[r][c] = U[r][c] * w_c (bmm with a diagonal: the other term is an exact +0)
+    const float m00 = cp * w0, m01 = -sp * w1, m10 = sp * w0, m11 = cp * w1;
+    // A = M U^T : A[r][c] = M[r][0] U[c][0] + M[r][1] U[c][1]
+    E[0] = L[2]; E[1] = L[5];
+    E[2] = fmaf(m01, -sp, m00 * cp);
+    E[3] = fmaf(m01, cp, m00 * sp);
+    E[4] = fmaf(m11, cp, m10 * sp);
+}
+
+extern "C" int affnet_lafs_to_ellipses(affnet_ctx* ctx, const float* d_lafs, const int32_t* d_count, int n_max, float* d_out, void* stream) {
+    if (!ctx || !d_lafs || !d_out || n_max < 0) return aff_fail(ctx, AFFNET_ERR_INVALID, "lafs_to_ellipses: bad argument");
+    if (n_max == 0) return AFFNET_OK;
+    hipLaunchKernelGGL(lafs2ell_kernel, dim3(aff_cdiv(n_max, 256), ctx->B), dim3(256), 0, (hipStream_t)stream, d_lafs, d_count, n_max, d_out);
+    AFF_LAUNCH_CHECK(ctx);
+    return AFFNET_OK;
+}

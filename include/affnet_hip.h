@@ -234,6 +234,10 @@ int affnet_apply_rotation(affnet_ctx* ctx, float* d_lafs, const float* d_R, cons
 int affnet_scale_lafs(affnet_ctx* ctx, const float* d_in, float* d_out, const int32_t* d_count, int n_max,
                       int w, int h, int inverse, void* stream);
 
+/* Pixel LAFs (n,2,3) -> Oxford ellipses (n,5) = x y a b c with [a b; b c] = (A A^T)^-1 through the closed-form 2x2 SVD.
+ * Replaces LAF.py:35-51 (LAFs2ellT) + :106-144 (bsvd2x2).  Rows >= count are zero. */
+int affnet_lafs_to_ellipses(affnet_ctx* ctx, const float* d_lafs, const int32_t* d_count, int n_max, float* d_out, void* stream);
+
 /* Pyramid level for descriptor patches: argmin over (o,l) of |sigma[o][l]*2^o - sqrt|det A|/PS|
  * in float64, first minimum wins; also writes normalised LAFs (by pyr[0][0] size).
  * Replaces LAF.py:450-472 (host scipy cdist round trip) + SparseImgRepresenter.py:181-188.

@@ -743,3 +743,43 @@ def affine_shape_estimator(x):
     nc = t * t * xx + r * r * zz
     A = torch.cat([torch.cat([na.view(-1, 1, 1), nb.view(-1, 1, 1)], dim=2), torch.cat([nb.view(-1, 1, 1), nc.view(-1, 1, 1)], dim=2)], dim=1)
     return rectify_up_is_up(A)
+
+
+# ----------------------------------------------------------------------------------------
+# LAF -> Oxford ellipse on tensors
+# ----------------------------------------------------------------------------------------
+
+
+def bsvd2x2(As):
+    """Batched closed-form 2x2 SVD.  LAF.py:106-144."""
+    Su = torch.bmm(As, As.permute(0, 2, 1))
+    phi = 0.5 * torch.atan2(Su[:, 0, 1] + Su[:, 1, 0] + 1e-12, Su[:, 0, 0] - Su[:, 1, 1] + 1e-12)
+    U = torch.zeros(As.size(0), 2, 2)
+    U[:, 0, 0] = torch.cos(phi); U[:, 1, 1] = torch.cos(phi); U[:, 0, 1] = -torch.sin(phi); U[:, 1, 0] = torch.sin(phi)
+    Sw = torch.bmm(As.permute(0, 2, 1), As)
+    theta = 0.5 * torch.atan2(Sw[:, 0, 1] + Sw[:, 1, 0] + 1e-12, Sw[:, 0, 0] - Sw[:, 1, 1] + 1e-12)
+    W = torch.zeros(As.size(0), 2, 2)
+    W[:, 0, 0] = torch.cos(theta); W[:, 1, 1] = torch.cos(theta); W[:, 0, 1] = -torch.sin(theta); W[:, 1, 0] = torch.sin(theta)
+    SUsum = Su[:, 0, 0] + Su[:, 1, 1]
+    SUdif = torch.sqrt((Su[:, 0, 0] - Su[:, 1, 1]) ** 2 + 4 * Su[:, 0, 1] * Su[:, 1, 0] + 1e-12)
+    SIG = torch.zeros(As.size(0), 2, 2)
+    SIG[:, 0, 0] = torch.sqrt((SUsum + SUdif) / 2.0)
+    SIG[:, 1, 1] = torch.sqrt((SUsum - SUdif) / 2.0)
+    S = torch.bmm(torch.bmm(U.permute(0, 2, 1), As), W)
+    C = torch.sign(S)
+    C[:, 0, 1] = 0
+    C[:, 1, 0] = 0
+    return U, SIG, torch.bmm(W, C)
+
+
+def lafs_to_ellipses_t(lafs):
+    """(n,2,3) pixel LAFs -> (n,5) Oxford ellipses x y a b c on tensors.  LAF.py:35-51 (LAFs2ellT)."""
+    ell = torch.zeros((len(lafs), 5))
+    scale = torch.sqrt(lafs[:, 0, 0] * lafs[:, 1, 1] - lafs[:, 0, 1] * lafs[:, 1, 0] + 1e-10)
+    u, W, _ = bsvd2x2(lafs[:, 0:2, 0:2] / scale.view(-1, 1, 1).repeat(1, 2, 2))
+    W[:, 0, 0] = 1.0 / (scale * scale * W[:, 0, 0] ** 2)
+    W[:, 1, 1] = 1.0 / (scale * scale * W[:, 1, 1] ** 2)
+    A = torch.bmm(torch.bmm(u, W), u.permute(0, 2, 1))
+    ell[:, 0], ell[:, 1] = lafs[:, 0, 2], lafs[:, 1, 2]
+    ell[:, 2], ell[:, 3], ell[:, 4] = A[:, 0, 0], A[:, 0, 1], A[:, 1, 1]
+    return ell

@@ -35,6 +35,7 @@ def main():
     with torch.no_grad(), rh.quiet():
         L, r = det(x, do_ori=True)
     out["default_LAFs"], out["default_resp"] = L.numpy(), r.numpy()
+    out["default_ellT"] = ns.LAF.LAFs2ellT(L.clone()).numpy()            # LAF.py:35-51
 
     class BaumShim(HC.AffineShapeEstimator):
         def forward(self, x, *ignored):

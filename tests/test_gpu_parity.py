@@ -426,6 +426,11 @@ def test_handcrafted_default_slots(amd, nets, golden_dir):
     assert (row_err < 1e-3).mean() >= 0.97
     # frames that differ must differ by a pure rotation: same centre, same determinant
     assert np.abs(L.cpu().numpy()[:, :, 2] - g["default_LAFs"][:, :, 2]).max() < 1e-3
+    # LAFs2ellT (section 8f row 3) on the reference's own LAFs
+    ell = amd.LAF.LAFs2ellT(torch.from_numpy(g["default_LAFs"]).to(DEV)).cpu().numpy()
+    rel = np.abs(ell - g["default_ellT"]) / (np.abs(g["default_ellT"]) + 1e-6 * np.abs(g["default_ellT"]).max())
+    print("LAFs2ellT: worst relative error %.3g" % rel.max())
+    assert rel.max() < 2e-4 and np.array_equal(ell[:, :2], g["default_ellT"][:, :2])
     det = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=4).to(DEV)
     L, r = det(x, do_ori=False)
     assert L.shape == g["baum4_LAFs"].shape and np.array_equal(r.cpu().numpy(), g["baum4_resp"])

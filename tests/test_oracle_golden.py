@@ -130,6 +130,8 @@ def test_handcrafted_slot_fillers_vs_reference_golden(golden_dir):
     ex = orc.OracleExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=0)
     L, r = ex(x, do_ori=True)
     assert np.array_equal(r.numpy(), g["default_resp"]) and np.abs(L.numpy() - g["default_LAFs"]).max() < 1e-4
+    ell = orc.lafs_to_ellipses_t(torch.from_numpy(g["default_LAFs"])).numpy()          # LAFs2ellT (LAF.py:35-51)
+    assert np.abs(ell - g["default_ellT"]).max() <= 1e-6 * np.abs(g["default_ellT"]).max()
     ex = orc.OracleExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=4)
     L, r = ex(x, do_ori=False)
     assert np.array_equal(r.numpy(), g["baum4_resp"]) and np.abs(L.numpy() - g["baum4_LAFs"]).max() < 1e-3
