@@ -86,7 +86,8 @@ extern "C" int affnet_describe_detected(affnet_ctx* ctx, const affnet_nets* nets
         if (baumberg)
             return aff_handcrafted_launch(ctx, AFFNET_HC_BAUMBERG, nullptr, lafs, ctx->st_det_ids, det_count, P, nets->h_baumberg_window, A_out,
                                           nullptr, st);
-        return affnet_cnn32_forward_pyr(ctx, AFFNET_NET_AFFNET, nets->d_affnet, lafs, ctx->st_det_ids, det_count, P, A_out, nullptr, stream);
+        return affnet_cnn32_forward_pyr(ctx, AFFNET_NET_AFFNET, nets->d_affnet, lafs, ctx->st_det_ids, det_count, P, A_out, ctx->st_hard_scratch,
+                                        stream);   // conv5 tensors (P x 4096 floats) share the HardNet scratch
     };
     if (nets->d_affnet || baumberg) {
         rc = shape_pass(ctx->st_det_lafs, ctx->st_A);
@@ -120,8 +121,8 @@ extern "C" int affnet_describe_detected(affnet_ctx* ctx, const affnet_nets* nets
     aff_prof_mark(ctx, 4, st);
     if (do_ori) {
         if (nets->d_orinet)
-            rc = affnet_cnn32_forward_pyr(ctx, AFFNET_NET_ORINET, nets->d_orinet, ctx->st_lafs_shaped, d_ids, d_count, F, ctx->st_R, nullptr,
-                                          stream);
+            rc = affnet_cnn32_forward_pyr(ctx, AFFNET_NET_ORINET, nets->d_orinet, ctx->st_lafs_shaped, d_ids, d_count, F, ctx->st_R,
+                                          ctx->st_hard_scratch, stream);
         else
             rc = aff_handcrafted_launch(ctx, AFFNET_HC_ORIENTATION, nullptr, ctx->st_lafs_shaped, d_ids, d_count, F, nets->h_orientation_window,
                                         ctx->st_R, nullptr, st);

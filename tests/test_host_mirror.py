@@ -119,14 +119,14 @@ def test_packed_weights_reproduce_the_network(kind, name, weights):
         got = y / torch.sqrt((y * y).sum(1, keepdim=True) + 1e-8)
         want = orc.hardnet_forward(sd, p)
     elif kind == 0:
-        hw = blob[off:off + 3 * 4096].view(3, 4096)
+        hw = blob[off:off + 3 * 4096].view(3, 4096)                       # [o][pixel][channel]
         hb = blob[off + 3 * 4096: off + 3 * 4096 + 3]
-        t = torch.tanh(x.reshape(6, -1) @ hw.t() + hb)
+        t = torch.tanh(x.permute(0, 2, 3, 1).reshape(6, -1) @ hw.t() + hb)
         A = torch.zeros(6, 2, 2)
         A[:, 0, 0], A[:, 1, 0], A[:, 1, 1] = 1 + t[:, 0], t[:, 1], 1 + t[:, 2]
         got, want = orc.rectify_up_is_up(A), orc.affnet_forward(sd, p)
     else:
-        hw = blob[off:off + 2 * 4096].view(2, 64, 8, 8)
+        hw = blob[off:off + 2 * 4096].view(2, 8, 8, 64).permute(0, 3, 1, 2).contiguous()     # [o][ky][kx][c] -> (o, c, ky, kx)
         hb = blob[off + 2 * 4096: off + 2 * 4096 + 2]
         t = torch.tanh(F.conv2d(x, hw, hb, padding=1)).mean(dim=(2, 3))
         got = orc.rotation_matrix(torch.atan2(t[:, 0] + 1e-8, t[:, 1] + 1e-8))
