@@ -868,7 +868,7 @@ __device__ __forceinline__ void duo_tick() {
 }
 
 template <int KIND>
-__global__ __launch_bounds__(1024) void cnn16_duo_kernel(CnnArgs a, PyrSrc ps, int total_rows) {
+__global__ __launch_bounds__(1024) void cnn16_duo_kernel(CnnArgs a, PyrSrc ps, int total_rows, int antiphase) {
     constexpr int CB = 16, NW = 8, NTHR = 512, PPT = 2, RPT = 16;
     constexpr int T1M = 8, T1N = 1, T2M = 2, T2N = 2, T4M = 2, T4N = 1, AREG = 48;
     constexpr int G2 = pick_groups(CB, T2M, T2N, 32, AREG), G3 = pick_groups(2 * CB, T2M, T2N, 32, AREG);
@@ -910,7 +910,7 @@ __global__ __launch_bounds__(1024) void cnn16_duo_kernel(CnnArgs a, PyrSrc ps, i
     asm volatile("" : "+v"(tid));                             \
     asm volatile("" : "+s"(wave));                            \
     const int lane = tid & 63
-    if (g == 1) DUO_TICK();                                                  // anti-phase: group 1 runs one slot behind
+    if (g == 1 && antiphase) DUO_TICK();                                     // anti-phase: group 1 runs one slot behind
     bool have_prev = false;
     size_t prev_row = 0;
     f32x4 acc5[T4M][T4N];
@@ -1080,7 +1080,7 @@ __global__ __launch_bounds__(1024) void cnn16_duo_kernel(CnnArgs a, PyrSrc ps, i
         finish_prev(tid, lane, wave);
     }
 #undef DUO_IDS
-    if (g == 0) DUO_TICK();                                                  // group 1 executed one tick more at the start
+    if (g == 0 && antiphase) DUO_TICK();                                     // group 1 executed one tick more at the start
 }
 
 // ---- HardNet head: (n x 8192) x (8192 x 128) GEMM + BN bias + L2 normalisation ----------------------
@@ -1207,15 +1207,15 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
     // Measured (tools/duo_timing.py): correct, but 8% slower than one patch per workgroup - with only two wavefronts per
     // SIMD inside a loop the small-tile AffNet loops reach 85-90% of the pipe rate instead of 94%, and the E* slot (20-29k
     // cycles) is longer than the partner's M1 / M5 slot (18-20k).  Kept as an experiment, off by default.
-    static const int duo = []() { const char* e = getenv("AFFNET_CNN_DUO"); return (e && atoi(e) == 1) ? 1 : 0; }();
+    static const int duo = []() { const char* e = getenv("AFFNET_CNN_DUO"); return e ? atoi(e) : 0; }();      // 1 = anti-phase, 2 = lockstep
     static const int n_cu = []() { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
     static const int duo_dbg = []() { const char* e = getenv("AFFNET_CNN_DUO_STAMPS"); return (e && atoi(e)) ? 1 : 0; }();
     const bool use_duo = duo && kind != AFFNET_NET_HARDNET && dbg_layer < 0 && (!g_dbg_time || duo_dbg);
     if (use_duo) {
         const int total_rows = n_max * B, npairs = (total_rows + 1) / 2;
         const dim3 dgrid(npairs < n_cu ? npairs : n_cu);
-        if (kind == AFFNET_NET_AFFNET) hipLaunchKernelGGL((cnn16_duo_kernel<AFFNET_NET_AFFNET>), dgrid, dim3(1024), 0, st, a, ps, total_rows);
-        else hipLaunchKernelGGL((cnn16_duo_kernel<AFFNET_NET_ORINET>), dgrid, dim3(1024), 0, st, a, ps, total_rows);
+        if (kind == AFFNET_NET_AFFNET) hipLaunchKernelGGL((cnn16_duo_kernel<AFFNET_NET_AFFNET>), dgrid, dim3(1024), 0, st, a, ps, total_rows, duo == 1 ? 1 : 0);
+        else hipLaunchKernelGGL((cnn16_duo_kernel<AFFNET_NET_ORINET>), dgrid, dim3(1024), 0, st, a, ps, total_rows, duo == 1 ? 1 : 0);
     } else if (kind == AFFNET_NET_AFFNET) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_AFFNET, 8>), grid, dim3(512), 0, st, a, ps);
     else if (kind == AFFNET_NET_ORINET) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_ORINET, 8>), grid, dim3(512), 0, st, a, ps);
     else if (hard_waves == 8) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_HARDNET, 8>), grid, dim3(512), 0, st, a, ps);

@@ -92,7 +92,17 @@ def main():
                     help="1 (with --streams 1): pyramid + detector of chunk i+1 run on a second stream next to the CNN stages of "
                          "chunk i (two contexts alternate); the CNN kernels stay serialised on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config5", action="store_true",
+                    help="BASELINE.json configs[4] instead of the headline configs[2]: 3840x2160 images, 8000 kp each (deep pyramid stress); "
+                         "batch / chunk default to 8 / 4")
     args = ap.parse_args()
+    global H, W, NKP
+    if args.config5:
+        H, W, NKP = 2160, 3840, 8000
+        if args.batch == BATCH:
+            args.batch = 8
+        if args.chunk == 16:
+            args.chunk = 4
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -210,13 +220,13 @@ def main():
         achieved = flops_launch / (trunk_ms * 1e-3) / 1e12 if trunk_ms > 0 else 0.0
         traffic, traffic_note = pmc_traffic(img_per_launch)
         out = {
-            "metric": "keypoints/sec (detect+AffNet+OriNet+HardNet) per image, 2000 kp @1024x768",
+            "metric": "keypoints/sec (detect+AffNet+OriNet+HardNet) per image, %d kp @%dx%d" % (NKP, W, H),
             "value": kps / tmax, "unit": "keypoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": tmax / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[2]: batch of %d synthetic 1024x768 grayscale images per GPU per step, "
-                                   "2000 kp each, full path detect+AffNet+OriNet+HardNet; AffNet/OriNet shipped weights, "
-                                   "HardNet seeded synthetic weights (HardNet++.pth is a missing blob)" % args.batch,
+            "config": {"workload": "BASELINE.json configs[%d]: batch of %d synthetic %dx%d grayscale images per GPU per step, "
+                                   "%d kp each, full path detect+AffNet+OriNet+HardNet; AffNet/OriNet shipped weights, "
+                                   "HardNet seeded synthetic weights (HardNet++.pth is a missing blob)" % (4 if args.config5 else 2, args.batch, W, H, NKP),
                        "global_batch": args.batch * world, "keypoints_per_image": kp_per_img,
                        "images_per_launch": CH,
                        "streams_per_gpu": "1 CNN stream + 1 detector stream (2 contexts alternate)" if PIPE else S,
