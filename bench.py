@@ -82,7 +82,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="images per step per rank")
     ap.add_argument("--chunk", type=int, default=int(os.environ.get("AFFNET_BENCH_CHUNK", "16")),
                     help="images per fused library call (every kernel launch covers `chunk` images)")
