@@ -9,8 +9,9 @@ libaffnet_hip.so.
   stages are driven one by one through the C ABI and the slot is called on device tensors.
 
 Default slots as in the reference (SparseImgRepresenter.py:42-49): OriNet=None -> OrientationDetector(patch_size=19),
-AffNet=None -> AffineShapeEstimator(patch_size=19) (affnet_amd.HandCraftedModules, csrc/handcrafted.hip).  Not built: a
-custom RespNet and nlevels != 3; asking for them raises NotImplementedError.
+AffNet=None -> AffineShapeEstimator(patch_size=19) (affnet_amd.HandCraftedModules, csrc/handcrafted.hip); a custom
+RespNet callable is evaluated per pyramid level and the detector runs on its response maps.  Not built: nlevels != 3
+(NotImplementedError).
 """
 import ctypes as C
 
@@ -35,8 +36,8 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
             self.num = -1
         else:
             self.th = 0
-        if RespNet is not None:
-            raise NotImplementedError("custom RespNet slot: only the built-in HessianResp is implemented in HIP")
+        self.RespNet = RespNet       # None = the built-in Hessian response fused into the detector kernel; otherwise any callable
+                                     # RespNet(level (1,1,h,w), sigma) -> (1,1,h,w) (SparseImgRepresenter.py:38-41), run per level
         if nlevels != 3:
             raise NotImplementedError("the HIP detector is specialised for nlevels=3 (5 levels per octave)")
         self.OriNet = OriNet if OriNet is not None else OrientationDetector(patch_size=19)       # SparseImgRepresenter.py:42-45
@@ -66,6 +67,25 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
         self.scale_pyr = ctx.pyramid_views()
         self.sigmas = [list(s) for s in ctx.plan.sigmas]
         self.pix_dists = [list(p) for p in ctx.plan.pix_dists]
+
+    def _response_pyramid(self, ctx, img):
+        """Custom RespNet slot: builds the pyramid, evaluates RespNet on every level of every image and returns the response
+        maps laid out like the pyramid (what affnet_detect_responses / affnet_detect_image_responses expect)."""
+        dev = img.device
+        st = engine.stream_of(dev)
+        check(lib.affnet_pyramid_build(ctx.handle, ptr(img), st), ctx.handle, "affnet_pyramid_build")
+        stride = lib.affnet_pyramid_image_stride(ctx.handle)
+        base = lib.affnet_pyramid_level_offset(ctx.handle, 0, 0)
+        resp = torch.zeros(ctx.batch * stride, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for b in range(ctx.batch):
+                pyr = ctx.pyramid_views(b)
+                for o, (h, w) in enumerate(ctx.plan.sizes):
+                    for l in range(ctx.plan.levels_per_octave):
+                        off = b * stride + lib.affnet_pyramid_level_offset(ctx.handle, o, l) - base
+                        r = self.RespNet(pyr[o][l], ctx.plan.sigmas[o][l])
+                        resp[off:off + h * w].copy_(r.reshape(-1).to(dev, torch.float32))
+        return resp
 
     @staticmethod
     def _native(slot):
@@ -104,7 +124,13 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
             else:
                 nets.d_orinet = self.OriNet.packed_weights(dev).data_ptr()
         nets.d_hardnet = desc.packed_weights(dev).data_ptr() if desc is not None else None
-        if det_stream is None:
+        if self.RespNet is not None:
+            rmaps = self._response_pyramid(ctx, img)
+            check(lib.affnet_detect_image_responses(ctx.handle, ptr(rmaps), engine.stream_of(dev)), ctx.handle, "affnet_detect_image_responses")
+            rc = lib.affnet_describe_detected(ctx.handle, C.byref(nets), int(bool(do_ori)), ptr(lafs), ptr(resp), ptr(ids), ptr(dsc),
+                                              ptr(count), engine.stream_of(dev))
+            check(rc, ctx.handle, "affnet_describe_detected")
+        elif det_stream is None:
             rc = lib.affnet_extract_features(ctx.handle, C.byref(nets), ptr(img), int(bool(do_ori)), ptr(lafs), ptr(resp), ptr(ids),
                                              ptr(dsc), ptr(count), engine.stream_of(dev))
             check(rc, ctx.handle, "affnet_extract_features")
@@ -168,13 +194,21 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
         dev, st = x.device, engine.stream_of(x.device)
         img = x.contiguous().float()
         P, F = ctx.cap_pre, ctx.cap_final
-        check(lib.affnet_pyramid_build(ctx.handle, ptr(img), st), ctx.handle, "affnet_pyramid_build")
+        rmaps = None
+        if self.RespNet is not None:
+            rmaps = self._response_pyramid(ctx, img)
+        else:
+            check(lib.affnet_pyramid_build(ctx.handle, ptr(img), st), ctx.handle, "affnet_pyramid_build")
         self._publish_pyramid(ctx)
         resp = torch.empty(P, dtype=torch.float32, device=dev)
         lafs = torch.empty(P, 2, 3, dtype=torch.float32, device=dev)
         ids = torch.empty(P, 3, dtype=torch.int32, device=dev)
         cnt = torch.zeros(1, dtype=torch.int32, device=dev)
-        check(lib.affnet_detect(ctx.handle, ptr(resp), ptr(lafs), ptr(ids), ptr(cnt), st), ctx.handle, "affnet_detect")
+        if rmaps is not None:
+            check(lib.affnet_detect_responses(ctx.handle, ptr(rmaps), ptr(resp), ptr(lafs), ptr(ids), ptr(cnt), st), ctx.handle,
+                  "affnet_detect_responses")
+        else:
+            check(lib.affnet_detect(ctx.handle, ptr(resp), ptr(lafs), ptr(ids), ptr(cnt), st), ctx.handle, "affnet_detect")
         n = int(cnt.item())
         ctx.read_counts()
         if n == 0:

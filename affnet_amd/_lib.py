@@ -54,6 +54,7 @@ SYMBOLS = {
     "affnet_pyramid_build": (_I, [_P, _P, _P]),
     "affnet_hessian_response": (_I, [_P, _P, _P, _I, _I, C.c_float, _P]),
     "affnet_detect": (_I, [_P, _P, _P, _P, _P, _P]),
+    "affnet_detect_responses": (_I, [_P, _P, _P, _P, _P, _P, _P]),
     "affnet_laf_grid_sample": (_I, [_P, _P, _I, _I, _P, _I, _I, _P, _P]),
     "affnet_pyr_grid_sample": (_I, [_P, _P, _P, _P, _I, _I, _P, _P]),
     "affnet_cnn32_packed_floats": (_SZ, [_I]),
@@ -76,6 +77,7 @@ SYMBOLS = {
     "affnet_centre_nn": (_I, [_P, _P, _I, _P, _I, _P, _P, _P]),
     "affnet_extract_features": (_I, [_P, C.POINTER(Nets), _P, _I, _P, _P, _P, _P, _P, _P]),
     "affnet_detect_image": (_I, [_P, _P, _P]),
+    "affnet_detect_image_responses": (_I, [_P, _P, _P]),
     "affnet_describe_detected": (_I, [_P, C.POINTER(Nets), _I, _P, _P, _P, _P, _P, _P]),
     "affnet_profile_enable": (_I, [_P, _I]),
     "affnet_profile_read": (_I, [_P, C.POINTER(C.c_double * 8), C.POINTER(C.c_int32)]),

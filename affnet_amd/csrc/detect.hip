@@ -49,6 +49,7 @@ struct HessParams {
     int32_t* overflow;
     // batch (blockIdx.z = image): per-image strides of the pyramid (floats), the raw lists (entries), the counters
     size_t levels_stride, raw_stride;
+    int precomputed;       // != 0: `levels` holds RESPONSE maps of a custom RespNet slot (same layout); only clamp(r - th, 0) applies
 };
 
 __device__ __forceinline__ float hessian_at(const float* __restrict__ X, int ty, int tx, float s4, float th) {
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void hessian_nms_kernel(HessParams p) {
     p.raw += blockIdx.z * p.raw_stride;
     p.raw_cnt += blockIdx.z * CNT_TOTAL;
     p.overflow += blockIdx.z * CNT_TOTAL;
-    for (int l = 0; l < 5; ++l) {
+    for (int l = 0; l < 5 && !p.precomputed; ++l) {
         const float* src = p.levels + l * lvl_stride;
         for (int i = threadIdx.x; i < HX_H * HX_W; i += 256) {
             const int ty = i / HX_W, tx = i - ty * HX_W;
@@ -100,7 +101,9 @@ __global__ __launch_bounds__(256) void hessian_nms_kernel(HessParams p) {
             const int ry = i / HR_W, rx = i - ry * HR_W;
             const int gy = y0 + ry - 1, gx = x0 + rx - 1;
             float r = -INFINITY;                       // outside the image: -inf for max_pool3d padding
-            if (gy >= 0 && gy < h && gx >= 0 && gx < w) r = hessian_at(X[l], ry + 1, rx + 1, s4, p.th);
+            if (gy >= 0 && gy < h && gx >= 0 && gx < w)
+                r = p.precomputed ? fmaxf(p.levels[l * lvl_stride + (size_t)gy * w + gx] - p.th, 0.0f)   // SparseImgRepresenter.py:77
+                                  : hessian_at(X[l], ry + 1, rx + 1, s4, p.th);
             Rr[l][ry * HR_S + rx] = r;
         }
     }
@@ -439,7 +442,9 @@ __global__ __launch_bounds__(256) void select_emit_kernel(const float* __restric
     out_ids[3 * r] = sel_ids[3 * i]; out_ids[3 * r + 1] = sel_ids[3 * i + 1]; out_ids[3 * r + 2] = sel_ids[3 * i + 2];
 }
 
-extern "C" int affnet_detect(affnet_ctx* ctx, float* d_resp, float* d_lafs, int32_t* d_ids, int32_t* d_count, void* stream) {
+// d_responses == NULL: Hessian responses computed from the pyramid in the workspace; otherwise response maps of a custom
+// RespNet slot, laid out like the pyramid (image stride = affnet_pyramid_image_stride, level offsets as the pyramid's).
+int aff_detect_impl(affnet_ctx* ctx, const float* d_responses, float* d_resp, float* d_lafs, int32_t* d_ids, int32_t* d_count, void* stream) {
     if (!ctx || !ctx->ws || !d_resp || !d_lafs || !d_ids) return aff_fail(ctx, AFFNET_ERR_INVALID, "detect: context not bound or null output");
     hipStream_t st = (hipStream_t)stream;
     const affnet_config& c = ctx->cfg;
@@ -457,7 +462,8 @@ extern "C" int affnet_detect(affnet_ctx* ctx, float* d_resp, float* d_lafs, int3
     for (int o = 0; o < c.n_octaves; ++o) {
         const OctaveGeom& g = ctx->oct[o];
         HessParams hp;
-        hp.levels = ctx->pyr + g.pyr_off;
+        hp.levels = (d_responses ? d_responses : ctx->pyr) + g.pyr_off;
+        hp.precomputed = d_responses ? 1 : 0;
         hp.h = g.h; hp.w = g.w; hp.n_levels = 5;
         for (int l = 0; l < 5; ++l) { hp.sigma[l] = c.level_sigma[o][l]; hp.sigma4[l] = c.level_sigma4[o][l]; }
         hp.th = c.threshold;
@@ -496,4 +502,14 @@ extern "C" int affnet_detect(affnet_ctx* ctx, float* d_resp, float* d_lafs, int3
                        ctx->st_rank, c.mr_size, d_resp, d_lafs, d_ids, d_count);
     AFF_LAUNCH_CHECK(ctx);
     return AFFNET_OK;
+}
+
+extern "C" int affnet_detect(affnet_ctx* ctx, float* d_resp, float* d_lafs, int32_t* d_ids, int32_t* d_count, void* stream) {
+    return aff_detect_impl(ctx, nullptr, d_resp, d_lafs, d_ids, d_count, stream);
+}
+
+extern "C" int affnet_detect_responses(affnet_ctx* ctx, const float* d_responses, float* d_resp, float* d_lafs, int32_t* d_ids,
+                                       int32_t* d_count, void* stream) {
+    if (!d_responses) return aff_fail(ctx, AFFNET_ERR_INVALID, "detect_responses: null response pyramid");
+    return aff_detect_impl(ctx, d_responses, d_resp, d_lafs, d_ids, d_count, stream);
 }

@@ -54,6 +54,22 @@ int aff_handcrafted_launch(affnet_ctx* ctx, int kind, const float* patches, cons
 int aff_hardnet_forward_pyr_marked(affnet_ctx* ctx, const float* packed, const float* lafs, const int32_t* ids, const int32_t* count,
                                    int n_max, float* out, float* scratch, hipStream_t st);
 
+int aff_detect_impl(affnet_ctx* ctx, const float* d_responses, float* d_resp, float* d_lafs, int32_t* d_ids, int32_t* d_count, void* stream);
+
+// Detector half for a custom RespNet slot: the caller has built the pyramid (affnet_pyramid_build), evaluated its RespNet on
+// every level and hands over the response pyramid; candidates go to the context's internal list for
+// affnet_describe_detected.
+extern "C" int affnet_detect_image_responses(affnet_ctx* ctx, const float* d_responses, void* stream) {
+    if (!ctx || !ctx->ws || !d_responses) return aff_fail(ctx, AFFNET_ERR_INVALID, "detect_image_responses: context not bound or null responses");
+    hipStream_t st = (hipStream_t)stream;
+    aff_prof_mark(ctx, 0, st);
+    aff_prof_mark(ctx, 1, st);
+    int rc = aff_detect_impl(ctx, d_responses, ctx->st_det_resp, ctx->st_det_lafs, ctx->st_det_ids, ctx->st_det_count, stream);
+    if (rc) return rc;
+    aff_prof_mark(ctx, 9, st);
+    return AFFNET_OK;
+}
+
 extern "C" int affnet_detect_image(affnet_ctx* ctx, const float* d_img, void* stream) {
     if (!ctx || !ctx->ws || !d_img) return aff_fail(ctx, AFFNET_ERR_INVALID, "detect_image: context not bound or null image");
     hipStream_t st = (hipStream_t)stream;

@@ -143,6 +143,12 @@ int affnet_hessian_response(affnet_ctx* ctx, const float* d_in, float* d_out, in
 int affnet_detect(affnet_ctx* ctx, float* d_resp, float* d_lafs, int32_t* d_ids,
                   int32_t* d_count, void* stream);
 
+/* Same detector on RESPONSE maps supplied by the caller - the RespNet slot of the reference (SparseImgRepresenter.py:24,38-41:
+ * any callable RespNet(level (1,1,h,w), sigma) -> (1,1,h,w)).  d_responses is laid out like the pyramid in the workspace
+ * (affnet_pyramid_level_offset - offset of level (0,0), affnet_pyramid_image_stride); clamp(r - th, 0) is applied here. */
+int affnet_detect_responses(affnet_ctx* ctx, const float* d_responses, float* d_resp, float* d_lafs, int32_t* d_ids,
+                            int32_t* d_count, void* stream);
+
 /* Affine patch sampler: affine_grid + bilinear grid_sample, zeros padding,
  * align_corners=False, including the reference's fp32 coordinate round trip.
  * Replaces LAF.py:313-324,326-372 (generate_patch_grid_from_normalized_LAFs,
@@ -304,6 +310,9 @@ int affnet_extract_features(affnet_ctx* ctx, const affnet_nets* nets, const floa
  *   affnet_detect_image      = pyramid + detector into the context's internal candidate list;
  *   affnet_describe_detected = AffNet shape + filter, OriNet, denormalise, level select, HardNet. */
 int affnet_detect_image(affnet_ctx* ctx, const float* d_img, void* stream);
+/* Detector half on caller-supplied response maps (custom RespNet slot; the pyramid must have been built with
+ * affnet_pyramid_build): candidates go to the internal list consumed by affnet_describe_detected. */
+int affnet_detect_image_responses(affnet_ctx* ctx, const float* d_responses, void* stream);
 int affnet_describe_detected(affnet_ctx* ctx, const affnet_nets* nets, int do_ori, float* d_lafs_px, float* d_resp,
                              int32_t* d_ids, float* d_desc, int32_t* d_count, void* stream);
 

@@ -190,13 +190,15 @@ def nms3d_compose(low, cur, high, num_features, octave_map, scales, mr_size):
     return resp, lafs, octave_map, idx.view(-1)
 
 
-def multi_scale_detector(x, num_features, n_levels=3, init_sigma=1.6, border=5, mr_size=3.0, th=0.0):
-    """SparseImgRepresenter.py:53-111.  Returns dict with pyramid and candidate arrays."""
+def multi_scale_detector(x, num_features, n_levels=3, init_sigma=1.6, border=5, mr_size=3.0, th=0.0, resp_fn=None):
+    """SparseImgRepresenter.py:53-111.  Returns dict with pyramid and candidate arrays.  resp_fn = the RespNet slot
+    (:38-41): callable(level (1,1,h,w), sigma) -> (1,1,h,w); None = HessianResp."""
+    hessian = hessian_response if resp_fn is None else resp_fn
     pyr, sigmas, dists = scale_pyramid(x, n_levels, init_sigma, border)
     resp_l, laf_l, oct_l, lev_l, pix_l = [], [], [], [], []
     for o, levels in enumerate(pyr):
         omap = (levels[0] * 0).byte()
-        rmaps = [torch.clamp(hessian_response(levels[l], sigmas[o][l]) - th, min=0) for l in range(len(levels))]
+        rmaps = [torch.clamp(hessian(levels[l], sigmas[o][l]) - th, min=0) for l in range(len(levels))]
         for l in range(1, len(levels) - 1):
             r, lafs, om, pix = nms3d_compose(rmaps[l - 1], rmaps[l], rmaps[l + 1], num_features, omap,
                                              sigmas[o][l - 1:l + 2], mr_size)
@@ -439,7 +441,7 @@ class OracleExtractor(object):
 
     def __init__(self, border=16, num_features=500, patch_size=32, mrSize=3.0, nlevels=3,
                  num_Baum_iters=0, init_sigma=1.6, th=None, affnet_sd=None, orinet_sd=None,
-                 reproduce_wasted_extraction=False):
+                 reproduce_wasted_extraction=False, resp_fn=None):
         self.mrSize, self.b, self.num = mrSize, border, num_features
         self.nlevels, self.iters, self.init_sigma = nlevels, num_Baum_iters, init_sigma
         self.th = th
@@ -448,6 +450,7 @@ class OracleExtractor(object):
         else:
             self.th = 0
         self.aff, self.ori = affnet_sd, orinet_sd
+        self.resp_fn = resp_fn
         self.PS = 32
         self.waste = reproduce_wasted_extraction
         self.scale_pyr = self.sigmas = self.pix_dists = None
@@ -493,7 +496,7 @@ class OracleExtractor(object):
         """SparseImgRepresenter.py:189-209.  Returns (LAFs px (N,2,3), responses (N,))."""
         with torch.no_grad():
             pre = int(1.5 * self.num) if self.iters > 0 else self.num
-            det = multi_scale_detector(x, pre, self.nlevels, self.init_sigma, self.b, self.mrSize, self.th)
+            det = multi_scale_detector(x, pre, self.nlevels, self.init_sigma, self.b, self.mrSize, self.th, self.resp_fn)
             self.scale_pyr, self.sigmas, self.pix_dists = det["pyr"], det["sigmas"], det["pix_dists"]
             det["lafs"][:, 0:2, 0:2] = self.mrSize * det["lafs"][:, :, 0:2]
             self.detected = {k: det[k].clone() for k in ("resp", "lafs", "oct", "lev", "pix")}

@@ -402,6 +402,38 @@ def test_iterated_affnet_shape(amd, nets, weights, iters):
     assert L1.shape != res["LAFs"].shape or float((L1 - res["LAFs"]).abs().max()) > 1e-3
 
 
+def test_custom_respnet_slot(amd, nets, weights):
+    """RespNet slot (SparseImgRepresenter.py:24,38-41): any callable(level, sigma) -> response map.  (1) a torch restatement of
+    HessianResp through the slot gives the built-in detector's keypoints; (2) a different response (sigma^2 |Laplacian|) gives the
+    oracle's keypoints for the same function."""
+    import torch.nn.functional as F
+    A, O, H = nets
+    x = orc.synthetic_image(240, 320, 1)
+
+    def hess(level, sigma):
+        return orc.hessian_response(level.cpu(), sigma).to(level.device)
+
+    def lap(level, sigma):                         # runs on whatever device the level lives on
+        k = torch.tensor([[0.0, 1.0, 0.0], [1.0, -4.0, 1.0], [0.0, 1.0, 0.0]], device=level.device).view(1, 1, 3, 3)
+        return (F.conv2d(F.pad(level, (1, 1, 1, 1), "replicate"), k).abs() * float(sigma * sigma))
+
+    mk = lambda rn: amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=1, AffNet=A, OriNet=O,
+                                                       RespNet=rn).to(DEV)
+    builtin = mk(None).run(x.to(DEV), do_ori=True, desc=H)
+    via_slot = mk(hess).run(x.to(DEV), do_ori=True, desc=H)
+    for k in ("LAFs", "responses", "ids", "descriptors"):
+        assert torch.equal(builtin[k], via_slot[k]), k
+    got = mk(lap).run(x.to(DEV), do_ori=True, desc=H)
+    ex = orc.OracleExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=1, affnet_sd=weights["AffNet"],
+                             orinet_sd=weights["OriNet"], resp_fn=lambda lv, s: lap(lv, s))
+    Lw, rw = ex(x, do_ori=True)
+    gi, wi = _match(got["ids"].cpu().numpy(), ex.keys.numpy())
+    row_err = np.abs(got["LAFs"].cpu().numpy()[gi] - Lw.numpy()[wi]).reshape(len(gi), -1).max(axis=1)
+    print("custom RespNet: matched %d / %d, rows within 1e-3 px %.4f" % (len(gi), len(ex.keys), (row_err < 1e-3).mean()))
+    assert len(gi) >= 0.97 * len(ex.keys) and (row_err < 1e-3).mean() >= 0.99     # conv2d on GPU vs CPU: response ties can flip
+    assert not torch.equal(got["ids"], builtin["ids"])
+
+
 def test_handcrafted_default_slots(amd, nets, golden_dir):
     """OrientationDetector / AffineShapeEstimator kernels against the unmodified reference classes
     (golden) - unit level, the default-constructed extractor, and 4 Baumberg iterations."""
