@@ -10,8 +10,7 @@ libaffnet_hip.so.
 
 Default slots as in the reference (SparseImgRepresenter.py:42-49): OriNet=None -> OrientationDetector(patch_size=19),
 AffNet=None -> AffineShapeEstimator(patch_size=19) (affnet_amd.HandCraftedModules, csrc/handcrafted.hip); a custom
-RespNet callable is evaluated per pyramid level and the detector runs on its response maps.  Not built: nlevels != 3
-(NotImplementedError).
+RespNet callable is evaluated per pyramid level and the detector runs on its response maps.  nlevels 1..6 (the reference's default is 3).
 """
 import ctypes as C
 
@@ -38,8 +37,8 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
             self.th = 0
         self.RespNet = RespNet       # None = the built-in Hessian response fused into the detector kernel; otherwise any callable
                                      # RespNet(level (1,1,h,w), sigma) -> (1,1,h,w) (SparseImgRepresenter.py:38-41), run per level
-        if nlevels != 3:
-            raise NotImplementedError("the HIP detector is specialised for nlevels=3 (5 levels per octave)")
+        if not 1 <= nlevels <= 6:
+            raise NotImplementedError("nlevels must be 1..6 (levels per octave = nlevels + 2 <= 8)")
         self.OriNet = OriNet if OriNet is not None else OrientationDetector(patch_size=19)       # SparseImgRepresenter.py:42-45
         self.AffNet = AffNet if AffNet is not None else AffineShapeEstimator(patch_size=19)      # :46-49
         self.scale_pyr = self.sigmas = self.pix_dists = None

@@ -26,7 +26,7 @@ enum {
     CNT_SHAPED,                              // rows after the shape filter
     CNT_SURVIVED,                            // survivors of the shape filter before top-N
     CNT_POS0 = AFFNET_MAX_OCTAVES + 16,      // CNT_POS0 + (level-1)*AFFNET_MAX_OCTAVES + o : positive maxima of (octave, level)
-    CNT_TOTAL = AFFNET_MAX_OCTAVES + 16 + 3 * AFFNET_MAX_OCTAVES
+    CNT_TOTAL = AFFNET_MAX_OCTAVES + 16 + (AFFNET_MAX_LEVELS - 2) * AFFNET_MAX_OCTAVES
 };
 
 struct RawMax {            // one 3-D local maximum found by hessian_nms_kernel

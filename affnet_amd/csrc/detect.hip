@@ -66,15 +66,17 @@ __device__ __forceinline__ float hessian_at(const float* __restrict__ X, int ty,
     return fmaxf(r - th, 0.0f);
 }
 
+// NL = levels per octave = nLevels + 2 (5 for the reference's default nlevels = 3; 3..8 are instantiated)
+template <int NL>
 __global__ __launch_bounds__(256) void hessian_nms_kernel(HessParams p) {
-    // LDS: 5 blurred tiles (20x68) + 5 response tiles (18x67)
-    __shared__ __attribute__((aligned(16))) float X[5][HX_H * HX_W];
-    __shared__ float Rr[5][HR_H * HR_S];
+    // LDS: NL blurred tiles (20x68) + NL response tiles (18x67)
+    __shared__ __attribute__((aligned(16))) float X[NL][HX_H * HX_W];
+    __shared__ float Rr[NL][HR_H * HR_S];
     // Maxima found by this workgroup are staged and appended with ONE global atomic (a single contended counter retires
     // only ~90 atomics/us: per-candidate atomics cost 150 us on octave 0).  The staging list aliases the blurred tiles,
     // which are dead once the responses are in Rr: 51 KB of LDS -> 3 workgroups per CU instead of 2.
     RawMax* s_list = reinterpret_cast<RawMax*>(&X[0][0]);
-    static_assert(sizeof(RawMax) * HN_CAP <= sizeof(float) * 5 * HX_H * HX_W, "staging list must fit in the tile area");
+    static_assert(sizeof(RawMax) * HN_CAP <= sizeof(float) * NL * HX_H * HX_W, "staging list must fit in the tile area");
     __shared__ int s_n, s_base;
     if (threadIdx.x == 0) s_n = 0;
     const int h = p.h, w = p.w;
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256) void hessian_nms_kernel(HessParams p) {
     p.raw += blockIdx.z * p.raw_stride;
     p.raw_cnt += blockIdx.z * CNT_TOTAL;
     p.overflow += blockIdx.z * CNT_TOTAL;
-    for (int l = 0; l < 5 && !p.precomputed; ++l) {
+    for (int l = 0; l < NL && !p.precomputed; ++l) {
         const float* src = p.levels + l * lvl_stride;
         for (int i = threadIdx.x; i < HX_H * HX_W; i += 256) {
             const int ty = i / HX_W, tx = i - ty * HX_W;
@@ -95,7 +97,7 @@ __global__ __launch_bounds__(256) void hessian_nms_kernel(HessParams p) {
         }
     }
     __syncthreads();
-    for (int l = 0; l < 5; ++l) {
+    for (int l = 0; l < NL; ++l) {
         const float s4 = p.sigma4[l];
         for (int i = threadIdx.x; i < HR_H * HR_W; i += 256) {
             const int ry = i / HR_W, rx = i - ry * HR_W;
@@ -118,10 +120,10 @@ __global__ __launch_bounds__(256) void hessian_nms_kernel(HessParams p) {
         if (gx >= w || gy >= h) break;
         const bool in_border = !border_ok || gy < p.border || gy >= h - p.border || gx < p.border || gx >= w - p.border;
         if (in_border) continue;                      // zero_response_at_border -> nms value 0 -> never a candidate
-        // column maxima over the 3x3 spatial window of each of the 5 response levels are shared by the 3 NMS levels
-        float m5[5];
+        // column maxima over the 3x3 spatial window of each of the NL response levels are shared by the NL - 2 NMS levels
+        float m5[NL];
 #pragma unroll
-        for (int l = 0; l < 5; ++l) {
+        for (int l = 0; l < NL; ++l) {
             const float* r = &Rr[l][ty * HR_S + tx];  // top-left of the 3x3 window (response tile has 1-px halo)
             float m = fmaxf(fmaxf(r[0], r[1]), r[2]);
             m = fmaxf(m, fmaxf(fmaxf(r[HR_S], r[HR_S + 1]), r[HR_S + 2]));
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void hessian_nms_kernel(HessParams p) {
             m5[l] = m;
         }
 #pragma unroll
-        for (int l = 1; l <= 3; ++l) {
+        for (int l = 1; l <= NL - 2; ++l) {
             const float c = Rr[l][(ty + 1) * HR_S + tx + 1];
             const float M = fmaxf(fmaxf(m5[l - 1], m5[l]), m5[l + 1]);
             const float d = c - M;
@@ -448,7 +450,8 @@ int aff_detect_impl(affnet_ctx* ctx, const float* d_responses, float* d_resp, fl
     if (!ctx || !ctx->ws || !d_resp || !d_lafs || !d_ids) return aff_fail(ctx, AFFNET_ERR_INVALID, "detect: context not bound or null output");
     hipStream_t st = (hipStream_t)stream;
     const affnet_config& c = ctx->cfg;
-    if (c.levels_per_octave != 5) return aff_fail(ctx, AFFNET_ERR_INVALID, "detect: only nLevels=3 (5 levels per octave) is implemented");
+    const int NLv = c.levels_per_octave;
+    if (NLv < 3 || NLv > 8) return aff_fail(ctx, AFFNET_ERR_INVALID, "detect: levels_per_octave = %d (3..8 supported)", NLv);
     const int B = ctx->B;
     AFF_HIP(ctx, hipMemsetAsync(ctx->cnt, 0, (size_t)B * CNT_TOTAL * sizeof(int32_t), st));
     AFF_HIP(ctx, hipMemsetAsync(ctx->omap, 0, (size_t)B * ctx->map_stride, st));
@@ -464,18 +467,26 @@ int aff_detect_impl(affnet_ctx* ctx, const float* d_responses, float* d_resp, fl
         HessParams hp;
         hp.levels = (d_responses ? d_responses : ctx->pyr) + g.pyr_off;
         hp.precomputed = d_responses ? 1 : 0;
-        hp.h = g.h; hp.w = g.w; hp.n_levels = 5;
-        for (int l = 0; l < 5; ++l) { hp.sigma[l] = c.level_sigma[o][l]; hp.sigma4[l] = c.level_sigma4[o][l]; }
+        hp.h = g.h; hp.w = g.w; hp.n_levels = NLv;
+        for (int l = 0; l < NLv; ++l) { hp.sigma[l] = c.level_sigma[o][l]; hp.sigma4[l] = c.level_sigma4[o][l]; }
         hp.th = c.threshold;
         hp.border = (int)c.mr_size;
         hp.raw = ctx->raw + g.raw_off; hp.raw_cap = g.raw_cap;
         hp.raw_cnt = ctx->cnt + CNT_RAW0 + o; hp.overflow = ctx->cnt + CNT_OVERFLOW;
         hp.levels_stride = ctx->pyr_stride; hp.raw_stride = ctx->raw_stride;
-        hipLaunchKernelGGL(hessian_nms_kernel, dim3(aff_cdiv(g.w, HT_X), aff_cdiv(g.h, HT_Y), B), dim3(256), 0, st, hp);
+        const dim3 hgrid(aff_cdiv(g.w, HT_X), aff_cdiv(g.h, HT_Y), B);
+        switch (NLv) {
+            case 3: hipLaunchKernelGGL(hessian_nms_kernel<3>, hgrid, dim3(256), 0, st, hp); break;
+            case 4: hipLaunchKernelGGL(hessian_nms_kernel<4>, hgrid, dim3(256), 0, st, hp); break;
+            case 5: hipLaunchKernelGGL(hessian_nms_kernel<5>, hgrid, dim3(256), 0, st, hp); break;
+            case 6: hipLaunchKernelGGL(hessian_nms_kernel<6>, hgrid, dim3(256), 0, st, hp); break;
+            case 7: hipLaunchKernelGGL(hessian_nms_kernel<7>, hgrid, dim3(256), 0, st, hp); break;
+            default: hipLaunchKernelGGL(hessian_nms_kernel<8>, hgrid, dim3(256), 0, st, hp); break;
+        }
         AFF_LAUNCH_CHECK(ctx);
         rp.raw[o] = hp.raw; rp.omap[o] = ctx->omap + g.map_off; rp.raw_cap[o] = g.raw_cap;
     }
-    rp.n_detect_levels = 3; rp.cnt = ctx->cnt;
+    rp.n_detect_levels = NLv - 2; rp.cnt = ctx->cnt;
     rp.cand_resp = ctx->cand_resp; rp.cand_syx = ctx->cand_syx; rp.cand_ids = ctx->cand_ids; rp.cand_cap = (int)ctx->cand_cap;
     rp.raw_stride = ctx->raw_stride; rp.map_stride = ctx->map_stride;
     {

@@ -402,6 +402,26 @@ def test_iterated_affnet_shape(amd, nets, weights, iters):
     assert L1.shape != res["LAFs"].shape or float((L1 - res["LAFs"]).abs().max()) > 1e-3
 
 
+@pytest.mark.parametrize("nlevels", [2, 4])
+def test_other_nlevels(amd, nets, weights, nlevels):
+    """nlevels ctor kwarg (SparseImgRepresenter.py:20; ScalePyramid nLevels): 4 / 6 levels per octave instead of 5."""
+    A, O, H = nets
+    x = orc.synthetic_image(240, 320, 1)
+    det = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=1, nlevels=nlevels, AffNet=A,
+                                             OriNet=O).to(DEV)
+    res = det.run(x.to(DEV), do_ori=True, desc=H)
+    assert len(det.scale_pyr[0]) == nlevels + 2
+    ex = orc.OracleExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=1, nlevels=nlevels, affnet_sd=weights["AffNet"],
+                             orinet_sd=weights["OriNet"])
+    Lw, rw, Pw, Dw = orc.describe(x, ex, weights["HardNet"], do_ori=True, ps=32)
+    gi, wi = _match(res["ids"].cpu().numpy(), ex.keys.numpy())
+    row_err = np.abs(res["LAFs"].cpu().numpy()[gi] - Lw.numpy()[wi]).reshape(len(gi), -1).max(axis=1)
+    print("nlevels %d: matched %d / %d, worst row %.3g px" % (nlevels, len(gi), len(ex.keys), row_err.max()))
+    assert len(gi) >= 0.99 * len(ex.keys) and (row_err < 1e-3).mean() >= 0.99
+    assert np.array_equal(res["responses"].cpu().numpy()[gi], rw.numpy()[wi])
+    assert np.abs(res["descriptors"].cpu().numpy()[gi] - Dw.numpy()[wi]).max() < 1e-3
+
+
 def test_custom_respnet_slot(amd, nets, weights):
     """RespNet slot (SparseImgRepresenter.py:24,38-41): any callable(level, sigma) -> response map.  (1) a torch restatement of
     HessianResp through the slot gives the built-in detector's keypoints; (2) a different response (sigma^2 |Laplacian|) gives the

@@ -159,8 +159,9 @@ def test_no_cpu_fallback_and_unbuilt_slots_fail_loudly(weights):
     with pytest.raises(NotImplementedError):
         affnet_amd.HandCraftedModules.OrientationDetector()                   # reference default PS = 32: kernels are for 19
     assert affnet_amd.ScaleSpaceAffinePatchExtractor(RespNet=lambda x, s: x).RespNet is not None      # slot accepted (GPU test runs it)
+    assert affnet_amd.ScaleSpaceAffinePatchExtractor(nlevels=4).nlevels == 4                           # 1..6 levels supported
     with pytest.raises(NotImplementedError):
-        affnet_amd.ScaleSpaceAffinePatchExtractor(nlevels=4)
+        affnet_amd.ScaleSpaceAffinePatchExtractor(nlevels=7)
     d = affnet_amd.ScaleSpaceAffinePatchExtractor(th=28.41)
     assert d.num == -1                                                        # SparseImgRepresenter.py:33-35
     with pytest.raises(RuntimeError, match="forward"):
