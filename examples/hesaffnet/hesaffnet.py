@@ -1,13 +1,12 @@
 #!/usr/bin/env python
-"""Hessian-AffNet detector CLI - the reference's examples/hesaffnet/hesaffnet.py on MI355X.
+"""Hessian-AffNet detector command line (MI355X): same contract as the reference's examples/hesaffnet/hesaffnet.py.
 
-    python hesaffnet.py imgs/cat.png cat.txt 2000
+    python hesaffnet.py IMAGE OUT.txt NFEATS
 
-Same arguments, same loader (RGB -> channel mean -> float32 0..255), same constructor call, same output
-(Oxford ellipse text file: "1.0", count, then `x y a b c` rows).  Like the reference (hesaffnet.py:26,50)
-the default threshold th = -1 is passed, which makes the extractor ignore `nfeats` and keep every maximum;
-set HESAFFNET_TH=none to use the feature budget instead (th=None, the form the reference's test() uses).
-"""
+Output = Oxford ellipse text file: line 1 "1.0", line 2 the count, then one `x y a b c` row per region.
+The reference script passes th = -1 (hesaffnet.py:26,50), which switches the extractor to threshold mode: NFEATS is
+ignored and every scale-space maximum is kept.  That default is kept; HESAFFNET_TH=none selects the feature budget
+instead (th=None, what the reference's test() uses)."""
 import os
 import sys
 
@@ -15,41 +14,41 @@ import numpy as np
 import torch
 from PIL import Image
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, ROOT)
-from affnet_amd.SparseImgRepresenter import ScaleSpaceAffinePatchExtractor  # noqa: E402
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, REPO)
+import affnet_amd  # noqa: E402
 from affnet_amd.LAF import LAFs2ell  # noqa: E402
-from affnet_amd.Utils import line_prepender  # noqa: E402
-from affnet_amd.architectures import AffNetFast  # noqa: E402
 
-th = -1  # hesaffnet.py:26
-if os.environ.get("HESAFFNET_TH", "").lower() == "none":
-    th = None
-try:
-    input_img_fname = sys.argv[1]
-    output_fname = sys.argv[2]
-    nfeats = int(sys.argv[3])
-except Exception:
-    print("Wrong input format. Try python hesaffnet.py imgs/cat.png cat.txt 2000")
-    sys.exit(1)
 
-img = Image.open(input_img_fname).convert("RGB")
-img = np.mean(np.array(img), axis=2)
-var_image_reshape = torch.from_numpy(img.astype(np.float32)).view(1, 1, img.shape[0], img.shape[1])
+def read_gray(path):
+    """RGB -> per-pixel channel mean, float32 0..255, shape (1,1,H,W) (hesaffnet.py:35-39)."""
+    rgb = np.asarray(Image.open(path).convert("RGB"), dtype=np.float64)
+    gray = rgb.mean(axis=2).astype(np.float32)
+    return torch.from_numpy(gray)[None, None]
 
-AffNetPix = AffNetFast(PS=32)
-weightd_fname = os.path.join(ROOT, "pretrained", "AffNet.pth")
-checkpoint = torch.load(weightd_fname, map_location="cpu", weights_only=False)
-AffNetPix.load_state_dict(checkpoint["state_dict"])
-AffNetPix.eval()
 
-HA = ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=nfeats, border=5, num_Baum_iters=1, th=th, AffNet=AffNetPix)
-HA = HA.cuda()
-var_image_reshape = var_image_reshape.cuda()
-with torch.no_grad():
-    LAFs, resp = HA(var_image_reshape)
-ells = LAFs2ell(LAFs.data.cpu().numpy())
+def write_oxford(path, ellipses):
+    with open(path, "w") as f:
+        f.write("1.0\n%d\n" % len(ellipses))
+        np.savetxt(f, ellipses, delimiter=" ", fmt="%10.10f")
 
-np.savetxt(output_fname, ells, delimiter=" ", fmt="%10.10f")
-line_prepender(output_fname, str(len(ells)))
-line_prepender(output_fname, "1.0")
+
+def main(argv):
+    if len(argv) != 3 or not argv[2].lstrip("-").isdigit():
+        print("Wrong input format. Try python hesaffnet.py imgs/cat.png cat.txt 2000")
+        return 1
+    image_path, out_path, budget = argv[0], argv[1], int(argv[2])
+    threshold = None if os.environ.get("HESAFFNET_TH", "").lower() == "none" else -1
+    shape_net = affnet_amd.AffNetFast(PS=32)
+    state = torch.load(os.path.join(REPO, "pretrained", "AffNet.pth"), map_location="cpu", weights_only=False)
+    shape_net.load_state_dict(state["state_dict"])
+    extractor = affnet_amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=budget, border=5, num_Baum_iters=1,
+                                                          th=threshold, AffNet=shape_net).cuda()
+    with torch.no_grad():
+        frames, _ = extractor(read_gray(image_path).cuda())
+    write_oxford(out_path, LAFs2ell(frames.cpu().numpy()))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))

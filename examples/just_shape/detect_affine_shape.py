@@ -1,14 +1,12 @@
 #!/usr/bin/env python
-"""AffNet on an HPatches-style patch column - the reference's examples/just_shape/detect_affine_shape.py
-on MI355X.
+"""AffNet shapes for an HPatches-style patch column (MI355X): same contract as the reference's
+examples/just_shape/detect_affine_shape.py.
 
-    python detect_affine_shape.py imgs/ref.png out.txt
+    python detect_affine_shape.py COLUMN.png OUT.txt
 
-The column (h x w grey image, h a multiple of w) is cut into w x w tiles; each tile is resized to 32x32
-(bilinear; identity when w == 32), divided by 255 and fed to AffNet in batches of 128; rows of the
-output text file are `a11 a12 a21 a22` ('%10.5f').  cv2 is not available in this image, so the tile
-resize uses PIL (same bilinear kernel for the identity / integer cases the tests cover).
-"""
+COLUMN is an h x w grey image with h a multiple of w: every w x w tile is one patch.  Tiles are brought to 32 x 32
+(bilinear, identity when w == 32), scaled to 0..1 and pushed through AffNet 128 at a time; OUT gets one row
+`a11 a12 a21 a22` per patch ('%10.5f').  PIL does the resize (cv2 is not part of this image)."""
 import os
 import sys
 
@@ -16,38 +14,35 @@ import numpy as np
 import torch
 from PIL import Image
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, ROOT)
-from affnet_amd.architectures import AffNetFast  # noqa: E402
+REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, REPO)
+import affnet_amd  # noqa: E402
 
-PS = 32
-model = AffNetFast(PS=PS)
-checkpoint = torch.load(os.path.join(ROOT, "pretrained", "AffNet.pth"), map_location="cpu", weights_only=False)
-model.load_state_dict(checkpoint["state_dict"])
-model.eval()
-model.cuda()
+SIDE, CHUNK = 32, 128
 
-try:
-    input_img_fname = sys.argv[1]
-    output_fname = sys.argv[2]
-except Exception:
-    print("Wrong input format. Try ./detect_affine_shape.py imgs/ref.png out.txt")
-    sys.exit(1)
 
-image = np.array(Image.open(input_img_fname).convert("L"))
-h, w = image.shape
-n_patches = h // w
-patches = np.ndarray((n_patches, 1, PS, PS), dtype=np.float32)
-for i in range(n_patches):
-    patch = image[i * w:(i + 1) * w, 0:w]
-    if w != PS:
-        patch = np.array(Image.fromarray(patch).resize((PS, PS), Image.BILINEAR))
-    patches[i, 0, :, :] = patch / 255.0
-descriptors_for_net = np.zeros((n_patches, 4))
-bs = 128
-for st in range(0, n_patches, bs):
-    data_a = torch.from_numpy(patches[st:st + bs]).cuda()
+def tiles_of(column):
+    """(h, w) uint8 column -> (n, 1, 32, 32) float32 in 0..1."""
+    h, w = column.shape
+    tiles = column[: (h // w) * w].reshape(h // w, w, w)
+    if w != SIDE:
+        tiles = np.stack([np.asarray(Image.fromarray(t).resize((SIDE, SIDE), Image.BILINEAR)) for t in tiles])
+    return torch.from_numpy(tiles.astype(np.float32) / 255.0)[:, None]
+
+
+def main(argv):
+    if len(argv) != 2:
+        print("Wrong input format. Try ./detect_affine_shape.py imgs/ref.png out.txt")
+        return 1
+    net = affnet_amd.AffNetFast(PS=SIDE)
+    net.load_state_dict(torch.load(os.path.join(REPO, "pretrained", "AffNet.pth"), map_location="cpu", weights_only=False)["state_dict"])
+    net.cuda()
+    patches = tiles_of(np.asarray(Image.open(argv[0]).convert("L")))
     with torch.no_grad():
-        out_a = model(data_a)
-    descriptors_for_net[st:st + bs, :] = out_a.data.cpu().numpy().reshape(-1, 4)
-np.savetxt(output_fname, descriptors_for_net, delimiter=" ", fmt="%10.5f")
+        shapes = [net(patches[i:i + CHUNK].cuda()).reshape(-1, 4).cpu() for i in range(0, len(patches), CHUNK)]
+    np.savetxt(argv[1], torch.cat(shapes).numpy() if shapes else np.zeros((0, 4)), delimiter=" ", fmt="%10.5f")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main(sys.argv[1:]))
