@@ -46,6 +46,7 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
         self._ctx_key = None
         self.last_ids = None       # (N,3) int32 (octave, level-1, pixel) of the detections returned last
         self.max_keep = 16384      # row capacity in threshold mode (num = -1)
+        self.raw_div = 4           # raw-maxima list capacity per octave = h*w / raw_div (overflow -> AffnetHipError, never truncation)
 
     # ------------------------------------------------------------------------------------------
     def _context(self, x, allow_batch=False):
@@ -55,10 +56,10 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
                              "(HandCraftedModules.py:283-284) - use enqueue()/run_batch() for (B,1,H,W) batches")
         pre = int(1.5 * self.num) if self.num_Baum_iters > 0 else self.num
         key = (x.size(0), x.size(2), x.size(3), x.device, pre, self.num, float(self.th), self.mrSize, self.b, self.init_sigma,
-               self.max_keep, self.num_Baum_iters)
+               self.max_keep, self.num_Baum_iters, self.raw_div)
         if self._ctx is None or self._ctx_key != key:
             self._ctx = engine.Context(x.size(2), x.size(3), x.device, self.nlevels, self.init_sigma, self.b, self.mrSize,
-                                       float(self.th), self.num, pre, self.max_keep, batch=x.size(0), baum_iters=self.num_Baum_iters)
+                                       float(self.th), self.num, pre, self.max_keep, batch=x.size(0), baum_iters=self.num_Baum_iters, raw_div=self.raw_div)
             self._ctx_key = key
         return self._ctx
 

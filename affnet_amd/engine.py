@@ -35,10 +35,10 @@ class Context(object):
     """One extractor instance on one device: config, workspace, pyramid views."""
 
     def __init__(self, height, width, device, n_levels, init_sigma, border, mr_size, threshold,
-                 num_features, num_prefilter, max_keep=16384, batch=1, baum_iters=0):
+                 num_features, num_prefilter, max_keep=16384, batch=1, baum_iters=0, raw_div=4):
         self.plan = PyramidPlan(height, width, n_levels, init_sigma, border)
         self.batch = int(batch)
-        self.cfg = self.plan.fill_config(mr_size, threshold, num_features, num_prefilter, max_keep, batch=self.batch, baum_iters=baum_iters)
+        self.cfg = self.plan.fill_config(mr_size, threshold, num_features, num_prefilter, max_keep, raw_div=raw_div, batch=self.batch, baum_iters=baum_iters)
         self.device = device
         self.handle = C.c_void_p()
         idx = device.index if device.index is not None else torch.cuda.current_device()

@@ -568,6 +568,24 @@ def test_edge_cases(amd, nets):
     assert np.abs(L.cpu().numpy() - Lw.numpy()).max() < 1e-4          # (o,l,pixel) row order, LAFs to float noise
 
 
+def test_capacity_overflow_is_an_error_not_a_truncation(amd, nets):
+    """Fixed-capacity device lists: when a list overflows the library reports AFFNET_ERR_CAPACITY through the one read-back
+    (affnet_read_counts) instead of silently dropping keypoints."""
+    from affnet_amd._lib import AffnetHipError
+    A, O, H = nets
+    x = orc.synthetic_image(240, 320, 1).to(DEV)
+    det = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=1, AffNet=A, OriNet=O).to(DEV)
+    det.raw_div = 1 << 20                      # raw-maxima capacity 256 per octave; octave 0 of this image has ~700 maxima
+    with pytest.raises(AffnetHipError, match="overflow"):
+        det.run(x, do_ori=True)
+    det.raw_div = 4
+    assert det.run(x, do_ori=True)["LAFs"].shape[0] == 300
+    det = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=1, th=-1, AffNet=A).to(DEV)
+    det.max_keep = 64                          # threshold mode keeps every maximum: capacity 64 rows cannot hold ~1700
+    with pytest.raises(AffnetHipError, match="overflow"):
+        det.run(x)
+
+
 def test_full_size_properties_config3(amd, nets, weights):
     """1024x768, 2000 kp (the metric's configuration): size-independent properties + determinism."""
     A, O, H = nets
