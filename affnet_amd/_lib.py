@@ -83,6 +83,7 @@ SYMBOLS = {
     "affnet_profile_read": (_I, [_P, C.POINTER(C.c_double * 8), C.POINTER(C.c_int32)]),
     "affnet_read_counts": (_I, [_P, C.POINTER(C.c_int32 * 4), _P]),
     "affnet_host_base_grid": (_I, [_I, C.POINTER(C.c_float)]),
+    "affnet_cnn32_probe": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "affnet_selftest_mfma": (_I, [_P, _P, _P, _P]),
 }
 

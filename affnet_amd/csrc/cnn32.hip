@@ -234,7 +234,8 @@ __device__ __forceinline__ void prefetch_bias(const float* __restrict__ bias, f3
     for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const f32x4*>(&bias[(ng * TN + j) * 16 + 4 * (lane >> 4)]);   // channels 4g..4g+3
 }
 
-template <int NW, int CIN, int COUT, typename LI, int STRIDE, int TM, int TN, int GRP>
+// PROBE (tuning aid, affnet_cnn32_probe): bit 0 = skip the weight loads, bit 1 = skip the activation loads inside the loop.
+template <int NW, int CIN, int COUT, typename LI, int STRIDE, int TM, int TN, int GRP, int PROBE = 0>
 __device__ __forceinline__ void conv3x3_mfma(const float* act, const float* __restrict__ Wg, const f32x4 (&b0)[GRP][TN],
                                              f32x4 (&acc)[TM][TN], int wave, int lane) {
     constexpr int HOUT = LI::H / STRIDE;
@@ -273,10 +274,14 @@ __device__ __forceinline__ void conv3x3_mfma(const float* act, const float* __re
         return g0 * 4 * LI::PSG + (ky * LI::WP + kx) * 4;
     };
     auto load_group = [&](Frag<GRP, TM, TN>& f, int u, int a_off, const float* w) {
+        if (!(PROBE & 2)) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) f.a[u][i] = *reinterpret_cast<const f32x4*>(&act[a_off + u * 4 * LI::PSG + a_base[i]]);
+            for (int i = 0; i < TM; ++i) f.a[u][i] = *reinterpret_cast<const f32x4*>(&act[a_off + u * 4 * LI::PSG + a_base[i]]);
+        }
+        if (!(PROBE & 1)) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) f.b[u][j] = *reinterpret_cast<const f32x4*>(&w[u * 16 * COUT + b_base[j]]);
+            for (int j = 0; j < TN; ++j) f.b[u][j] = *reinterpret_cast<const f32x4*>(&w[u * 16 * COUT + b_base[j]]);
+        }
     };
     auto mfma_group = [&](const Frag<GRP, TM, TN>& f, int u) {
 #pragma unroll
@@ -294,8 +299,26 @@ __device__ __forceinline__ void conv3x3_mfma(const float* act, const float* __re
 #pragma unroll
         for (int u = 0; u < GRP; ++u) {
             load_group(nxt, u, a_off, w);
-            __builtin_amdgcn_sched_barrier(0);
             mfma_group(cur, u);
+            // Schedule: the TM ds_read_b128 and TN global_load_dwordx4 of this group are spread BETWEEN its MFMAs (one load
+            // after every Q MFMAs) instead of being issued as a burst in front of them.  A wave cannot issue an MFMA while it
+            // issues a load (a 1 KB dwordx4 wave-load holds the issue slot for tens of cycles); with bursts at the group
+            // boundaries both waves of a SIMD tended to be in their bursts together and the pipe idled ~8 % of the loop
+            // (tools/mfma_probe.py: conv1 81.7 % -> 88.5 % of peak with the weight loads removed).
+            constexpr int NM = 4 * TM * TN, NL = ((PROBE & 2) ? 0 : TM) + ((PROBE & 1) ? 0 : TN), Q = NL ? NM / (NL + 1) : NM;
+            // weight loads (L2, long latency) first, activation loads (LDS) after them
+#pragma unroll
+            for (int l = 0; l < ((PROBE & 1) ? 0 : TN); ++l) {
+                if (l == 0) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                else __builtin_amdgcn_sched_group_barrier(0x008, Q, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+#pragma unroll
+            for (int l = 0; l < ((PROBE & 2) ? 0 : TM); ++l) {
+                __builtin_amdgcn_sched_group_barrier(0x008, Q, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);      // whatever MFMAs remain
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -309,6 +332,7 @@ __device__ __forceinline__ void conv3x3_mfma(const float* act, const float* __re
             for (int j = 0; j < TN; ++j) f0.b[u][j] = b0[u][j];
         }
     }
+    if (PROBE) f1 = f0;
 #pragma unroll 1
     for (int ch = 0; ch + 1 < NCHUNK; ch += 2) {
         stage(f0, f1, ch + 1);
@@ -1269,6 +1293,46 @@ extern "C" int affnet_cnn32_debug_layer(affnet_ctx* ctx, int net_kind, const flo
                                         void* stream) {
     if (!ctx || !d_patch || !d_out || layer < 0 || layer > 5) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32_debug_layer: bad argument");
     return cnn_launch(ctx, net_kind, d_packed, d_patch, nullptr, nullptr, nullptr, 1, d_out, nullptr, layer, d_out, (hipStream_t)stream);
+}
+
+// ---- tuning aid: one HardNet layer's MFMA loop in isolation (no barriers, no epilogue), repeated ----------------------
+template <int LAYER, int PROBE>
+__global__ __launch_bounds__(512, 2) void cnn32_probe_kernel(const float* __restrict__ packed, NetOffsets off, int reps, float* __restrict__ out) {
+    constexpr int CB = 32, NW = 8;
+    __shared__ __attribute__((aligned(16))) float lds[TrunkLds<CB>::TOTAL];     // same footprint as the trunk: 1 workgroup / CU
+    for (int i = threadIdx.x; i < TrunkLds<CB>::TOTAL; i += 512) lds[i] = 0.001f * (float)(i & 255);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float sink = 0.f;
+    for (int r = 0; r < reps; ++r) {
+        if (LAYER == 1) {
+            f32x4 acc[8][2], b0[1][2];
+            prefetch_b0<NW, CB, 32, 8, 2, 1>(packed + off.w[1], b0, wave, lane);
+            conv3x3_mfma<NW, CB, CB, LayC0, 1, 8, 2, 1, PROBE>(lds, packed + off.w[1], b0, acc, wave, lane);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sink += acc[i][0][0] + acc[i][1][3];
+        } else {
+            f32x4 acc[4][1], b0[2][1];
+            prefetch_b0<NW, 4 * CB, 8, 4, 1, 2>(packed + off.w[5], b0, wave, lane);
+            conv3x3_mfma<NW, 4 * CB, 4 * CB, LayC4, 1, 4, 1, 2, PROBE>(lds, packed + off.w[5], b0, acc, wave, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) sink += acc[i][0][0] + acc[i][0][3];
+        }
+    }
+    if (sink == 12345.678f) out[0] = sink;
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[1] = sink;
+}
+
+// layer: 1 (conv1, TM 8 x TN 2) or 5 (conv5, TM 4 x TN 1, 2 groups / chunk); probe: PROBE bits; d_out: 2 floats.
+extern "C" int affnet_cnn32_probe(const float* d_packed_hardnet, int layer, int probe, int reps, int n_blocks, float* d_out, void* stream) {
+    if (!d_packed_hardnet || !d_out || (layer != 1 && layer != 5) || probe < 0 || probe > 3) return AFFNET_ERR_INVALID;
+    const NetOffsets off = to_offsets(net_layout(AFFNET_NET_HARDNET));
+    hipStream_t st = (hipStream_t)stream;
+#define PROBE_CASE(L, P) if (layer == L && probe == P) hipLaunchKernelGGL((cnn32_probe_kernel<L, P>), dim3(n_blocks), dim3(512), 0, st, d_packed_hardnet, off, reps, d_out)
+    PROBE_CASE(1, 0); PROBE_CASE(1, 1); PROBE_CASE(1, 2); PROBE_CASE(1, 3);
+    PROBE_CASE(5, 0); PROBE_CASE(5, 1); PROBE_CASE(5, 2); PROBE_CASE(5, 3);
+#undef PROBE_CASE
+    return hipGetLastError() == hipSuccess ? AFFNET_OK : AFFNET_ERR_HIP;
 }
 
 // ---- MFMA layout self-test ------------------------------------------------------------------------------
