@@ -49,6 +49,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // (columns = 16 pixels), i.e. each 16x16 tile is out^T[channel][pixel].  A lane then owns FOUR CONSECUTIVE CHANNELS of one
 // pixel (rows 4g..4g+3 of column lane&15) = exactly one float4 of the interleaved layout, so the epilogue is one
 // conflict-free ds_write_b128 per tile instead of four 4-way-conflicting ds_write_b32.
+// LDS reads of the MFMA loops go through an explicit 32-bit LDS byte address: one address VGPR per K group (made
+// opaque to the optimiser) + a compile-time immediate per tile.  Left to itself the compiler folds the chunk constant
+// into every tile offset, overflows the 16-bit DS offset field and spends one v_add_u32 per ds_read_b128 inside the
+// MFMA stream (conv1: 8 per 64 MFMAs, -12 % MFMA rate in tools/mfma_probe.py).
+typedef __attribute__((address_space(3))) const f32x4 LdsF4;
+__device__ __forceinline__ unsigned lds_byte_addr(const float* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const float*)p;
+}
+__device__ __forceinline__ f32x4 lds_read4(unsigned byte_addr) { return *(LdsF4*)(size_t)byte_addr; }
+
 template <int H_, int WP_, int PSG_>
 struct Lay {
     static constexpr int H = H_, WP = WP_, PSG = PSG_;
@@ -234,7 +244,8 @@ __device__ __forceinline__ void prefetch_bias(const float* __restrict__ bias, f3
     for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const f32x4*>(&bias[(ng * TN + j) * 16 + 4 * (lane >> 4)]);   // channels 4g..4g+3
 }
 
-// PROBE (tuning aid, affnet_cnn32_probe): bit 0 = skip the weight loads, bit 1 = skip the activation loads inside the loop.
+// PROBE (tuning aid, affnet_cnn32_probe): bit 0 = skip the weight loads, bit 1 = skip the activation loads inside the loop,
+// bit 3 = activation reads from lane-consecutive addresses (bank-conflict-free reference pattern).
 template <int NW, int CIN, int COUT, typename LI, int STRIDE, int TM, int TN, int GRP, int PROBE = 0>
 __device__ __forceinline__ void conv3x3_mfma(const float* act, const float* __restrict__ Wg, const f32x4 (&b0)[GRP][TN],
                                              f32x4 (&acc)[TM][TN], int wave, int lane) {
@@ -255,10 +266,12 @@ __device__ __forceinline__ void conv3x3_mfma(const float* act, const float* __re
         a_lane = kq * LI::PSG + ((oy * STRIDE) * LI::WP + ox * STRIDE) * 4;
     }
     const int b_lane = (kq * COUT + ng * TN * 16 + m) * 4;
-    int a_base[TM], b_base[TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-        a_base[i] = a_lane + (HOUT == 8 ? i * 2 * STRIDE * LI::WP * 4 : (((i * 16) / HOUT) * STRIDE * LI::WP + ((i * 16) % HOUT) * STRIDE) * 4);
+    if (PROBE & 8) a_lane = lane * 4;                      // probe: 64 consecutive float4 per read = the conflict-free ideal
+    const unsigned a_addr0 = lds_byte_addr(act) + a_lane * 4;
+    auto a_imm = [](int i) {                               // byte offset of tile i from tile 0 (compile-time after unrolling)
+        return 4 * ((PROBE & 8) ? i * 256 : (HOUT == 8 ? i * 2 * STRIDE * LI::WP * 4 : (((i * 16) / HOUT) * STRIDE * LI::WP + ((i * 16) % HOUT) * STRIDE) * 4));
+    };
+    int b_base[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) b_base[j] = b_lane + j * 64;
 #pragma unroll
@@ -275,8 +288,10 @@ __device__ __forceinline__ void conv3x3_mfma(const float* act, const float* __re
     };
     auto load_group = [&](Frag<GRP, TM, TN>& f, int u, int a_off, const float* w) {
         if (!(PROBE & 2)) {
+            unsigned ab = a_addr0 + (a_off + u * 4 * LI::PSG) * 4;
+            asm("" : "+v"(ab));
 #pragma unroll
-            for (int i = 0; i < TM; ++i) f.a[u][i] = *reinterpret_cast<const f32x4*>(&act[a_off + u * 4 * LI::PSG + a_base[i]]);
+            for (int i = 0; i < TM; ++i) f.a[u][i] = lds_read4(ab + a_imm(i));
         }
         if (!(PROBE & 1)) {
 #pragma unroll
@@ -326,13 +341,17 @@ __device__ __forceinline__ void conv3x3_mfma(const float* act, const float* __re
         const int a_off = a_chunk_off(0);
 #pragma unroll
         for (int u = 0; u < GRP; ++u) {
+            const unsigned ab = a_addr0 + (a_off + u * 4 * LI::PSG) * 4;
 #pragma unroll
-            for (int i = 0; i < TM; ++i) f0.a[u][i] = *reinterpret_cast<const f32x4*>(&act[a_off + u * 4 * LI::PSG + a_base[i]]);
+            for (int i = 0; i < TM; ++i) f0.a[u][i] = lds_read4(ab + a_imm(i));
 #pragma unroll
             for (int j = 0; j < TN; ++j) f0.b[u][j] = b0[u][j];
         }
     }
     if (PROBE) f1 = f0;
+    // (The two waves of a workgroup that share a SIMD do not advance evenly - the older one wins the arbitration and leaves
+    // the loop ~12 % earlier.  Alternating s_setprio between them evens that out but the pair's finish time, set by the
+    // MFMA pipe, does not move: measured, not kept.)
 #pragma unroll 1
     for (int ch = 0; ch + 1 < NCHUNK; ch += 2) {
         stage(f0, f1, ch + 1);
@@ -367,10 +386,11 @@ __device__ __forceinline__ void conv3x3_mfma_roll(const float* act, const float*
         a_lane = kq * LI::PSG + ((oy * STRIDE) * LI::WP + ox * STRIDE) * 4;
     }
     const int b_lane = (kq * COUT + ng * TN * 16 + m) * 4;
-    int a_base[TM], b_base[TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-        a_base[i] = a_lane + (HOUT == 8 ? i * 2 * STRIDE * LI::WP * 4 : (((i * 16) / HOUT) * STRIDE * LI::WP + ((i * 16) % HOUT) * STRIDE) * 4);
+    const unsigned a_addr0 = lds_byte_addr(act) + a_lane * 4;
+    auto a_imm = [](int i) {                               // byte offset of tile i from tile 0 (compile-time after unrolling)
+        return 4 * (HOUT == 8 ? i * 2 * STRIDE * LI::WP * 4 : (((i * 16) / HOUT) * STRIDE * LI::WP + ((i * 16) % HOUT) * STRIDE) * 4);
+    };
+    int b_base[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) b_base[j] = b_lane + j * 64;
 #pragma unroll
@@ -386,12 +406,13 @@ __device__ __forceinline__ void conv3x3_mfma_roll(const float* act, const float*
     {
         const int a_off = a_chunk_off(0);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const f32x4*>(&act[a_off + a_base[i]]);
+        for (int i = 0; i < TM; ++i) fa[i] = lds_read4(a_addr0 + a_off * 4 + a_imm(i));
 #pragma unroll
         for (int j = 0; j < TN; ++j) fb0[j] = b0[0][j];
     }
     auto chunk = [&](const f32x4 (&bc)[TN], f32x4 (&bn)[TN], int nxt_ch) {
-        const int a_off = a_chunk_off(nxt_ch);
+        unsigned ab = a_addr0 + a_chunk_off(nxt_ch) * 4;
+        asm("" : "+v"(ab));
         const float* w = Wg + (size_t)nxt_ch * (16 * COUT);
 #pragma unroll
         for (int j = 0; j < TN; ++j) bn[j] = *reinterpret_cast<const f32x4*>(&w[b_base[j]]);
@@ -407,7 +428,7 @@ __device__ __forceinline__ void conv3x3_mfma_roll(const float* act, const float*
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bc[j][s4], fa[i][s4], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = ip; i < ip + 2; ++i) fa[i] = *reinterpret_cast<const f32x4*>(&act[a_off + a_base[i]]);
+            for (int i = ip; i < ip + 2; ++i) fa[i] = lds_read4(ab + a_imm(i));
         }
     };
 #pragma unroll 1
@@ -1304,17 +1325,18 @@ __global__ __launch_bounds__(512, 2) void cnn32_probe_kernel(const float* __rest
     __syncthreads();
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float sink = 0.f;
+    if (PROBE & 4) asm volatile("; accumulators in AGPRs" ::"a"(sink));     // any 'a' operand switches the MFMAs to their AGPR form
     for (int r = 0; r < reps; ++r) {
         if (LAYER == 1) {
             f32x4 acc[8][2], b0[1][2];
             prefetch_b0<NW, CB, 32, 8, 2, 1>(packed + off.w[1], b0, wave, lane);
-            conv3x3_mfma<NW, CB, CB, LayC0, 1, 8, 2, 1, PROBE>(lds, packed + off.w[1], b0, acc, wave, lane);
+            conv3x3_mfma<NW, CB, CB, LayC0, 1, 8, 2, 1, (PROBE & 11)>(lds, packed + off.w[1], b0, acc, wave, lane);
 #pragma unroll
             for (int i = 0; i < 8; ++i) sink += acc[i][0][0] + acc[i][1][3];
         } else {
             f32x4 acc[4][1], b0[2][1];
             prefetch_b0<NW, 4 * CB, 8, 4, 1, 2>(packed + off.w[5], b0, wave, lane);
-            conv3x3_mfma<NW, 4 * CB, 4 * CB, LayC4, 1, 4, 1, 2, PROBE>(lds, packed + off.w[5], b0, acc, wave, lane);
+            conv3x3_mfma<NW, 4 * CB, 4 * CB, LayC4, 1, 4, 1, 2, (PROBE & 11)>(lds, packed + off.w[5], b0, acc, wave, lane);
 #pragma unroll
             for (int i = 0; i < 4; ++i) sink += acc[i][0][0] + acc[i][0][3];
         }
@@ -1325,12 +1347,12 @@ __global__ __launch_bounds__(512, 2) void cnn32_probe_kernel(const float* __rest
 
 // layer: 1 (conv1, TM 8 x TN 2) or 5 (conv5, TM 4 x TN 1, 2 groups / chunk); probe: PROBE bits; d_out: 2 floats.
 extern "C" int affnet_cnn32_probe(const float* d_packed_hardnet, int layer, int probe, int reps, int n_blocks, float* d_out, void* stream) {
-    if (!d_packed_hardnet || !d_out || (layer != 1 && layer != 5) || probe < 0 || probe > 3) return AFFNET_ERR_INVALID;
+    if (!d_packed_hardnet || !d_out || (layer != 1 && layer != 5) || probe < 0 || probe > 15) return AFFNET_ERR_INVALID;
     const NetOffsets off = to_offsets(net_layout(AFFNET_NET_HARDNET));
     hipStream_t st = (hipStream_t)stream;
 #define PROBE_CASE(L, P) if (layer == L && probe == P) hipLaunchKernelGGL((cnn32_probe_kernel<L, P>), dim3(n_blocks), dim3(512), 0, st, d_packed_hardnet, off, reps, d_out)
-    PROBE_CASE(1, 0); PROBE_CASE(1, 1); PROBE_CASE(1, 2); PROBE_CASE(1, 3);
-    PROBE_CASE(5, 0); PROBE_CASE(5, 1); PROBE_CASE(5, 2); PROBE_CASE(5, 3);
+    PROBE_CASE(1, 0); PROBE_CASE(1, 1); PROBE_CASE(1, 2); PROBE_CASE(1, 3); PROBE_CASE(1, 4); PROBE_CASE(1, 8); PROBE_CASE(1, 9);
+    PROBE_CASE(5, 0); PROBE_CASE(5, 1); PROBE_CASE(5, 2); PROBE_CASE(5, 3); PROBE_CASE(5, 4); PROBE_CASE(5, 8); PROBE_CASE(5, 9);
 #undef PROBE_CASE
     return hipGetLastError() == hipSuccess ? AFFNET_OK : AFFNET_ERR_HIP;
 }

@@ -88,7 +88,7 @@ def main():
                     help="images per fused library call (every kernel launch covers `chunk` images)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("AFFNET_BENCH_STREAMS", "1")),
                     help="independent streams (each with its own context) the chunks alternate over")
-    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("AFFNET_BENCH_PIPELINE", "1")),
+    ap.add_argument("--pipeline", type=int, default=int(os.environ.get("AFFNET_BENCH_PIPELINE", "0")),
                     help="1 (with --streams 1): pyramid + detector of chunk i+1 run on a second stream next to the CNN stages of "
                          "chunk i (two contexts alternate); the CNN kernels stay serialised on one stream")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -10,7 +10,7 @@ import affnet_amd
 from affnet_amd._lib import lib, ptr
 
 dev = torch.device("cuda:0")
-n = 2048
+n = int(os.environ.get("PHASE_PATCHES", "2048"))      # 256 = one workgroup per CU: the phases without a co-resident workgroup
 p = (torch.rand(n, 1, 32, 32) * 255).to(dev)
 A = affnet_amd.AffNetFast(); A.load_state_dict(torch.load(os.path.join(ROOT, "pretrained/AffNet.pth"), map_location="cpu", weights_only=False)["state_dict"]); A.to(dev)
 H = affnet_amd.HardNet(); H.load_state_dict(affnet_amd.synthetic_hardnet_state(0)); H.to(dev)
@@ -23,7 +23,7 @@ for net, nm, nw in [(A, "AffNet", 8), (H, "HardNet", int(os.environ.get("AFFNET_
     net(p); torch.cuda.synchronize()
     lib.affnet_cnn32_debug_timing(None)
     t = st.cpu().numpy().reshape(n, nw, 32).astype(np.float64)
-    nst = 12 if nm == "HardNet" else 13
+    nst = 12
     d = np.diff(t[:, :, :nst], axis=2)              # cycles per phase per wave
     wg = t[:, :, :nst].max(axis=1) - t[:, :, 0:1].min(axis=1)   # per patch: boundary times relative to WG start
     print("== %s (%d waves): mean phase cycles per wave (s_memtime ticks, 100 MHz const clock?)" % (nm, nw))
@@ -33,6 +33,20 @@ for net, nm, nw in [(A, "AffNet", 8), (H, "HardNet", int(os.environ.get("AFFNET_
     for i in range(nst - 1):
         print("  %-12s mean %9.0f  max-over-waves %9.0f" % (names[i], d[:, :, i].mean(), d[:, :, i].max(axis=1).mean()))
     print("  total per patch (WG) %.0f ticks" % tot)
+    simd = (st.cpu().numpy().reshape(n, nw, 32)[:, :, 14] >> 4) & 3
+    for i in (2, 6, 10):
+        print("  %-12s per wave:" % names[i], " ".join("%6.0f" % v for v in d[:, :, i].mean(axis=0)))
+    # the two waves of a workgroup that share a SIMD: how far apart do they finish a loop?
+    first, second = [], []
+    for k in range(0, n, max(1, n // 128)):
+        for sd in range(4):
+            w = np.where(simd[k] == sd)[0]
+            if len(w) == 2:
+                a, b = d[k, w[0], 2], d[k, w[1], 2]
+                first.append(min(a, b)); second.append(max(a, b))
+    if first:
+        print("  conv1 mfma, SIMD-sharing pairs: faster wave %.0f, slower wave %.0f ticks; SIMD ids of waves 0..%d in patch 0: %s" %
+              (np.mean(first), np.mean(second), nw - 1, simd[0].tolist()))
     ti = st.cpu().numpy().reshape(n, nw, 32)
     start, end = ti[:, :, 0].min(axis=1).astype(np.float64), ti[:, :, 13].max(axis=1).astype(np.float64)
     print("  last phase stamp -> kernel end (head / global store): %.0f ticks" % (ti[:, :, 13] - ti[:, :, nst - 1]).mean())
