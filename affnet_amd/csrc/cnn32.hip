@@ -537,6 +537,70 @@ __device__ __forceinline__ void store_tiles_global(float* __restrict__ dst, cons
     }
 }
 
+// AffNet / OriNet heads, first half, straight from the conv5 accumulators (no conv5 tensor in HBM): a lane owns channels
+// c4..c4+3 of pixel p of each of its tiles = one float4 of the head weights [o][pixel][channel]; it forms its share of
+// every head dot product, the wave reduces them and lane 0 writes the wave's partial sums to part[wave][*].  The eight
+// partials per patch are combined in fixed order by cnn16_finish_kernel (bit-reproducible, no atomics).
+//   AffNet: 3 outputs  = conv 64 -> 3, 8x8 valid                   (architectures.py:227-229)      part[8][4]
+//   OriNet: 2 x 9      = conv 64 -> 2, 8x8, padding 1 -> 3x3 map   (architectures.py:56-58)        part[8][18]
+#define HEAD_PART_AFF 32
+#define HEAD_PART_ORI 144
+template <int KIND, int TM>
+__device__ __forceinline__ void head_partials(const float* __restrict__ hw, const f32x4 (&bias)[1], const f32x4 (&acc)[TM][1],
+                                              float* __restrict__ part, int wave, int lane) {
+    constexpr int MT = 4, MG = MT / TM;
+    const int mg = wave % MG, ng = wave / MG;
+    const int n = lane & 15, g = lane >> 4;
+    const int c4 = ng * 16 + 4 * g;
+    f32x4 v[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        v[i] = acc[i][0] + bias[0];
+        v[i].x = fmaxf(v[i].x, 0.0f); v[i].y = fmaxf(v[i].y, 0.0f); v[i].z = fmaxf(v[i].z, 0.0f); v[i].w = fmaxf(v[i].w, 0.0f);
+    }
+    if (KIND == AFFNET_NET_AFFNET) {
+        f32x4 w[3][TM];
+#pragma unroll
+        for (int o = 0; o < 3; ++o)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) w[o][i] = *reinterpret_cast<const f32x4*>(hw + o * 4096 + ((mg * TM + i) * 16 + n) * 64 + c4);
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sacc = fmaf(v[i][j], w[o][i][j], sacc);
+            sacc = wave_sum(sacc);
+            if (lane == 0) part[wave * 4 + o] = sacc;
+        }
+    } else {
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            f32x4 w[9][TM];
+#pragma unroll
+            for (int q = 0; q < 9; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int p = (mg * TM + i) * 16 + n, py = p >> 3, px = p & 7;
+                    const int ky = py - q / 3 + 1, kx = px - q % 3 + 1;                    // padding 1: tap that sees this pixel
+                    const bool ok = ky >= 0 && ky < 8 && kx >= 0 && kx < 8;
+                    w[q][i] = ok ? *reinterpret_cast<const f32x4*>(hw + o * 4096 + (ky * 8 + kx) * 64 + c4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+            for (int q = 0; q < 9; ++q) {
+                float sacc = 0.f;
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) sacc = fmaf(v[i][j], w[q][i][j], sacc);
+                sacc = wave_sum(sacc);
+                if (lane == 0) part[wave * 18 + o * 9 + q] = sacc;
+            }
+        }
+    }
+}
+
 struct PyrSrc {            // pyramid sampling source (fused sampler)
     const float* lvl[AFFNET_MAX_OCTAVES][AFFNET_MAX_LEVELS];
     int h[AFFNET_MAX_OCTAVES], w[AFFNET_MAX_OCTAVES];
@@ -775,8 +839,12 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         conv3x3_mfma<NW, 4 * CB, 4 * CB, LayC4, 1, T4M, T4N, G5>(act, a.packed + a.off.w[5], b5, acc, wave, lane);
         if (PRIO) __builtin_amdgcn_s_setprio(3);
         CNN_STAMP(11);
-        if (a.dbg_layer < 0) {      // conv5 tensor -> HBM as [pixel][channel]; the heads run as separate kernels over all patches
-            store_tiles_global<4 * CB, T4M, T4N>(a.out + pidx * (64 * 4 * CB), bias5, acc, wave, lane);
+        if (a.dbg_layer < 0) {
+            if constexpr (KIND == AFFNET_NET_HARDNET)   // conv5 tensor -> HBM as [pixel][channel]; the head GEMM runs over all patches
+                store_tiles_global<4 * CB, T4M, T4N>(a.out + pidx * (64 * 4 * CB), bias5, acc, wave, lane);
+            else                                        // per-wave partial sums of the head's dot products
+                head_partials<KIND, T4M>(a.packed + a.off.head_w, bias5, acc,
+                                         a.out + pidx * (KIND == AFFNET_NET_AFFNET ? HEAD_PART_AFF : HEAD_PART_ORI), wave, lane);
             CNN_STAMP(13);
             return;
         }
@@ -788,344 +856,45 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
     if (a.dbg_layer == 5) { dump_planes<4 * CB, LayC5, NTHR>(act, a.dbg_out); return; }
 }
 
-// ---- AffNet / OriNet heads over the conv5 tensors [patch][pixel][channel] (16 KB per patch) -------------------------
-// Kept out of the trunk kernels on purpose: inside them the head was a chain of latency-bound steps (LDS exchange,
-// group syncs, one lane of tanh / atan2 / divisions) during which the workgroup held its 80 KB of LDS without issuing
-// a single MFMA - 8-30k cycles per patch next to a partner's MFMA loop.  Here one workgroup handles one patch.
-//   AffNet : conv 64 -> 3, 8x8 valid, + bias -> tanh -> [[1+x0, 0],[x1, 1+x2]] -> rectifyAffineTransformationUpIsUp
+// ---- AffNet / OriNet heads, second half: combine the eight per-wave partials of a patch, one thread per patch -------
+//   AffNet : + bias -> tanh -> [[1+x0, 0],[x1, 1+x2]] -> rectifyAffineTransformationUpIsUp
 //            (architectures.py:227-229,246-252, LAF.py:285-291)
-//   OriNet : conv 64 -> 2, 8x8, padding 1 -> 3x3 -> tanh -> mean -> atan2 -> rotation (architectures.py:56-58,76-82)
+//   OriNet : + bias -> tanh -> mean over the 3x3 map -> atan2 -> rotation (architectures.py:56-58,76-82, LAF.py:276-283)
 template <int KIND>
-__global__ __launch_bounds__(256) void cnn16_head_kernel(const float* __restrict__ trunk, const float* __restrict__ hw, const float* __restrict__ hb,
-                                                         const int32_t* __restrict__ count, int n_max, float* __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) float tile[4096];
-    __shared__ float redh[4 * 18];
+__global__ __launch_bounds__(256) void cnn16_finish_kernel(const float* __restrict__ part, const float* __restrict__ hb,
+                                                           const int32_t* __restrict__ count, int n_max, float* __restrict__ out) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
     const int n = count ? min(count[blockIdx.y], n_max) : n_max;
-    if ((int)blockIdx.x >= n) return;
-    const size_t pidx = (size_t)blockIdx.y * n_max + blockIdx.x;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const float* src = trunk + pidx * 4096;
+    if (row >= n) return;
+    const size_t pidx = (size_t)blockIdx.y * n_max + row;
+    float* o = out + 4 * pidx;
     if (KIND == AFFNET_NET_AFFNET) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+        const f32x4* pp = reinterpret_cast<const f32x4*>(part + pidx * HEAD_PART_AFF);
+        f32x4 r[8];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = (tid + 256 * i) * 4;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(src + e);
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(hw + e), w1 = *reinterpret_cast<const f32x4*>(hw + 4096 + e),
-                        w2 = *reinterpret_cast<const f32x4*>(hw + 8192 + e);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { s0 = fmaf(v[j], w0[j], s0); s1 = fmaf(v[j], w1[j], s1); s2 = fmaf(v[j], w2[j], s2); }
-        }
-        s0 = wave_sum(s0); s1 = wave_sum(s1); s2 = wave_sum(s2);
-        if (lane == 0) { redh[4 * wave] = s0; redh[4 * wave + 1] = s1; redh[4 * wave + 2] = s2; }
-        __syncthreads();
-        if (tid == 0) {
-            s0 = (redh[0] + redh[4]) + (redh[8] + redh[12]); s1 = (redh[1] + redh[5]) + (redh[9] + redh[13]);
-            s2 = (redh[2] + redh[6]) + (redh[10] + redh[14]);
-            const float x0 = tanhf(s0 + hb[0]), x1 = tanhf(s1 + hb[1]), x2 = tanhf(s2 + hb[2]);
-            const float a00 = 1.0f + x0, a01 = 0.0f * x0, a10 = x1, a11 = 1.0f + x2;
-            const float det = sqrtf(fabsf(a00 * a11 - a10 * a01 + 1e-10f));
-            const float b2a2 = sqrtf(a01 * a01 + a00 * a00);
-            float* o = out + 4 * pidx;
-            o[0] = b2a2 / det; o[1] = 0.0f * det;
-            o[2] = (a11 * a01 + a10 * a00) / (b2a2 * det); o[3] = det / b2a2;
-        }
+        for (int w = 0; w < 8; ++w) r[w] = pp[w];
+        const f32x4 s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        const float x0 = tanhf(s.x + hb[0]), x1 = tanhf(s.y + hb[1]), x2 = tanhf(s.z + hb[2]);
+        const float a00 = 1.0f + x0, a01 = 0.0f * x0, a10 = x1, a11 = 1.0f + x2;
+        const float det = sqrtf(fabsf(a00 * a11 - a10 * a01 + 1e-10f));
+        const float b2a2 = sqrtf(a01 * a01 + a00 * a00);
+        o[0] = b2a2 / det; o[1] = 0.0f * det;
+        o[2] = (a11 * a01 + a10 * a00) / (b2a2 * det); o[3] = det / b2a2;
     } else {
+        const float* pp = part + pidx * HEAD_PART_ORI;
+        float t0 = 0.f, t1 = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int e = (tid + 256 * i) * 4;
-            *reinterpret_cast<f32x4*>(&tile[e]) = *reinterpret_cast<const f32x4*>(src + e);
+        for (int q = 0; q < 9; ++q) {
+            float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; w += 2) { r0 += pp[w * 18 + q] + pp[(w + 1) * 18 + q]; r1 += pp[w * 18 + 9 + q] + pp[(w + 1) * 18 + 9 + q]; }
+            t0 += tanhf(r0 + hb[0]); t1 += tanhf(r1 + hb[1]);
         }
-        __syncthreads();
-        float s[2][9];
-#pragma unroll
-        for (int o = 0; o < 2; ++o)
-#pragma unroll
-            for (int q = 0; q < 9; ++q) s[o][q] = 0.f;
-        for (int e = tid; e < 4096; e += 256) {          // e = (ky*8 + kx)*64 + c : one weight of the 8x8 kernel
-            const int c = e & 63, kk = e >> 6, ky = kk >> 3, kx = kk & 7;
-            const float w0 = hw[e], w1 = hw[4096 + e];
-#pragma unroll
-            for (int q = 0; q < 9; ++q) {
-                const int py = q / 3 + ky - 1, px = q % 3 + kx - 1;                     // padding 1
-                const float vv = (py >= 0 && py < 8 && px >= 0 && px < 8) ? tile[(py * 8 + px) * 64 + c] : 0.0f;
-                s[0][q] = fmaf(vv, w0, s[0][q]); s[1][q] = fmaf(vv, w1, s[1][q]);
-            }
-        }
-#pragma unroll
-        for (int o = 0; o < 2; ++o)
-#pragma unroll
-            for (int q = 0; q < 9; ++q) s[o][q] = wave_sum(s[o][q]);
-        if (lane == 0) {
-#pragma unroll
-            for (int o = 0; o < 2; ++o)
-#pragma unroll
-                for (int q = 0; q < 9; ++q) redh[wave * 18 + o * 9 + q] = s[o][q];
-        }
-        __syncthreads();
-        if (tid == 0) {
-            float t0 = 0.f, t1 = 0.f;
-#pragma unroll
-            for (int q = 0; q < 9; ++q) {
-                const float r0 = (redh[q] + redh[18 + q]) + (redh[36 + q] + redh[54 + q]);
-                const float r1 = (redh[9 + q] + redh[27 + q]) + (redh[45 + q] + redh[63 + q]);
-                t0 += tanhf(r0 + hb[0]); t1 += tanhf(r1 + hb[1]);
-            }
-            const float yv = t0 / 9.0f, xv = t1 / 9.0f;                       // AdaptiveAvgPool2d(1)
-            const float ang = atan2f(yv + 1e-8f, xv + 1e-8f);                 // architectures.py:78
-            const float sn = sinf(ang), cs = cosf(ang);
-            float* o = out + 4 * pidx;
-            o[0] = cs; o[1] = sn; o[2] = -sn; o[3] = cs;                      // LAF.py:276-283
-        }
+        const float yv = t0 / 9.0f, xv = t1 / 9.0f;                       // AdaptiveAvgPool2d(1)
+        const float ang = atan2f(yv + 1e-8f, xv + 1e-8f);                 // architectures.py:78
+        const float sn = sinf(ang), cs = cosf(ang);
+        o[0] = cs; o[1] = sn; o[2] = -sn; o[3] = cs;
     }
-}
-
-// ---- AffNet / OriNet: two patches per workgroup, in anti-phase --------------------------------------------------
-// With one patch per workgroup and two workgroups per CU the matrix pipe idles whenever both workgroups are outside
-// their MFMA loops at the same time - a quarter of the time, because their input / conv0 / epilogue / head phases are
-// as long as HardNet's while the MFMA work is 4x smaller (and they run 5-10x slower next to a partner's MFMA loop).
-// Here ONE persistent workgroup of 16 wavefronts owns the CU: group 0 (waves 0-7) and group 1 (waves 8-15) each walk
-// their own stream of patches through the same program of alternating slots
-//     E* | M1 | E1 | M2 | E2 | M3 | E3 | M4 | E4 | M5 | (E* of the next patch) ...
-// (M_k = MFMA loop of conv k; E_k = its epilogue; E* = conv5 epilogue (global store) of the previous patch, then input,
-// standardisation and conv0 of the next), separated by workgroup-wide s_barrier "ticks".  Group 1 starts one tick late,
-// so in every tick exactly one group is in an MFMA loop (alone on the pipe: 2 waves / SIMD) while the other one does its
-// short latency-bound slot in its shadow and then waits at the barrier.  Synchronisation inside an E* slot (reductions,
-// patch -> conv0) cannot use s_barrier (the partner is in the middle of a loop): a group-local barrier on an LDS counter.
-struct GroupBar {
-    int* cnt;
-    int target;
-    __device__ __forceinline__ void sync(int lane) {
-        target += 8;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");           // this wave's LDS writes are done before it arrives
-        if (lane == 0) {
-            __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < target) __builtin_amdgcn_s_sleep(1);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    }
-};
-
-__device__ __forceinline__ void duo_tick() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-template <int KIND>
-__global__ __launch_bounds__(1024) void cnn16_duo_kernel(CnnArgs a, PyrSrc ps, int total_rows, int antiphase) {
-    constexpr int CB = 16, NW = 8, NTHR = 512, PPT = 2, RPT = 16;
-    constexpr int T1M = 8, T1N = 1, T2M = 2, T2N = 2, T4M = 2, T4N = 1, AREG = 48;
-    constexpr int G2 = pick_groups(CB, T2M, T2N, 32, AREG), G3 = pick_groups(2 * CB, T2M, T2N, 32, AREG);
-    constexpr int G4 = pick_groups(2 * CB, T4M, T4N, 32, AREG), G5 = pick_groups(4 * CB, T4M, T4N, 32, AREG);
-    constexpr int GL = TrunkLds<CB>::TOTAL;
-    __shared__ __attribute__((aligned(16))) float lds[2 * GL + 8];
-    // g / wave are wave-uniform: keep them (and everything derived: LDS bases, row numbers) in SGPRs
-    const int g = __builtin_amdgcn_readfirstlane(threadIdx.x >> 9), wave0 = __builtin_amdgcn_readfirstlane((threadIdx.x >> 6) & 7);
-    const int tid0 = threadIdx.x & 511;
-    float* act = lds + g * GL;
-    float* patch = act + TrunkLds<CB>::ACT;
-    float* red = patch + TrunkLds<CB>::PATCH;
-    int* counters = reinterpret_cast<int*>(lds + 2 * GL);
-    if (threadIdx.x < 2) counters[threadIdx.x] = 0;
-    duo_tick();
-    GroupBar gb{counters + g, 0};
-    __builtin_amdgcn_s_setprio(3);        // E slots (latency bound, short) outrank the partner group's MFMA loop (priority 0)
-    int n_tick = 0;
-    // tuning aid: wave 0 of each group stamps s_memtime before / after every tick (first 256 ticks of each workgroup)
-#define DUO_TICK()                                                                                                       \
-    do {                                                                                                                 \
-        if (a.dbg_time && wave0 == 0 && (threadIdx.x & 63) == 0 && n_tick < 256)                                         \
-            a.dbg_time[((size_t)(blockIdx.x * 2 + g) * 256 + n_tick) * 2] = __builtin_readcyclecounter();               \
-        duo_tick();                                                                                                      \
-        if (a.dbg_time && wave0 == 0 && (threadIdx.x & 63) == 0 && n_tick < 256)                                         \
-            a.dbg_time[((size_t)(blockIdx.x * 2 + g) * 256 + n_tick) * 2 + 1] = __builtin_readcyclecounter();           \
-        ++n_tick;                                                                                                        \
-    } while (0)
-    int n_iter = 0;
-#define DUO_SUB(k)                                                                                                       \
-    do {                                                                                                                 \
-        if (a.dbg_time && wave0 == 0 && (threadIdx.x & 63) == 0 && n_iter < 64)                                          \
-            a.dbg_time[262144 + ((size_t)(blockIdx.x * 2 + g) * 64 + n_iter) * 8 + (k)] = __builtin_readcyclecounter();  \
-    } while (0)
-    // Inside the persistent loop the lane / wave ids pass through an opaque asm once per patch: otherwise LLVM hoists every
-    // per-lane address of all six layers out of the patch loop (they are loop invariant) and spills ~150 VGPRs.
-#define DUO_IDS()                                             \
-    int tid = tid0, wave = wave0;                             \
-    asm volatile("" : "+v"(tid));                             \
-    asm volatile("" : "+s"(wave));                            \
-    const int lane = tid & 63
-    if (g == 1 && antiphase) DUO_TICK();                                     // anti-phase: group 1 runs one slot behind
-    bool have_prev = false;
-    size_t prev_row = 0;
-    f32x4 acc5[T4M][T4N];
-    f32x4 bias5[T4N];
-    const int npairs = (total_rows + 1) >> 1;
-
-    // conv5 epilogue of the previous patch of this group (first part of an E* slot): bias + ReLU, [pixel][channel] to HBM for
-    // cnn16_head_kernel - no synchronisation needed
-    auto finish_prev = [&](int tid, int lane, int wave) __attribute__((always_inline)) {
-        store_tiles_global<4 * CB, T4M, T4N>(a.out + prev_row * (64 * 4 * CB), bias5, acc5, wave, lane);
-    };
-
-    for (int pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
-        const int row = 2 * pair + g;
-        const int img = row / a.n_max, ri = row - img * a.n_max;
-        const bool valid = row < total_rows && ri < (a.count ? min(a.count[img], a.n_max) : a.n_max);
-        const size_t pidx = (size_t)row;
-        DUO_IDS();
-        if (!valid) {                             // ragged tail / rows past the image's count: keep the tick cadence only
-            if (have_prev) finish_prev(tid, lane, wave);
-            have_prev = false;
-#pragma unroll 1
-            for (int t = 0; t < 10; ++t) DUO_TICK();
-            continue;
-        }
-        // ================= E*: finish the previous patch, start this one =================================================
-        float w0[3][T1N];
-        f32x4 bias0[T1N], b1[1][T1N], bias1[T1N];
-        float v[PPT];
-        {                                         // requests first: their latency hides behind the previous patch's head
-            conv0_load_w<NW, CB, T1M, T1N>(a.packed + a.off.w[0], a.packed + a.off.b[0], w0, bias0, wave, lane);
-            prefetch_b0<NW, CB, 32, T1M, T1N, 1>(a.packed + a.off.w[1], b1, wave, lane);
-            prefetch_bias<NW, 32, T1M, T1N>(a.packed + a.off.b[1], bias1, wave, lane);
-            if (a.patches) {
-                const float* src = a.patches + pidx * 1024;
-#pragma unroll
-                for (int q = 0; q < PPT; ++q) v[q] = src[tid + q * NTHR];
-            } else {
-                int o = a.ids[3 * pidx], l = a.ids[3 * pidx + 1];
-                o = o < 0 ? 0 : (o >= ps.n_octaves ? ps.n_octaves - 1 : o);
-                l = l < 0 ? 0 : (l >= ps.n_levels ? ps.n_levels - 1 : l);
-                const float* im = ps.lvl[o][l] + (size_t)img * ps.img_stride;
-                const int h = ps.h[o], w = ps.w[o];
-                const float* L = a.lafs + 6 * pidx;
-                const float m = (float)(h < w ? h : w);
-                const float t00 = L[0] * m, t01 = L[1] * m, t02 = L[2] * (float)w;
-                const float t10 = L[3] * m, t11 = L[4] * m, t12 = L[5] * (float)h;
-#pragma unroll
-                for (int q = 0; q < PPT; ++q)
-                    v[q] = aff_sample_bilinear(im, h, w, t00, t01, t02, t10, t11, t12, ps.base[tid & 31], ps.base[(tid >> 5) + q * RPT]);
-            }
-        }
-        DUO_SUB(0);
-        if (have_prev) finish_prev(tid, lane, wave);
-        DUO_SUB(4);
-        {
-            if (tid < 4 * 33) {
-                const int e = tid;
-                const int y = e < 34 ? 0 : (e < 68 ? 33 : 1 + ((e - 68) >> 1)), x = e < 34 ? e : (e < 68 ? e - 34 : ((e - 68) & 1) * 33);
-                patch[y * WP32 + x] = 0.0f;
-            }
-            zero_halo<LayC0, NTHR>(act, CB, tid);
-            float sum = 0.f;
-#pragma unroll
-            for (int q = 0; q < PPT; ++q) sum += v[q];
-            sum = wave_sum(sum);
-            if (lane == 0) red[wave] = sum;
-            gb.sync(lane);
-                float mean = 0.f;
-#pragma unroll
-            for (int wv = 0; wv < NW; ++wv) mean += red[wv];
-            mean *= (1.0f / 1024.0f);
-            float sq = 0.f;
-#pragma unroll
-            for (int q = 0; q < PPT; ++q) { v[q] -= mean; sq += v[q] * v[q]; }
-            sq = wave_sum(sq);
-            if (lane == 0) red[NW + wave] = sq;
-            gb.sync(lane);
-                float var = 0.f;
-#pragma unroll
-            for (int wv = 0; wv < NW; ++wv) var += red[NW + wv];
-            var *= (1.0f / 1023.0f);
-            const float sd = sqrtf(var) + 1e-7f;
-#pragma unroll
-            for (int q = 0; q < PPT; ++q) patch[((tid >> 5) + q * RPT + 1) * WP32 + (tid & 31) + 1] = v[q] / sd;
-            gb.sync(lane);
-                f32x4 acc[T1M][T1N];
-            conv0_mfma<NW, CB, T1M, T1N>(patch, w0, bias0, acc, wave, lane);
-                store_tiles_lds<CB, LayC0, T1M, T1N, false>(act, bias0, acc, wave, lane);
-            }
-        ++n_iter;
-        DUO_TICK();
-        // ================= M1 | E1 ========================================================================================
-        f32x4 b2[G2][T2N], bias2[T2N];
-        {
-            f32x4 acc[T1M][T1N];
-            __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma<NW, CB, CB, LayC0, 1, T1M, T1N, 1>(act, a.packed + a.off.w[1], b1, acc, wave, lane);
-            __builtin_amdgcn_s_setprio(3);
-            DUO_TICK();
-            {
-                prefetch_b0<NW, 2 * CB, 16, T2M, T2N, G2>(a.packed + a.off.w[2], b2, wave, lane);
-                prefetch_bias<NW, 16, T2M, T2N>(a.packed + a.off.b[2], bias2, wave, lane);
-                zero_halo<LayC1, NTHR>(act, CB, tid);
-                store_tiles_lds<CB, LayC1, T1M, T1N>(act, bias1, acc, wave, lane);
-            }
-            DUO_TICK();
-        }
-        // ================= M2 | E2 ========================================================================================
-        f32x4 b3[G3][T2N], bias3[T2N];
-        {
-            f32x4 acc[T2M][T2N];
-            __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma<NW, CB, 2 * CB, LayC1, 2, T2M, T2N, G2>(act, a.packed + a.off.w[2], b2, acc, wave, lane);
-            __builtin_amdgcn_s_setprio(3);
-            DUO_TICK();
-            {
-                prefetch_b0<NW, 2 * CB, 16, T2M, T2N, G3>(a.packed + a.off.w[3], b3, wave, lane);
-                prefetch_bias<NW, 16, T2M, T2N>(a.packed + a.off.b[3], bias3, wave, lane);
-                zero_halo<LayC2, NTHR>(act, 2 * CB, tid);
-                store_tiles_lds<2 * CB, LayC2, T2M, T2N>(act, bias2, acc, wave, lane);
-            }
-            DUO_TICK();
-        }
-        // ================= M3 | E3 ========================================================================================
-        f32x4 b4[G4][T4N], bias4[T4N];
-        {
-            f32x4 acc[T2M][T2N];
-            __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma<NW, 2 * CB, 2 * CB, LayC2, 1, T2M, T2N, G3>(act, a.packed + a.off.w[3], b3, acc, wave, lane);
-            __builtin_amdgcn_s_setprio(3);
-            DUO_TICK();
-            {
-                prefetch_b0<NW, 4 * CB, 8, T4M, T4N, G4>(a.packed + a.off.w[4], b4, wave, lane);
-                prefetch_bias<NW, 8, T4M, T4N>(a.packed + a.off.b[4], bias4, wave, lane);
-                zero_halo<LayC3, NTHR>(act, 2 * CB, tid);
-                store_tiles_lds<2 * CB, LayC3, T2M, T2N>(act, bias3, acc, wave, lane);
-            }
-            DUO_TICK();
-        }
-        // ================= M4 | E4 ========================================================================================
-        f32x4 b5[G5][T4N];
-        {
-            f32x4 acc[T4M][T4N];
-            __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma<NW, 2 * CB, 4 * CB, LayC3, 2, T4M, T4N, G4>(act, a.packed + a.off.w[4], b4, acc, wave, lane);
-            __builtin_amdgcn_s_setprio(3);
-            DUO_TICK();
-            {
-                prefetch_b0<NW, 4 * CB, 8, T4M, T4N, G5>(a.packed + a.off.w[5], b5, wave, lane);
-                prefetch_bias<NW, 8, T4M, T4N>(a.packed + a.off.b[5], bias5, wave, lane);
-                zero_halo<LayC4, NTHR>(act, 4 * CB, tid);
-                store_tiles_lds<4 * CB, LayC4, T4M, T4N>(act, bias4, acc, wave, lane);
-            }
-            DUO_TICK();
-        }
-        // ================= M5 (its epilogue + head open the next E* slot) ====================================================
-        __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma<NW, 4 * CB, 4 * CB, LayC4, 1, T4M, T4N, G5>(act, a.packed + a.off.w[5], b5, acc5, wave, lane);
-            __builtin_amdgcn_s_setprio(3);
-        DUO_TICK();
-        have_prev = true;
-        prev_row = pidx;
-    }
-    if (have_prev) {
-        DUO_IDS();
-        finish_prev(tid, lane, wave);
-    }
-#undef DUO_IDS
-    if (g == 0 && antiphase) DUO_TICK();                                     // group 1 executed one tick more at the start
 }
 
 // ---- HardNet head: (n x 8192) x (8192 x 128) GEMM + BN bias + L2 normalisation ----------------------
@@ -1241,39 +1010,24 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
     const NetLayout L = net_layout(kind);
     CnnArgs a;
     a.packed = packed; a.off = to_offsets(L); a.patches = patches; a.lafs = lafs; a.ids = ids; a.count = count; a.n_max = n_max;
-    a.out = (dbg_layer < 0) ? scratch : out;              // the trunk kernels write the conv5 tensor; heads run separately
+    a.out = (dbg_layer < 0) ? scratch : out;              // trunk kernels: HardNet conv5 tensor / AffNet, OriNet head partials
     a.dbg_layer = dbg_layer; a.dbg_out = dbg_out; a.dbg_time = g_dbg_time;
     PyrSrc ps;
     aff_fill_pyr_src(ctx, &ps);
     const int B = patches ? 1 : ctx->B;                  // patch tensors are single-"image"; pyramid sampling covers the batch
     const dim3 grid(n_max, B);
-    static const int hard_waves = []() { const char* e = getenv("AFFNET_HARDNET_WAVES"); return (e && atoi(e) == 16) ? 16 : 8; }();
-    // AFFNET_CNN_DUO=1: AffNet / OriNet as two patches per persistent 16-wave workgroup in anti-phase (cnn16_duo_kernel).
-    // Measured (tools/duo_timing.py): correct, but 8% slower than one patch per workgroup - with only two wavefronts per
-    // SIMD inside a loop the small-tile AffNet loops reach 85-90% of the pipe rate instead of 94%, and the E* slot (20-29k
-    // cycles) is longer than the partner's M1 / M5 slot (18-20k).  Kept as an experiment, off by default.
-    static const int duo = []() { const char* e = getenv("AFFNET_CNN_DUO"); return e ? atoi(e) : 0; }();      // 1 = anti-phase, 2 = lockstep
-    static const int n_cu = []() { hipDeviceProp_t p; int d = 0; (void)hipGetDevice(&d); return hipGetDeviceProperties(&p, d) == hipSuccess ? p.multiProcessorCount : 256; }();
-    static const int duo_dbg = []() { const char* e = getenv("AFFNET_CNN_DUO_STAMPS"); return (e && atoi(e)) ? 1 : 0; }();
-    const bool use_duo = duo && kind != AFFNET_NET_HARDNET && dbg_layer < 0 && (!g_dbg_time || duo_dbg);
-    if (use_duo) {
-        const int total_rows = n_max * B, npairs = (total_rows + 1) / 2;
-        const dim3 dgrid(npairs < n_cu ? npairs : n_cu);
-        if (kind == AFFNET_NET_AFFNET) hipLaunchKernelGGL((cnn16_duo_kernel<AFFNET_NET_AFFNET>), dgrid, dim3(1024), 0, st, a, ps, total_rows, duo == 1 ? 1 : 0);
-        else hipLaunchKernelGGL((cnn16_duo_kernel<AFFNET_NET_ORINET>), dgrid, dim3(1024), 0, st, a, ps, total_rows, duo == 1 ? 1 : 0);
-    } else if (kind == AFFNET_NET_AFFNET) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_AFFNET, 8>), grid, dim3(512), 0, st, a, ps);
+    // (Tried and removed: two AffNet patches per persistent 16-wave workgroup in anti-phase - correct but 8 % slower, the
+    // small-tile loops reach 85-90 % of the pipe rate with two waves per SIMD; 16-wave HardNet workgroups - slower too.)
+    if (kind == AFFNET_NET_AFFNET) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_AFFNET, 8>), grid, dim3(512), 0, st, a, ps);
     else if (kind == AFFNET_NET_ORINET) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_ORINET, 8>), grid, dim3(512), 0, st, a, ps);
-    else if (hard_waves == 8) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_HARDNET, 8>), grid, dim3(512), 0, st, a, ps);
-    else hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_HARDNET, 16>), grid, dim3(1024), 0, st, a, ps);
+    else hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_HARDNET, 8>), grid, dim3(512), 0, st, a, ps);
     AFF_LAUNCH_CHECK(ctx);
-    if (kind != AFFNET_NET_HARDNET && dbg_layer < 0) {       // heads over the conv5 tensors in `scratch`
-        const dim3 hgrid(n_max, B);
+    if (kind != AFFNET_NET_HARDNET && dbg_layer < 0) {       // combine the per-wave head partials in `scratch`
+        const dim3 hgrid(aff_cdiv(n_max, 256), B);
         if (kind == AFFNET_NET_AFFNET)
-            hipLaunchKernelGGL((cnn16_head_kernel<AFFNET_NET_AFFNET>), hgrid, dim3(256), 0, st, scratch, packed + L.head_w, packed + L.head_b, count,
-                               n_max, out);
+            hipLaunchKernelGGL((cnn16_finish_kernel<AFFNET_NET_AFFNET>), hgrid, dim3(256), 0, st, scratch, packed + L.head_b, count, n_max, out);
         else
-            hipLaunchKernelGGL((cnn16_head_kernel<AFFNET_NET_ORINET>), hgrid, dim3(256), 0, st, scratch, packed + L.head_w, packed + L.head_b, count,
-                               n_max, out);
+            hipLaunchKernelGGL((cnn16_finish_kernel<AFFNET_NET_ORINET>), hgrid, dim3(256), 0, st, scratch, packed + L.head_b, count, n_max, out);
         AFF_LAUNCH_CHECK(ctx);
     }
     if (mark_head) aff_prof_mark(ctx, 7, st);

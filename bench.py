@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="images per step per rank")
-    ap.add_argument("--chunk", type=int, default=int(os.environ.get("AFFNET_BENCH_CHUNK", "16")),
+    ap.add_argument("--chunk", type=int, default=int(os.environ.get("AFFNET_BENCH_CHUNK", "32")),
                     help="images per fused library call (every kernel launch covers `chunk` images)")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("AFFNET_BENCH_STREAMS", "1")),
                     help="independent streams (each with its own context) the chunks alternate over")
@@ -101,7 +101,7 @@ def main():
         H, W, NKP = 2160, 3840, 8000
         if args.batch == BATCH:
             args.batch = 8
-        if args.chunk == 16:
+        if args.chunk == 32:
             args.chunk = 4
 
     rank = int(os.environ.get("RANK", "0"))

@@ -16,7 +16,7 @@ A = affnet_amd.AffNetFast(); A.load_state_dict(torch.load(os.path.join(ROOT, "pr
 H = affnet_amd.HardNet(); H.load_state_dict(affnet_amd.synthetic_hardnet_state(0)); H.to(dev)
 names = ["input+norm", "conv0", "conv1 mfma", "conv1 store", "conv2 mfma", "conv2 store", "conv3 mfma", "conv3 store",
          "conv4 mfma", "conv4 store", "conv5 mfma", "conv5 store"]
-for net, nm, nw in [(A, "AffNet", 8), (H, "HardNet", int(os.environ.get("AFFNET_HARDNET_WAVES", "8")))]:
+for net, nm, nw in [(A, "AffNet", 8), (H, "HardNet", 8)]:
     net(p); torch.cuda.synchronize()
     st = torch.zeros(n * nw * 32, dtype=torch.int64, device=dev)
     lib.affnet_cnn32_debug_timing(ptr(st))

@@ -2,7 +2,7 @@
 # CNN kernel iteration: CNN parity tests + phase timing + bench.  Outputs under gpurun_out/.
 mkdir -p gpurun_out; export HSA_ENABLE_IPC_MODE_LEGACY=0 TMPDIR=/tmp
 timeout 600 python -m pytest tests -q -m gpu -p no:cacheprovider -x -k "${PYTEST_K:-cnn or mfma or full_path_synthetic or batched}" > gpurun_out/pytest_cnn.log 2>&1; echo "pytest exit: $?"; tail -n 4 gpurun_out/pytest_cnn.log
-AFFNET_HARDNET_WAVES=8 python tools/cnn_phase_timing.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/cnn_phase_timing.txt
+python tools/cnn_phase_timing.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/cnn_phase_timing.txt
 run() { # name, args
   timeout 300 python bench.py --steps 4 --warmup 2 --no-cpu-baseline $2 > gpurun_out/bench_$1.log 2>&1
   python - <<PY

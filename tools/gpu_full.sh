@@ -4,7 +4,7 @@ mkdir -p gpurun_out; export HSA_ENABLE_IPC_MODE_LEGACY=0 TMPDIR=/tmp
 timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest exit: $?"; tail -n 6 gpurun_out/pytest_gpu.log
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke exit: $?"; tail -n 1 gpurun_out/smoke.log
 timeout 600 python bench.py > gpurun_out/bench_default.log 2>&1; echo "bench exit: $?"; grep '^{' gpurun_out/bench_default.log | cut -c1-1500
-CMD="python bench.py --steps 1 --warmup 1 --batch 32 --chunk 16 --no-cpu-baseline"
+CMD="python bench.py --steps 1 --warmup 1 --batch 64 --chunk 32 --no-cpu-baseline"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o run -- $CMD > gpurun_out/prof.log 2>&1; echo "prof exit: $?"
 f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -n 12 "$f" | cut -c1-200
 i=1
