@@ -1005,7 +1005,7 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
     if (!packed || !out || n_max < 0 || (!patches && (!lafs || !ids))) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: null argument");
     if (!patches && !ctx->ws) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: sampling from the pyramid needs a bound workspace");
     if (dbg_layer < 0 && !scratch)
-        return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: d_scratch is required (HardNet n*(8192+512) floats, AffNet / OriNet n*4096 floats)");
+        return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: d_scratch is required (HardNet n*(8192+512) floats, AffNet / OriNet n*144 floats)");
     if (n_max == 0) return AFFNET_OK;
     const NetLayout L = net_layout(kind);
     CnnArgs a;

@@ -105,8 +105,8 @@ extern "C" int affnet_ctx_create(affnet_ctx** out, int device, const affnet_conf
     off += aff_align(F * 6 * sizeof(float));           // shaped lafs (normalised)
     off += aff_align(F * 4 * sizeof(float));           // R
     off += aff_align(F * 9 * sizeof(float));           // lafs_norm(6) + lvl ids(3)
-    {   // HardNet trunk output + split-K head partials; also holds the AffNet (P rows) / OriNet conv5 tensors (4096 floats each)
-        const size_t hard = F * (8192 + 4 * 128), aff = P * 4096;
+    {   // HardNet trunk output + split-K head partials; also holds the AffNet (P rows) / OriNet head partials (144 floats each)
+        const size_t hard = F * (8192 + 4 * 128), aff = P * 144;
         off += aff_align((hard > aff ? hard : aff) * sizeof(float));
     }
     ctx->ws_bytes = off;

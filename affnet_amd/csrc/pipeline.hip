@@ -103,7 +103,7 @@ extern "C" int affnet_describe_detected(affnet_ctx* ctx, const affnet_nets* nets
             return aff_handcrafted_launch(ctx, AFFNET_HC_BAUMBERG, nullptr, lafs, ctx->st_det_ids, det_count, P, nets->h_baumberg_window, A_out,
                                           nullptr, st);
         return affnet_cnn32_forward_pyr(ctx, AFFNET_NET_AFFNET, nets->d_affnet, lafs, ctx->st_det_ids, det_count, P, A_out, ctx->st_hard_scratch,
-                                        stream);   // conv5 tensors (P x 4096 floats) share the HardNet scratch
+                                        stream);   // head partials (P x 144 floats) share the HardNet scratch
     };
     if (nets->d_affnet || baumberg) {
         rc = shape_pass(ctx->st_det_lafs, ctx->st_A);

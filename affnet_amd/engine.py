@@ -120,7 +120,7 @@ def cnn_forward(kind, packed, patches, scratch=None):
     if n == 0:
         return out
     if scratch is None:       # conv5 tensors (+ split-K partials for HardNet) for the head kernels
-        scratch = torch.empty(n * ((8192 + 512) if kind == _lib.NET_HARDNET else 4096), dtype=torch.float32, device=dev)
+        scratch = torch.empty(n * ((8192 + 512) if kind == _lib.NET_HARDNET else 144), dtype=torch.float32, device=dev)
     ctx = utility_ctx(dev)
     rc = lib.affnet_cnn32_forward(ctx, kind, ptr(packed), ptr(patches), None, n, ptr(out), ptr(scratch), stream_of(dev))
     check(rc, ctx, "affnet_cnn32_forward")

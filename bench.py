@@ -94,7 +94,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--config5", action="store_true",
                     help="BASELINE.json configs[4] instead of the headline configs[2]: 3840x2160 images, 8000 kp each (deep pyramid stress); "
-                         "batch / chunk default to 8 / 4")
+                         "batch / chunk default to 8 / 8")
     args = ap.parse_args()
     global H, W, NKP
     if args.config5:
@@ -102,7 +102,7 @@ def main():
         if args.batch == BATCH:
             args.batch = 8
         if args.chunk == 32:
-            args.chunk = 4
+            args.chunk = 8
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -182,8 +182,8 @@ int affnet_cnn32_pack_weights(int net_kind, const float* const* conv_w, const fl
  *   AffNet : d_out (n,2,2) rectified affine shape      (architectures.py:246-252, LAF.py:285-291)
  *   OriNet : d_out (n,2,2) rotation matrix             (architectures.py:76-82,  LAF.py:276-283)
  *   HardNet: d_out (n,128) L2-normalised descriptor    (HardNet.py:98-101)
- * Only rows < *d_count are computed when d_count != NULL.  d_scratch (conv5 tensors for the head kernels): HardNet
- * n*(8192+512) floats (trunk output + split-K partials of the head GEMM), AffNet / OriNet n*4096 floats. */
+ * Only rows < *d_count are computed when d_count != NULL.  d_scratch: HardNet n*(8192+512) floats (conv5 tensor = A
+ * operand of the head GEMM + its split-K partials), AffNet / OriNet n*144 floats (per-wave partial sums of the head). */
 int affnet_cnn32_forward(affnet_ctx* ctx, int net_kind, const float* d_packed, const float* d_patches,
                          const int32_t* d_count, int n_max, float* d_out, float* d_scratch, void* stream);
 
