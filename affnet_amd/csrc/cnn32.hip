@@ -59,6 +59,17 @@ __device__ __forceinline__ unsigned lds_byte_addr(const float* p) {
 }
 __device__ __forceinline__ f32x4 lds_read4(unsigned byte_addr) { return *(LdsF4*)(size_t)byte_addr; }
 
+// Weight fragments of the MFMA loops come through a buffer descriptor: the lane offset is one loop-invariant 32-bit
+// VGPR, the chunk offset an SGPR, the tile offset an immediate - no 64-bit VALU pointer arithmetic between the MFMAs and
+// half the address payload of a flat global_load_dwordx4 per instruction.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const float* base, int n_floats) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, n_floats * 4, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_read4(__amdgpu_buffer_rsrc_t r, int lane_byte_off, int uniform_byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_byte_off, uniform_byte_off, 0));
+}
+
 template <int H_, int WP_, int PSG_>
 struct Lay {
     static constexpr int H = H_, WP = WP_, PSG = PSG_;
@@ -271,9 +282,6 @@ __device__ __forceinline__ void conv3x3_mfma(const float* act, const float* __re
     auto a_imm = [](int i) {                               // byte offset of tile i from tile 0 (compile-time after unrolling)
         return 4 * ((PROBE & 8) ? i * 256 : (HOUT == 8 ? i * 2 * STRIDE * LI::WP * 4 : (((i * 16) / HOUT) * STRIDE * LI::WP + ((i * 16) % HOUT) * STRIDE) * 4));
     };
-    int b_base[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) b_base[j] = b_lane + j * 64;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -286,7 +294,8 @@ __device__ __forceinline__ void conv3x3_mfma(const float* act, const float* __re
         const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;          // tap / 3, tap % 3 for tap < 9
         return g0 * 4 * LI::PSG + (ky * LI::WP + kx) * 4;
     };
-    auto load_group = [&](Frag<GRP, TM, TN>& f, int u, int a_off, const float* w) {
+    const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(Wg, 9 * CIN * COUT);
+    auto load_group = [&](Frag<GRP, TM, TN>& f, int u, int a_off, int w_off) {
         if (!(PROBE & 2)) {
             unsigned ab = a_addr0 + (a_off + u * 4 * LI::PSG) * 4;
             asm("" : "+v"(ab));
@@ -295,7 +304,7 @@ __device__ __forceinline__ void conv3x3_mfma(const float* act, const float* __re
         }
         if (!(PROBE & 1)) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) f.b[u][j] = *reinterpret_cast<const f32x4*>(&w[u * 16 * COUT + b_base[j]]);
+            for (int j = 0; j < TN; ++j) f.b[u][j] = buf_read4(wrsrc, b_lane * 4 + j * 256, (w_off + u * 16 * COUT) * 4);
         }
     };
     auto mfma_group = [&](const Frag<GRP, TM, TN>& f, int u) {
@@ -310,10 +319,10 @@ __device__ __forceinline__ void conv3x3_mfma(const float* act, const float* __re
     // compute the chunk held in `cur` while loading chunk `nxt_ch` into `nxt`
     auto stage = [&](const Frag<GRP, TM, TN>& cur, Frag<GRP, TM, TN>& nxt, int nxt_ch) {
         const int a_off = a_chunk_off(nxt_ch);
-        const float* w = Wg + (size_t)nxt_ch * (GRP * 16 * COUT);
+        const int w_off = nxt_ch * (GRP * 16 * COUT);
 #pragma unroll
         for (int u = 0; u < GRP; ++u) {
-            load_group(nxt, u, a_off, w);
+            load_group(nxt, u, a_off, w_off);
             mfma_group(cur, u);
             // Schedule: the TM ds_read_b128 and TN global_load_dwordx4 of this group are spread BETWEEN its MFMAs (one load
             // after every Q MFMAs) instead of being issued as a burst in front of them.  A wave cannot issue an MFMA while it
@@ -390,9 +399,7 @@ __device__ __forceinline__ void conv3x3_mfma_roll(const float* act, const float*
     auto a_imm = [](int i) {                               // byte offset of tile i from tile 0 (compile-time after unrolling)
         return 4 * (HOUT == 8 ? i * 2 * STRIDE * LI::WP * 4 : (((i * 16) / HOUT) * STRIDE * LI::WP + ((i * 16) % HOUT) * STRIDE) * 4);
     };
-    int b_base[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) b_base[j] = b_lane + j * 64;
+    const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(Wg, 9 * CIN * COUT);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -413,9 +420,8 @@ __device__ __forceinline__ void conv3x3_mfma_roll(const float* act, const float*
     auto chunk = [&](const f32x4 (&bc)[TN], f32x4 (&bn)[TN], int nxt_ch) {
         unsigned ab = a_addr0 + a_chunk_off(nxt_ch) * 4;
         asm("" : "+v"(ab));
-        const float* w = Wg + (size_t)nxt_ch * (16 * COUT);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bn[j] = *reinterpret_cast<const f32x4*>(&w[b_base[j]]);
+        for (int j = 0; j < TN; ++j) bn[j] = buf_read4(wrsrc, b_lane * 4 + j * 256, nxt_ch * (16 * COUT) * 4);
 #pragma unroll
         for (int ip = 0; ip < TM; ip += 2) {
             __builtin_amdgcn_sched_barrier(0);
@@ -656,7 +662,10 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
     constexpr int RPT = 32 / PPT;                       // patch rows covered by one pass of the workgroup
     // per-wave register blocking (TM x TN tiles of 16 px x 16 ch); MG * NG == NW for every layer
     constexpr int T1M = (CB == 16) ? 8 : 64 / NW, T1N = CB / 16;
-    constexpr int T2M = (CB == 16) ? 2 : 32 / NW, T2N = 2;
+    // conv2 / conv3: ONE channel tile per wave and as many pixel tiles as that allows - activation fragments come from LDS
+    // (nearly free), weight fragments are 1 KB global loads whose cost shows in the MFMA rate: 4 x 1 instead of 2 x 2 took the
+    // isolated AffNet conv3 loop from 121 to 146 TFLOP/s (tools/clock_probe.py 13 / 14)
+    constexpr int T2M = (CB == 16) ? 4 : 64 / NW, T2N = 1;
     constexpr int T4M = (CB == 16) ? 2 : 32 / NW, T4N = 1;
     // plane groups (4 k-steps each) per pipeline chunk; VGPR budget 128 at 4 waves / SIMD, 256 at 2
     constexpr int AREG = (NW == 8 && CB == 32) ? 128 : 48;
@@ -1099,11 +1108,52 @@ __global__ __launch_bounds__(512, 2) void cnn32_probe_kernel(const float* __rest
     if (threadIdx.x == 0 && blockIdx.x == 0) out[1] = sink;
 }
 
-// layer: 1 (conv1, TM 8 x TN 2) or 5 (conv5, TM 4 x TN 1, 2 groups / chunk); probe: PROBE bits; d_out: 2 floats.
+// Same for the 16-channel trunks (AffNet / OriNet shapes, 79 KB of LDS -> two workgroups per CU, 128 VGPRs).
+template <int LAYER, int PROBE>
+__global__ __launch_bounds__(512, 4) void cnn16_probe_kernel(const float* __restrict__ packed, NetOffsets off, int reps, float* __restrict__ out) {
+    constexpr int CB = 16, NW = 8;
+    __shared__ __attribute__((aligned(16))) float lds[TrunkLds<CB>::TOTAL];
+    for (int i = threadIdx.x; i < TrunkLds<CB>::TOTAL; i += 512) lds[i] = 0.001f * (float)(i & 255);
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float sink = 0.f;
+    for (int r = 0; r < reps; ++r) {
+        if (LAYER == 3) {
+            f32x4 acc[2][2], b0[2][2];
+            prefetch_b0<NW, 2 * CB, 16, 2, 2, 2>(packed + off.w[3], b0, wave, lane);
+            conv3x3_mfma<NW, 2 * CB, 2 * CB, LayC2, 1, 2, 2, 2, PROBE>(lds, packed + off.w[3], b0, acc, wave, lane);
+            sink += acc[0][0][0] + acc[1][1][3] + acc[0][1][1] + acc[1][0][2];
+        } else if (LAYER == 4) {    // conv3 again, 4 pixel tiles x 1 channel tile per wave: half the weight loads per MFMA
+            f32x4 acc[4][1], b0[1][1];
+            prefetch_b0<NW, 2 * CB, 16, 4, 1, 1>(packed + off.w[3], b0, wave, lane);
+            conv3x3_mfma<NW, 2 * CB, 2 * CB, LayC2, 1, 4, 1, 1, PROBE>(lds, packed + off.w[3], b0, acc, wave, lane);
+            sink += acc[0][0][0] + acc[1][0][3] + acc[2][0][1] + acc[3][0][2];
+        } else {
+            f32x4 acc[2][1], b0[2][1];
+            prefetch_b0<NW, 4 * CB, 8, 2, 1, 2>(packed + off.w[5], b0, wave, lane);
+            conv3x3_mfma<NW, 4 * CB, 4 * CB, LayC4, 1, 2, 1, 2, PROBE>(lds, packed + off.w[5], b0, acc, wave, lane);
+            sink += acc[0][0][0] + acc[1][0][3];
+        }
+    }
+    if (sink == 12345.678f) out[0] = sink;
+    if (threadIdx.x == 0 && blockIdx.x == 0) out[1] = sink;
+}
+
+// layer: 1 (HardNet conv1, TM 8 x TN 2), 5 (HardNet conv5, TM 4 x TN 1, 2 groups / chunk) with HardNet's packed weights;
+// 13 / 15 (AffNet conv3, TM 2 x TN 2 / conv5, TM 2 x TN 1) with AffNet's.  probe: PROBE bits; d_out: 2 floats.
 extern "C" int affnet_cnn32_probe(const float* d_packed_hardnet, int layer, int probe, int reps, int n_blocks, float* d_out, void* stream) {
-    if (!d_packed_hardnet || !d_out || (layer != 1 && layer != 5) || probe < 0 || probe > 15) return AFFNET_ERR_INVALID;
-    const NetOffsets off = to_offsets(net_layout(AFFNET_NET_HARDNET));
+    if (!d_packed_hardnet || !d_out || probe < 0 || probe > 15) return AFFNET_ERR_INVALID;
     hipStream_t st = (hipStream_t)stream;
+    if (layer == 13 || layer == 14 || layer == 15) {
+        if (probe > 3) return AFFNET_ERR_INVALID;
+        const NetOffsets off16 = to_offsets(net_layout(AFFNET_NET_AFFNET));
+#define PROBE16(L, P) if (layer == 10 + L && probe == P) hipLaunchKernelGGL((cnn16_probe_kernel<L, P>), dim3(n_blocks), dim3(512), 0, st, d_packed_hardnet, off16, reps, d_out)
+        PROBE16(3, 0); PROBE16(3, 1); PROBE16(3, 2); PROBE16(3, 3); PROBE16(4, 0); PROBE16(4, 1); PROBE16(4, 2); PROBE16(4, 3); PROBE16(5, 0); PROBE16(5, 1); PROBE16(5, 2); PROBE16(5, 3);
+#undef PROBE16
+        return hipGetLastError() == hipSuccess ? AFFNET_OK : AFFNET_ERR_HIP;
+    }
+    if (layer != 1 && layer != 5) return AFFNET_ERR_INVALID;
+    const NetOffsets off = to_offsets(net_layout(AFFNET_NET_HARDNET));
 #define PROBE_CASE(L, P) if (layer == L && probe == P) hipLaunchKernelGGL((cnn32_probe_kernel<L, P>), dim3(n_blocks), dim3(512), 0, st, d_packed_hardnet, off, reps, d_out)
     PROBE_CASE(1, 0); PROBE_CASE(1, 1); PROBE_CASE(1, 2); PROBE_CASE(1, 3); PROBE_CASE(1, 4); PROBE_CASE(1, 8); PROBE_CASE(1, 9);
     PROBE_CASE(5, 0); PROBE_CASE(5, 1); PROBE_CASE(5, 2); PROBE_CASE(5, 3); PROBE_CASE(5, 4); PROBE_CASE(5, 8); PROBE_CASE(5, 9);
