@@ -142,9 +142,13 @@ extern "C" int affnet_cnn32_pack_weights(int kind, const float* const* conv_w, c
         for (int n = 0; n < 128; ++n) {
             const float s = 1.0f / sqrtf(head_bn_var[n] + 1e-5f);
             out[L.head_b + n] = -head_bn_mean[n] * s;
-            // K order of the head GEMM = the trunk kernel's output order [pixel p][channel c] (float4 = 4 channels)
+            // K order of the head GEMM = the trunk kernel's output order k = pixel * 128 + channel; stored interleaved by 4 like
+            // the conv weights, [k/16][(k/4)%4][n][k%4], so that one 16-byte load per lane is the B fragment of 4 MFMA k-steps
             for (int c = 0; c < 128; ++c)
-                for (int pp = 0; pp < 64; ++pp) out[L.head_w + ((size_t)pp * 128 + c) * 128 + n] = head_w[(size_t)n * HEAD_K + c * 64 + pp] * s;
+                for (int pp = 0; pp < 64; ++pp) {
+                    const size_t k = (size_t)pp * 128 + c;
+                    out[L.head_w + (((k >> 4) * 4 + ((k >> 2) & 3)) * 128 + n) * 4 + (k & 3)] = head_w[(size_t)n * HEAD_K + c * 64 + pp] * s;
+                }
         }
     } else {
         const int no = kind == AFFNET_NET_AFFNET ? 3 : 2;
@@ -907,60 +911,85 @@ __global__ __launch_bounds__(256) void cnn16_finish_kernel(const float* __restri
 }
 
 // ---- HardNet head: (n x 8192) x (8192 x 128) GEMM + BN bias + L2 normalisation ----------------------
-// Split-K GEMM on the fp32 matrix cores.  One workgroup = 256 threads = 32 patches x 128 outputs x one
-// quarter of K (2048): wave w owns N-tiles 2w, 2w+1 for both 16-patch M-tiles (4 accumulators, each A and
-// B fragment is used twice).  The A slab (32 x 128) is staged through LDS with 16-byte loads / stores; B
-// ([k][n], BN-folded) streams from L2.  Partial sums go to a scratch [4][n][128] with plain stores (no float
-// atomics: bit-reproducible); hardnet_finish_kernel adds them in fixed order, adds the bias and
-// L2-normalises.  ceil(n/32) x 4 workgroups (252 for 2000 patches) fill the 256 CUs.
-#define HEAD_MP 32
+// Split-K GEMM on the fp32 matrix cores.  One workgroup = 256 threads = 64 patches x 128 outputs x one quarter of K
+// (2048): wave w owns N-tiles 2w, 2w+1 for all four 16-patch M-tiles (8 accumulators).  K is walked in the conv loops'
+// interleaved order (k = 16 G + 4 kq + j belongs to k-step j of lane group kq), so per 16 k a wave issues 4
+// ds_read_b128 (A, from the LDS slab) + 2 buffer_load_dwordx4 (B, BN-folded weights [k/16][kq][n][4] from L2) for 32
+// MFMAs.  The A slab (64 x 128) is fetched one iteration ahead into registers (buffer loads: rows >= n read as zero)
+// and written to LDS with 16-byte stores.  Partial sums go to a scratch [4][n][128] with plain stores (no float atomics:
+// bit-reproducible); hardnet_finish_kernel adds them in fixed order, adds the bias and L2-normalises.
+#define HEAD_MP 64
 #define HEAD_KSPLIT 4
 #define HEAD_KC 128
-#define HEAD_AS (HEAD_KC + 4)    // row stride: 16-byte aligned rows, 2-way worst-case bank conflicts
-__global__ __launch_bounds__(256) void hardnet_head_kernel(const float* __restrict__ trunk, const float* __restrict__ Bw,
-                                                           const int32_t* __restrict__ count, int n_max, float* __restrict__ partial) {
+#define HEAD_AS (HEAD_KC + 4)    // row stride: 16-byte aligned rows
+__global__ __launch_bounds__(256, 2) void hardnet_head_kernel(const float* __restrict__ trunk, const float* __restrict__ Bw,
+                                                              const int32_t* __restrict__ count, int n_max, float* __restrict__ partial) {
     __shared__ __attribute__((aligned(16))) float As[HEAD_MP * HEAD_AS];
     const int n = count ? min(count[blockIdx.z], n_max) : n_max;      // blockIdx.z = image of the batch
     const int p0 = blockIdx.x * HEAD_MP;
     if (p0 >= n) return;
-    trunk += (size_t)blockIdx.z * n_max * HEAD_K;
     const size_t rows_total = (size_t)gridDim.z * n_max;
     const int kbeg = blockIdx.y * (HEAD_K / HEAD_KSPLIT);
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int m = lane & 15, kq = lane >> 4;
-    f32x4 acc[2][2];
+    const __amdgpu_buffer_rsrc_t rA = weight_rsrc(trunk + (size_t)blockIdx.z * n_max * HEAD_K, n * HEAD_K);   // rows >= n -> 0
+    const __amdgpu_buffer_rsrc_t rB = weight_rsrc(Bw, HEAD_K * 128);
+    int offA[8];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int r = 0; r < 8; ++r) {
+        const int f = tid + 256 * r, row = f >> 5, c4 = f & 31;       // 32 consecutive float4 = one 512-byte row segment
+        offA[r] = ((p0 + row) * HEAD_K + 4 * c4) * 4;
+    }
+    const int offB = ((kq * 128) + wave * 32 + m) * 16;
+    const unsigned a_addr = lds_byte_addr(As) + (m * HEAD_AS + 4 * kq) * 4;
+    f32x4 acc[4][2], stage[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    for (int k0 = kbeg; k0 < kbeg + HEAD_K / HEAD_KSPLIT; k0 += HEAD_KC) {
-        __syncthreads();
-        // stage 32 x 128 floats = 1024 float4, 4 per thread (coalesced: 32 consecutive float4 per row)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int f = tid + 256 * r;
-            const int row = f >> 5, c4 = f & 31;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (p0 + row < n) v = *reinterpret_cast<const float4*>(trunk + (size_t)(p0 + row) * HEAD_K + k0 + 4 * c4);
-            *reinterpret_cast<float4*>(&As[row * HEAD_AS + 4 * c4]) = v;
+    for (int r = 0; r < 8; ++r) stage[r] = buf_read4(rA, offA[r], kbeg * 4);
+#pragma unroll 1
+    for (int k0 = kbeg; k0 < kbeg + HEAD_K / HEAD_KSPLIT; k0 += HEAD_KC) {
+        __syncthreads();                                              // the previous slab has been consumed
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int f = tid + 256 * r, row = f >> 5, c4 = f & 31;
+            *reinterpret_cast<f32x4*>(&As[row * HEAD_AS + 4 * c4]) = stage[r];
         }
         __syncthreads();
-        const float* bptr = Bw + (size_t)(k0 + kq) * 128 + wave * 32 + m;
-#pragma unroll 8
-        for (int kk = 0; kk < HEAD_KC; kk += 4) {
-            const float a0 = As[m * HEAD_AS + kk + kq], a1 = As[(16 + m) * HEAD_AS + kk + kq];
-            const float b0 = bptr[(size_t)kk * 128], b1 = bptr[(size_t)kk * 128 + 16];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b1, acc[1][1], 0, 0, 0);
+        if (k0 + HEAD_KC < kbeg + HEAD_K / HEAD_KSPLIT) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) stage[r] = buf_read4(rA, offA[r], (k0 + HEAD_KC) * 4);
+        }
+        f32x4 fa[2][4], fb[2][2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[0][i] = lds_read4(a_addr + i * 16 * HEAD_AS * 4);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) fb[0][j] = buf_read4(rB, offB + j * 256, k0 * 512);
+#pragma unroll
+        for (int g = 0; g < HEAD_KC / 16; ++g) {
+            const int cur = g & 1, nxt = cur ^ 1;
+            if (g + 1 < HEAD_KC / 16) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[nxt][i] = lds_read4(a_addr + i * 16 * HEAD_AS * 4 + (g + 1) * 64);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[nxt][j] = buf_read4(rB, offB + j * 256, (k0 + 16 * (g + 1)) * 512);
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][i][s4], fb[cur][j][s4], acc[i][j], 0, 0, 0);
         }
     }
     // acc[i][j][r]: patch p0 + 16 i + 4 (lane>>4) + r, channel 32 wave + 16 j + (lane & 15)
     const int g = lane >> 4;
     float* dst = partial + ((size_t)blockIdx.y * rows_total + (size_t)blockIdx.z * n_max) * 128;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = p0 + 16 * i + 4 * g + r;
@@ -1016,6 +1045,7 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
     if (dbg_layer < 0 && !scratch)
         return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: d_scratch is required (HardNet n*(8192+512) floats, AffNet / OriNet n*144 floats)");
     if (n_max == 0) return AFFNET_OK;
+    if (kind == AFFNET_NET_HARDNET && n_max > 65535) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: n_max=%d (HardNet head: max 65535 rows per image)", n_max);
     const NetLayout L = net_layout(kind);
     CnnArgs a;
     a.packed = packed; a.off = to_offsets(L); a.patches = patches; a.lafs = lafs; a.ids = ids; a.count = count; a.n_max = n_max;

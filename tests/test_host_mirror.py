@@ -113,7 +113,7 @@ def test_packed_weights_reproduce_the_network(kind, name, weights):
     for i, (W, b) in enumerate(layers):
         x = F.relu(F.conv2d(x, W, b, stride=2 if i in (2, 4) else 1, padding=1))
     if kind == 2:
-        Bw = blob[off:off + 8192 * 128].view(8192, 128)
+        Bw = blob[off:off + 8192 * 128].view(512, 4, 128, 4).permute(0, 1, 3, 2).reshape(8192, 128)   # [k/16][(k/4)%4][n][k%4] -> [k][n]
         bias = blob[off + 8192 * 128: off + 8192 * 128 + 128]
         y = x.permute(0, 2, 3, 1).reshape(6, -1) @ Bw + bias      # head K order = [pixel][channel] (the trunk kernel's store order)
         got = y / torch.sqrt((y * y).sum(1, keepdim=True) + 1e-8)
