@@ -153,7 +153,7 @@ extern "C" int affnet_cnn32_pack_weights(int kind, const float* const* conv_w, c
     } else {
         const int no = kind == AFFNET_NET_AFFNET ? 3 : 2;
         if (!head_b) return AFFNET_ERR_INVALID;
-        // [o][pixel p][channel c]: the order in which the trunk kernels write the conv5 tensor (cnn16_head_kernel)
+        // [o][pixel p][channel c]: (pixel, 4 consecutive channels) = what one lane of the conv5 epilogue owns (head_partials)
         for (int o = 0; o < no; ++o)
             for (int c = 0; c < 64; ++c)
                 for (int pp = 0; pp < 64; ++pp) out[L.head_w + (size_t)o * 4096 + pp * 64 + c] = head_w[((size_t)o * 64 + c) * 64 + pp];

@@ -119,7 +119,7 @@ def cnn_forward(kind, packed, patches, scratch=None):
     out = torch.empty((n, 128) if kind == _lib.NET_HARDNET else (n, 2, 2), dtype=torch.float32, device=dev)
     if n == 0:
         return out
-    if scratch is None:       # conv5 tensors (+ split-K partials for HardNet) for the head kernels
+    if scratch is None:       # HardNet: conv5 tensors + split-K partials of the head GEMM; AffNet / OriNet: per-wave head partials
         scratch = torch.empty(n * ((8192 + 512) if kind == _lib.NET_HARDNET else 144), dtype=torch.float32, device=dev)
     ctx = utility_ctx(dev)
     rc = lib.affnet_cnn32_forward(ctx, kind, ptr(packed), ptr(patches), None, n, ptr(out), ptr(scratch), stream_of(dev))
