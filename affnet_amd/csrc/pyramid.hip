@@ -39,12 +39,29 @@ __global__ __launch_bounds__(256) void blur2d_kernel(const float* __restrict__ i
     out += blockIdx.z * out_stride;
     if (dec_out) dec_out += blockIdx.z * out_stride;
     const int rows_needed = min(LH, h - y0 + 2 * R);           // tiles at the bottom edge: skip rows nobody reads
-    for (int i = threadIdx.x; i < rows_needed * LW; i += 256) {
-        const int ty = i / LW, tx = i - ty * LW;
-        int gy = y0 + ty - R, gx = x0 + tx - R;
-        gy = gy < 0 ? 0 : (gy >= h ? h - 1 : gy);   // replicate padding
-        gx = gx < 0 ? 0 : (gx >= w ? w - 1 : gx);
-        tile[ty * LS + tx] = in[(size_t)gy * w + gx];
+    {
+        // every load of a thread is in flight before the first LDS store (a load-store loop with a run-time trip count
+        // compiled to two loads per s_waitcnt vmcnt(0): 12 serialized HBM round trips per workgroup for K = 15)
+        constexpr int NLD = (LH * LW + 255) / 256;
+        const int n_el = rows_needed * LW;
+        float tmp[NLD];
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = min((int)threadIdx.x + 256 * k, n_el - 1);
+            const int ty = i / LW, tx = i - ty * LW;
+            int gy = y0 + ty - R, gx = x0 + tx - R;
+            gy = gy < 0 ? 0 : (gy >= h ? h - 1 : gy);   // replicate padding
+            gx = gx < 0 ? 0 : (gx >= w ? w - 1 : gx);
+            tmp[k] = in[(size_t)gy * w + gx];
+        }
+#pragma unroll
+        for (int k = 0; k < NLD; ++k) {
+            const int i = threadIdx.x + 256 * k;
+            if (i < n_el) {
+                const int ty = i / LW, tx = i - ty * LW;
+                tile[ty * LS + tx] = tmp[k];
+            }
+        }
     }
     __syncthreads();
     const int tx = (threadIdx.x & 15) * 4, ty = (threadIdx.x >> 4) * BT_R;
