@@ -48,10 +48,11 @@ def unpack_record(row, n_cap):
     return {"LAFs": body[:, :6].reshape(n, 2, 3), "responses": body[:, 6], "descriptors": body[:, 7:]}
 
 
-def gather_features_async(local_records, n_total, group=None):
+def gather_features_async(local_records, n_total, group=None, force=False):
     """Starts the all-gather and returns a `finish()` callable that waits for it and returns the records in global image
-    order - lets the caller overlap the exchange of step k with the compute of step k+1 (bench.py)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    order - lets the caller overlap the exchange of step k with the compute of step k+1 (bench.py).  force=True runs the
+    collective even in a 1-rank group (single-GPU dry run of the RCCL path)."""
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return lambda: local_records
     world = dist.get_world_size(group)
     per_rank = -(-n_total // world)

@@ -108,15 +108,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # AFFNET_BENCH_BACKEND=gloo + AFFNET_BENCH_ONE_DEVICE=1: dry run of the N > 1 code path on a single-GPU box
-        dist.init_process_group(os.environ.get("AFFNET_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
     if os.environ.get("AFFNET_BENCH_ONE_DEVICE"):
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    # AFFNET_BENCH_SELF_GATHER=1 (single process): a 1-rank RCCL group, so that the stream-ordered all-gather of the N > 1
+    # path runs on a 1-GPU box (tools/gpu_dist_dryrun.sh); AFFNET_BENCH_BACKEND=gloo + AFFNET_BENCH_ONE_DEVICE=1: 2 ranks on one GPU
+    SELF = world == 1 and bool(os.environ.get("AFFNET_BENCH_SELF_GATHER"))
+    DIST = world > 1 or SELF
+    if DIST:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(os.environ.get("AFFNET_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
 
     import affnet_amd
     from affnet_amd import _lib, sharded
@@ -156,7 +160,7 @@ def main():
     # summed on the device and read once after the closing synchronize, the RCCL gather of step k is ordered behind
     # step k's kernels by stream semantics and waited for, on the stream, in step k+1).  A host-side sync + count
     # read-back per step left the GPU idle ~2.4 ms per 135 ms step while the host launched the next step's detector.
-    LAZY = not PIPE and S == 1 and not (world > 1 and dist.get_backend() != "nccl")
+    LAZY = not PIPE and S == 1 and not (DIST and dist.get_backend() != "nccl")
     kp_dev = torch.zeros((), dtype=torch.int64, device=dev)
 
     def step():
@@ -167,20 +171,20 @@ def main():
         if LAZY:
             with torch.cuda.stream(streams[0]):
                 kp_dev.add_(torch.stack([r["count"].sum() for r in results]).sum())
-                if world > 1:
+                if DIST:
                     if pending[0] is not None:
                         pending[0]()                            # stream-side wait for the previous step's gather
-                    pending[0] = sharded.gather_features_async(sharded.pack_batched_records(results, NKP), args.batch * world)
+                    pending[0] = sharded.gather_features_async(sharded.pack_batched_records(results, NKP), args.batch * world, force=SELF)
             return results
         for s in streams:
             s.synchronize()
         kp_dev.add_(sum(int(r["count"].sum().item()) for r in results))
-        if world > 1:
+        if DIST:
             if pending[0] is not None:
                 pending[0]()                                    # records of the previous step have arrived
             rec = sharded.pack_batched_records(results, NKP)
             torch.cuda.synchronize()
-            pending[0] = sharded.gather_features_async(rec, args.batch * world)
+            pending[0] = sharded.gather_features_async(rec, args.batch * world, force=SELF)
         return results
 
     def drain():
@@ -191,7 +195,7 @@ def main():
         torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if DIST:
             if dist.get_backend() == "nccl":
                 dist.barrier(device_ids=[local_rank])
             else:
@@ -258,7 +262,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if DIST:
         dist.destroy_process_group()
 
 
