@@ -569,11 +569,12 @@ __device__ __forceinline__ void head_partials(const float* __restrict__ hw, cons
         v[i].x = fmaxf(v[i].x, 0.0f); v[i].y = fmaxf(v[i].y, 0.0f); v[i].z = fmaxf(v[i].z, 0.0f); v[i].w = fmaxf(v[i].w, 0.0f);
     }
     if (KIND == AFFNET_NET_AFFNET) {
+        const __amdgpu_buffer_rsrc_t r = weight_rsrc(hw, 3 * 4096);
         f32x4 w[3][TM];
 #pragma unroll
         for (int o = 0; o < 3; ++o)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) w[o][i] = *reinterpret_cast<const f32x4*>(hw + o * 4096 + ((mg * TM + i) * 16 + n) * 64 + c4);
+            for (int i = 0; i < TM; ++i) w[o][i] = buf_read4(r, (n * 64 + c4) * 4, (o * 4096 + (mg * TM + i) * 16 * 64) * 4);
 #pragma unroll
         for (int o = 0; o < 3; ++o) {
             float sacc = 0.f;
@@ -585,18 +586,26 @@ __device__ __forceinline__ void head_partials(const float* __restrict__ hw, cons
             if (lane == 0) part[wave * 4 + o] = sacc;
         }
     } else {
+        // taps outside the 8x8 kernel: the lane offset is pushed past the end of the buffer, the load returns 0 (no branch,
+        // no 64-bit address arithmetic, no memory traffic for those lanes)
+        const __amdgpu_buffer_rsrc_t r = weight_rsrc(hw, 2 * 4096);
+        int toff[9][TM];
+#pragma unroll
+        for (int q = 0; q < 9; ++q)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int p = (mg * TM + i) * 16 + n, py = p >> 3, px = p & 7;
+                const int ky = py - q / 3 + 1, kx = px - q % 3 + 1;                    // padding 1: tap that sees this pixel
+                const bool ok = ky >= 0 && ky < 8 && kx >= 0 && kx < 8;
+                toff[q][i] = ok ? ((ky * 8 + kx) * 64 + c4) * 4 : 0x40000000;
+            }
 #pragma unroll
         for (int o = 0; o < 2; ++o) {
             f32x4 w[9][TM];
 #pragma unroll
             for (int q = 0; q < 9; ++q)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int p = (mg * TM + i) * 16 + n, py = p >> 3, px = p & 7;
-                    const int ky = py - q / 3 + 1, kx = px - q % 3 + 1;                    // padding 1: tap that sees this pixel
-                    const bool ok = ky >= 0 && ky < 8 && kx >= 0 && kx < 8;
-                    w[q][i] = ok ? *reinterpret_cast<const f32x4*>(hw + o * 4096 + (ky * 8 + kx) * 64 + c4) : (f32x4){0.f, 0.f, 0.f, 0.f};
-                }
+                for (int i = 0; i < TM; ++i) w[q][i] = buf_read4(r, toff[q][i], o * 4096 * 4);
 #pragma unroll
             for (int q = 0; q < 9; ++q) {
                 float sacc = 0.f;
