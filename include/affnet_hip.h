@@ -336,10 +336,12 @@ int affnet_read_counts(affnet_ctx* ctx, int32_t out[4], void* stream);
  * torch's CPU rounding; exported so the CPU test-suite can pin it against torch.linspace. */
 int affnet_host_base_grid(int ps, float* out);
 
-/* Tuning aid: runs the MFMA loop of one HardNet layer (1 or 5) in isolation `reps` times per workgroup on `n_blocks`
- * workgroups (same LDS footprint as the trunk kernel).  probe bit 0: no weight loads inside the loop, bit 1: no activation
- * loads - separates matrix-pipe issue efficiency from L2 / LDS effects.  d_out: 2 floats (sink). */
-int affnet_cnn32_probe(const float* d_packed_hardnet, int layer, int probe, int reps, int n_blocks, float* d_out, void* stream);
+/* Tuning aid: runs the MFMA loop of one layer in isolation `reps` times per workgroup on `n_blocks` workgroups (same LDS
+ * footprint as the trunk kernel).  layer 1 / 5: HardNet conv1 / conv5 (d_packed = HardNet's packed weights); 13 / 14 / 15:
+ * AffNet conv3 as 2 x 2 tiles / conv3 as 4 x 1 tiles / conv5 (d_packed = AffNet's).  probe bit 0: no weight loads inside
+ * the loop, bit 1: no activation loads, bit 2: accumulators in AGPRs, bit 3: lane-consecutive LDS read pattern (HardNet
+ * layers only) - separates matrix-pipe issue efficiency from L2 / LDS effects.  d_out: 2 floats (sink). */
+int affnet_cnn32_probe(const float* d_packed, int layer, int probe, int reps, int n_blocks, float* d_out, void* stream);
 
 /* 16x16x4 fp32 MFMA layout self-test: d_out (16,16) = A (16,4) * B (4,16). */
 int affnet_selftest_mfma(const float* d_A, const float* d_B, float* d_out, void* stream);
