@@ -664,9 +664,9 @@ __device__ __forceinline__ void dump_planes(const float* act, float* dst) {
     }
 }
 
-// KIND: 0 AffNet, 1 OriNet, 2 HardNet (CB = 16 / 16 / 32).  NW = wavefronts per workgroup (8 or 16).
-// AffNet / OriNet: 8 waves, 79 KB LDS -> 2 workgroups per CU (4 waves / SIMD).  HardNet needs 154 KB LDS
-// (1 workgroup per CU): 16 waves give the CU 4 waves / SIMD to cover LDS / L2 latency and barriers.
+// One workgroup = one patch through one trunk.  KIND: 0 AffNet, 1 OriNet, 2 HardNet (CB = 16 / 16 / 32); NW = 8 wavefronts.
+// AffNet / OriNet: 79 KB LDS -> 2 workgroups per CU (4 waves / SIMD, 128 VGPRs); HardNet: 154 KB LDS -> 1 workgroup per
+// CU (2 waves / SIMD, 256 VGPRs).
 template <int KIND, int NW>
 __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4) void cnn32_trunk_kernel(CnnArgs a, PyrSrc ps) {
     constexpr int CB = (KIND == AFFNET_NET_HARDNET) ? 32 : 16;
