@@ -23,6 +23,10 @@ def main(dirs):
             continue
         print("%-48s calls/pass %4d  avg %9.1f us" % (k, len(dur[k]) // len(dirs), sum(dur[k]) / len(dur[k])))
         print("    " + "  ".join("%s=%.4g" % (c, sum(v) / len(v)) for c, v in sorted(acc[k].items())))
+        m = {c: sum(v) / len(v) for c, v in acc[k].items()}
+        if m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) > 0 and m.get("GRBM_GUI_ACTIVE", 0) > 0:
+            # MFMA busy cycles are summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs
+            print("    -> matrix pipe busy %.1f %% of SIMD cycles" % (100.0 * (m["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / (m["GRBM_GUI_ACTIVE"] / 8.0)))
 
 
 if __name__ == "__main__":
