@@ -162,6 +162,7 @@ def main():
     # read-back per step left the GPU idle ~2.4 ms per 135 ms step while the host launched the next step's detector.
     LAZY = not PIPE and S == 1 and not (DIST and dist.get_backend() != "nccl")
     kp_dev = torch.zeros((), dtype=torch.int64, device=dev)
+    inflight = []
 
     def step():
         results = [None] * len(chunks)
@@ -170,11 +171,16 @@ def main():
                 results[ci] = dets[(ci % S, c.size(0))].enqueue(c, do_ori=True, desc=Hn, det_stream=det_stream, input_ready=False)
         if LAZY:
             with torch.cuda.stream(streams[0]):
+                if len(inflight) >= 2:
+                    inflight.pop(0).synchronize()               # host stays at most two steps ahead of the GPU (bounds memory)
                 kp_dev.add_(torch.stack([r["count"].sum() for r in results]).sum())
                 if DIST:
                     if pending[0] is not None:
                         pending[0]()                            # stream-side wait for the previous step's gather
                     pending[0] = sharded.gather_features_async(sharded.pack_batched_records(results, NKP), args.batch * world, force=SELF)
+                ev = torch.cuda.Event()
+                ev.record()
+                inflight.append(ev)
             return results
         for s in streams:
             s.synchronize()
