@@ -115,42 +115,79 @@ __global__ __launch_bounds__(256) void hessian_nms_kernel(HessParams p) {
             }
     }
     __syncthreads();
-    for (int l = 0; l < NL; ++l) {
-        const float s4 = p.sigma4[l];
-        for (int i = threadIdx.x; i < HR_H * HR_W; i += 256) {
-            const int ry = i / HR_W, rx = i - ry * HR_W;
-            const int gy = y0 + ry - 1, gx = x0 + rx - 1;
-            float r = -INFINITY;                       // outside the image: -inf for max_pool3d padding
-            if (gy >= 0 && gy < h && gx >= 0 && gx < w)
-                r = p.precomputed ? fmaxf(p.levels[l * lvl_stride + (size_t)gy * w + gx] - p.th, 0.0f)   // SparseImgRepresenter.py:77
-                                  : hessian_at(X[l], ry + 1, rx + 1, s4, p.th);
-            Rr[l][ry * HR_S + rx] = r;
+    // Responses: one thread = 5 consecutive pixels of one response row (18 rows x 14 segments = 252 threads), all NL levels.
+    // The 3 x 7 window of the blurred tile is read once into registers (21 LDS reads for 5 responses instead of 45); every
+    // response is the same expression tree as hessian_at().
+    if (p.precomputed) {
+        for (int l = 0; l < NL; ++l)
+            for (int i = threadIdx.x; i < HR_H * HR_W; i += 256) {
+                const int ry = i / HR_W, rx = i - ry * HR_W;
+                const int gy = y0 + ry - 1, gx = x0 + rx - 1;
+                float r = -INFINITY;                   // outside the image: -inf for max_pool3d padding
+                if (gy >= 0 && gy < h && gx >= 0 && gx < w) r = fmaxf(p.levels[l * lvl_stride + (size_t)gy * w + gx] - p.th, 0.0f);   // SparseImgRepresenter.py:77
+                Rr[l][ry * HR_S + rx] = r;
+            }
+    } else if (threadIdx.x < HR_H * 14) {
+        const int ry = threadIdx.x / 14, rx0 = (threadIdx.x - ry * 14) * 5;
+        const int gy = y0 + ry - 1;
+        const bool row_in = gy >= 0 && gy < h;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const float s4 = p.sigma4[l];
+            const float* xr = &X[l][ry * HX_W + rx0];  // top-left of the window: response (ry, rx) is centred on X (ry + 1, rx + 1)
+            float u[7], c[7], d[7];
+#pragma unroll
+            for (int k = 0; k < 7; ++k) {
+                const bool ok = rx0 + k < HX_W;
+                u[k] = ok ? xr[k] : 0.0f; c[k] = ok ? xr[HX_W + k] : 0.0f; d[k] = ok ? xr[2 * HX_W + k] : 0.0f;
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int rx = rx0 + k;
+                if (rx >= HR_W) break;
+                const int gx = x0 + rx - 1;
+                const float cc = c[k + 1];
+                const float gxx = (c[k] - 2.0f * cc) + c[k + 2];
+                const float gyy = (u[k + 1] - 2.0f * cc) + d[k + 1];
+                const float gx_up = 0.5f * u[k] - 0.5f * u[k + 2];
+                const float gx_dn = 0.5f * d[k] - 0.5f * d[k + 2];
+                const float gxy = 0.5f * gx_up - 0.5f * gx_dn;
+                const float t1 = gxx * gyy;
+                const float t2 = gxy * gxy;
+                const float r = fmaxf(fabsf(t1 - t2) * s4 - p.th, 0.0f);
+                Rr[l][ry * HR_S + rx] = (row_in && gx >= 0 && gx < w) ? r : -INFINITY;   // outside the image: -inf (max_pool3d padding)
+            }
         }
     }
     __syncthreads();
     const bool border_ok = (p.border < w) && (p.border < h);
-    // each thread: 4 pixels of one row
+    // NMS: each thread owns 4 pixels of one row.  Per level the 3 x 6 response window is read once; the three-row column
+    // maxima are shared by the 4 pixels and by the NL - 2 detection levels (max is order-independent: same values).
     const int ty = threadIdx.x >> 4, txb = (threadIdx.x & 15) * 4;
     const int gy = y0 + ty;
-#pragma unroll 1
+    float cm[NL][6], ctr[NL][4];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+        const float* r = &Rr[l][ty * HR_S + txb];      // top-left of the window of pixel txb (response tile has a 1-px halo)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const float a0 = r[k], a1 = r[HR_S + k], a2 = r[2 * HR_S + k];
+            cm[l][k] = fmaxf(fmaxf(a0, a1), a2);
+            if (k >= 1 && k <= 4) ctr[l][k - 1] = a1;
+        }
+    }
+#pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int tx = txb + q, gx = x0 + tx;
         if (gx >= w || gy >= h) break;
         const bool in_border = !border_ok || gy < p.border || gy >= h - p.border || gx < p.border || gx >= w - p.border;
         if (in_border) continue;                      // zero_response_at_border -> nms value 0 -> never a candidate
-        // column maxima over the 3x3 spatial window of each of the NL response levels are shared by the NL - 2 NMS levels
         float m5[NL];
 #pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            const float* r = &Rr[l][ty * HR_S + tx];  // top-left of the 3x3 window (response tile has 1-px halo)
-            float m = fmaxf(fmaxf(r[0], r[1]), r[2]);
-            m = fmaxf(m, fmaxf(fmaxf(r[HR_S], r[HR_S + 1]), r[HR_S + 2]));
-            m = fmaxf(m, fmaxf(fmaxf(r[2 * HR_S], r[2 * HR_S + 1]), r[2 * HR_S + 2]));
-            m5[l] = m;
-        }
+        for (int l = 0; l < NL; ++l) m5[l] = fmaxf(fmaxf(cm[l][q], cm[l][q + 1]), cm[l][q + 2]);
 #pragma unroll
         for (int l = 1; l <= NL - 2; ++l) {
-            const float c = Rr[l][(ty + 1) * HR_S + tx + 1];
+            const float c = ctr[l][q];
             const float M = fmaxf(fmaxf(m5[l - 1], m5[l]), m5[l + 1]);
             const float d = c - M;
             const float e = d + 1e-5f;
