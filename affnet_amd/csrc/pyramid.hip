@@ -66,22 +66,35 @@ __global__ __launch_bounds__(256) void blur2d_kernel(const float* __restrict__ i
     __syncthreads();
     const int tx = (threadIdx.x & 15) * 4, ty = (threadIdx.x >> 4) * BT_R;
     if (y0 + ty >= h) return;
-    float acc[BT_R][4];
+    // The four outputs of a thread are two packed pairs (x, x+1), (x+2, x+3): tap j multiplies the input pairs
+    // (r[j], r[j+1]) and (r[j+2], r[j+3]).  Even j takes them from E[k] = (r[2k], r[2k+1]) (the aligned 16-byte reads),
+    // odd j from O[k] = (r[2k+1], r[2k+2]), a second read of the same row one float further - every v_pk_fma_f32 then has
+    // its operands in place (built from ONE copy of the row the compiler spent 88 v_mov per 120 v_pk_fma on re-pairing).
+    // Per accumulator the fmaf chain is unchanged: taps in row-major order.
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 acc01[BT_R], acc23[BT_R];
 #pragma unroll
-    for (int rr = 0; rr < BT_R; ++rr)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[rr][q] = 0.f;
+    for (int rr = 0; rr < BT_R; ++rr) { acc01[rr] = (f32x2){0.f, 0.f}; acc23[rr] = (f32x2){0.f, 0.f}; }
     constexpr int NV = (K + 3 + 3) / 4;            // float4 loads covering K+3 values
+    constexpr int NO = (K + 1) / 2;                // odd-aligned pairs O[0 .. NO-1] (largest index used: (K - 2 + 1) / 2 = (K - 1) / 2)
     // Input-row loop stays rolled (register window + K scalar taps per (row, output row) pair).
 #pragma unroll 1
     for (int i = 0; i < BT_R + K - 1; ++i) {
-        float r[NV * 4];
-        const float4* row = reinterpret_cast<const float4*>(&tile[(ty + i) * LS + tx]);
+        f32x2 E[NV * 2], O[NO];
+        const float* rowp = &tile[(ty + i) * LS + tx];
+        const float4* row = reinterpret_cast<const float4*>(rowp);
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const float4 q = row[v];
-            r[4 * v] = q.x; r[4 * v + 1] = q.y; r[4 * v + 2] = q.z; r[4 * v + 3] = q.w;
+            E[2 * v] = (f32x2){q.x, q.y}; E[2 * v + 1] = (f32x2){q.z, q.w};
         }
+        // (through an opaque LDS address: otherwise the compiler recognises the values it already holds and rebuilds the
+        // odd pairs with v_mov again)
+        unsigned oaddr = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)rowp + 4;
+        asm("" : "+v"(oaddr));
+        typedef __attribute__((address_space(3))) const float LdsF;
+#pragma unroll
+        for (int k = 0; k < NO; ++k) O[k] = (f32x2){*(LdsF*)(size_t)(oaddr + 8 * k), *(LdsF*)(size_t)(oaddr + 8 * k + 4)};
 #pragma unroll
         for (int rr = 0; rr < BT_R; ++rr) {
             const int ti = i - rr;                  // tap row for output row rr (uniform across the workgroup)
@@ -89,13 +102,20 @@ __global__ __launch_bounds__(256) void blur2d_kernel(const float* __restrict__ i
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 const float wt = taps.w[ti * K + j];
-                acc[rr][0] = fmaf(r[j], wt, acc[rr][0]);
-                acc[rr][1] = fmaf(r[j + 1], wt, acc[rr][1]);
-                acc[rr][2] = fmaf(r[j + 2], wt, acc[rr][2]);
-                acc[rr][3] = fmaf(r[j + 3], wt, acc[rr][3]);
+                const f32x2 wv = (f32x2){wt, wt};
+                if (j & 1) {
+                    acc01[rr] = __builtin_elementwise_fma(O[(j - 1) / 2], wv, acc01[rr]);
+                    acc23[rr] = __builtin_elementwise_fma(O[(j + 1) / 2], wv, acc23[rr]);
+                } else {
+                    acc01[rr] = __builtin_elementwise_fma(E[j / 2], wv, acc01[rr]);
+                    acc23[rr] = __builtin_elementwise_fma(E[j / 2 + 1], wv, acc23[rr]);
+                }
             }
         }
     }
+    float acc[BT_R][4];
+#pragma unroll
+    for (int rr = 0; rr < BT_R; ++rr) { acc[rr][0] = acc01[rr].x; acc[rr][1] = acc01[rr].y; acc[rr][2] = acc23[rr].x; acc[rr][3] = acc23[rr].y; }
     const int x = x0 + tx;
 #pragma unroll
     for (int rr = 0; rr < BT_R; ++rr) {
