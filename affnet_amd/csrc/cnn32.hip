@@ -644,7 +644,7 @@ struct CnnArgs {
 
 #define CNN_STAMP(k)                                                                                     \
     do {                                                                                                 \
-        if (a.dbg_time && lane == 0) a.dbg_time[((size_t)pidx * NW + wave) * 32 + (k)] = __builtin_readcyclecounter(); \
+        if (STAMPS && a.dbg_time && lane == 0) a.dbg_time[((size_t)pidx * NW + wave) * 32 + (k)] = __builtin_readcyclecounter(); \
     } while (0)
 
 template <int CB>
@@ -667,7 +667,9 @@ __device__ __forceinline__ void dump_planes(const float* act, float* dst) {
 // One workgroup = one patch through one trunk.  KIND: 0 AffNet, 1 OriNet, 2 HardNet (CB = 16 / 16 / 32); NW = 8 wavefronts.
 // AffNet / OriNet: 79 KB LDS -> 2 workgroups per CU (4 waves / SIMD, 128 VGPRs); HardNet: 154 KB LDS -> 1 workgroup per
 // CU (2 waves / SIMD, 256 VGPRs).
-template <int KIND, int NW>
+// STAMPS = debug instantiation: the s_memtime phase stamps of tools/cnn_phase_timing.py and the per-layer activation dumps
+// of affnet_cnn32_debug_layer exist only there (26 stamp sites = 26 predicated stores + branches in every wave otherwise).
+template <int KIND, int NW, bool STAMPS>
 __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4) void cnn32_trunk_kernel(CnnArgs a, PyrSrc ps) {
     constexpr int CB = (KIND == AFFNET_NET_HARDNET) ? 32 : 16;
     constexpr int NTHR = NW * 64;
@@ -704,7 +706,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
     constexpr bool PRIO = (KIND == AFFNET_NET_HARDNET);
     if (PRIO) __builtin_amdgcn_s_setprio(3);
     CNN_STAMP(0);
-    if (a.dbg_time && lane == 0) {      // where this workgroup runs (tuning aid: per-CU timelines)
+    if (STAMPS && a.dbg_time && lane == 0) {   // where this workgroup runs (tuning aid: per-CU timelines)
         a.dbg_time[((size_t)pidx * NW + wave) * 32 + 14] = __builtin_amdgcn_s_getreg((31 << 11) | 4);    // HW_REG_HW_ID
         a.dbg_time[((size_t)pidx * NW + wave) * 32 + 15] = __builtin_amdgcn_s_getreg((31 << 11) | 20);   // HW_REG_XCC_ID
     }
@@ -770,7 +772,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         CNN_STAMP(20);
     }
     __syncthreads();
-    if (a.dbg_layer == 0) { dump_planes<CB, LayC0, NTHR>(act, a.dbg_out); return; }
+    if (STAMPS && a.dbg_layer == 0) { dump_planes<CB, LayC0, NTHR>(act, a.dbg_out); return; }
     CNN_STAMP(2);
 
     // Every layer: MFMA loop -> request the next layer's first weight chunk and bias -> barrier (all waves done reading
@@ -795,7 +797,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         __syncthreads();
         CNN_STAMP(4);
     }
-    if (a.dbg_layer == 1) { dump_planes<CB, LayC1, NTHR>(act, a.dbg_out); return; }
+    if (STAMPS && a.dbg_layer == 1) { dump_planes<CB, LayC1, NTHR>(act, a.dbg_out); return; }
 
     // ---- conv2: CB -> 2CB, stride 2 @16x16 -----------------------------------------------------------
     f32x4 b3[G3][T2N];
@@ -814,7 +816,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         __syncthreads();
         CNN_STAMP(6);
     }
-    if (a.dbg_layer == 2) { dump_planes<2 * CB, LayC2, NTHR>(act, a.dbg_out); return; }
+    if (STAMPS && a.dbg_layer == 2) { dump_planes<2 * CB, LayC2, NTHR>(act, a.dbg_out); return; }
 
     // ---- conv3: 2CB -> 2CB @16x16 --------------------------------------------------------------------
     f32x4 b4[G4][T4N];
@@ -833,7 +835,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         __syncthreads();
         CNN_STAMP(8);
     }
-    if (a.dbg_layer == 3) { dump_planes<2 * CB, LayC3, NTHR>(act, a.dbg_out); return; }
+    if (STAMPS && a.dbg_layer == 3) { dump_planes<2 * CB, LayC3, NTHR>(act, a.dbg_out); return; }
 
     // ---- conv4: 2CB -> 4CB, stride 2 @8x8 --------------------------------------------------------------
     f32x4 b5[G5][T4N];
@@ -852,7 +854,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         __syncthreads();
         CNN_STAMP(10);
     }
-    if (a.dbg_layer == 4) { dump_planes<4 * CB, LayC4, NTHR>(act, a.dbg_out); return; }
+    if (STAMPS && a.dbg_layer == 4) { dump_planes<4 * CB, LayC4, NTHR>(act, a.dbg_out); return; }
 
     // ---- conv5: 4CB -> 4CB @8x8 ------------------------------------------------------------------------
     {
@@ -861,7 +863,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         conv3x3_mfma<NW, 4 * CB, 4 * CB, LayC4, 1, T4M, T4N, G5>(act, a.packed + a.off.w[5], b5, acc, wave, lane);
         if (PRIO) __builtin_amdgcn_s_setprio(3);
         CNN_STAMP(11);
-        if (a.dbg_layer < 0) {
+        if (!STAMPS || a.dbg_layer < 0) {
             if constexpr (KIND == AFFNET_NET_HARDNET)   // conv5 tensor -> HBM as [pixel][channel]; the head GEMM runs over all patches
                 store_tiles_global<4 * CB, T4M, T4N>(a.out + pidx * (64 * 4 * CB), bias5, acc, wave, lane);
             else                                        // per-wave partial sums of the head's dot products
@@ -875,7 +877,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         __syncthreads();
         CNN_STAMP(12);
     }
-    if (a.dbg_layer == 5) { dump_planes<4 * CB, LayC5, NTHR>(act, a.dbg_out); return; }
+    if (STAMPS && a.dbg_layer == 5) { dump_planes<4 * CB, LayC5, NTHR>(act, a.dbg_out); return; }
 }
 
 // ---- AffNet / OriNet heads, second half: combine the eight per-wave partials of a patch, one thread per patch -------
@@ -1066,9 +1068,12 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
     const dim3 grid(n_max, B);
     // (Tried and removed: two AffNet patches per persistent 16-wave workgroup in anti-phase - correct but 8 % slower, the
     // small-tile loops reach 85-90 % of the pipe rate with two waves per SIMD; 16-wave HardNet workgroups - slower too.)
-    if (kind == AFFNET_NET_AFFNET) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_AFFNET, 8>), grid, dim3(512), 0, st, a, ps);
-    else if (kind == AFFNET_NET_ORINET) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_ORINET, 8>), grid, dim3(512), 0, st, a, ps);
-    else hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_HARDNET, 8>), grid, dim3(512), 0, st, a, ps);
+#define TRUNK_LAUNCH(K) do { if (a.dbg_time || dbg_layer >= 0) hipLaunchKernelGGL((cnn32_trunk_kernel<K, 8, true>), grid, dim3(512), 0, st, a, ps); \
+                             else hipLaunchKernelGGL((cnn32_trunk_kernel<K, 8, false>), grid, dim3(512), 0, st, a, ps); } while (0)
+    if (kind == AFFNET_NET_AFFNET) TRUNK_LAUNCH(AFFNET_NET_AFFNET);
+    else if (kind == AFFNET_NET_ORINET) TRUNK_LAUNCH(AFFNET_NET_ORINET);
+    else TRUNK_LAUNCH(AFFNET_NET_HARDNET);
+#undef TRUNK_LAUNCH
     AFF_LAUNCH_CHECK(ctx);
     if (kind != AFFNET_NET_HARDNET && dbg_layer < 0) {       // combine the per-wave head partials in `scratch`
         const dim3 hgrid(aff_cdiv(n_max, 256), B);
