@@ -10,7 +10,9 @@ libaffnet_hip.so.
 
 Default slots as in the reference (SparseImgRepresenter.py:42-49): OriNet=None -> OrientationDetector(patch_size=19),
 AffNet=None -> AffineShapeEstimator(patch_size=19) (affnet_amd.HandCraftedModules, csrc/handcrafted.hip); a custom
-RespNet callable is evaluated per pyramid level and the detector runs on its response maps.  nlevels 1..6 (the reference's default is 3).
+RespNet callable is evaluated per pyramid level and the detector runs on its response maps.  nlevels 1..6 (the reference's default
+is 3; nlevels = 1 blurs with a 35 x 35 Gaussian), any init_sigma (init_sigma <= 0.5: octave 0 keeps the unblurred image and its own blur
+sequence, HandCraftedModules.py:25-31).
 """
 import ctypes as C
 
@@ -56,7 +58,7 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
                              "(HandCraftedModules.py:283-284) - use enqueue()/run_batch() for (B,1,H,W) batches")
         pre = int(1.5 * self.num) if self.num_Baum_iters > 0 else self.num
         key = (x.size(0), x.size(2), x.size(3), x.device, pre, self.num, float(self.th), self.mrSize, self.b, self.init_sigma,
-               self.max_keep, self.num_Baum_iters, self.raw_div)
+               self.nlevels, self.max_keep, self.num_Baum_iters, self.raw_div)
         if self._ctx is None or self._ctx_key != key:
             self._ctx = engine.Context(x.size(2), x.size(3), x.device, self.nlevels, self.init_sigma, self.b, self.mrSize,
                                        float(self.th), self.num, pre, self.max_keep, batch=x.size(0), baum_iters=self.num_Baum_iters, raw_div=self.raw_div)
@@ -161,7 +163,7 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
         enqueue for the whole batch, then ONE host read-back of the B row counts."""
         r = self.enqueue(x, do_ori=do_ori, desc=desc)
         ctx = self._ctx
-        ctx.read_counts()                   # surfaces capacity overflow
+        ctx.read_counts(allow_empty=True)   # surfaces capacity overflow; images without detections are legal in a batch
         cnt = r["count"].cpu().tolist()
         if x.size(0) == 1:
             r = {k: (v.unsqueeze(0) if isinstance(v, torch.Tensor) and k not in ("count", "_img") else v) for k, v in r.items()}
@@ -178,10 +180,9 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
         r = self.enqueue(x, do_ori=do_ori, desc=desc)
         ctx = self._ctx
         self._publish_pyramid(ctx)
-        counts = ctx.read_counts()          # the one host read-back (also surfaces capacity overflow)
+        ctx.read_counts()                   # the one host read-back: raises on capacity overflow and (AffnetEmptyError,
+                                            # "no keypoints detected") on an image without detections, like the reference
         n = int(r["count"].item())
-        if counts[0] == 0:
-            raise RuntimeError("no keypoints detected (the reference raises in torch.cat, SparseImgRepresenter.py:100)")
         self.last_ids = r["ids"][:n]
         dsc = r["descriptors"]
         return {"LAFs": r["LAFs"][:n], "responses": r["responses"][:n], "ids": r["ids"][:n],
@@ -210,9 +211,7 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
         else:
             check(lib.affnet_detect(ctx.handle, ptr(resp), ptr(lafs), ptr(ids), ptr(cnt), st), ctx.handle, "affnet_detect")
         n = int(cnt.item())
-        ctx.read_counts()
-        if n == 0:
-            raise RuntimeError("no keypoints detected (the reference raises in torch.cat, SparseImgRepresenter.py:100)")
+        ctx.read_counts()                   # raises AffnetEmptyError ("no keypoints detected") / on capacity overflow
         if self.num_Baum_iters > 1:
             raise NotImplementedError("num_Baum_iters > 1 with a foreign AffNet slot: use the native AffNetFast (fused path)")
         if self.num_Baum_iters > 0:

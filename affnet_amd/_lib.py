@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaffnet_hip.so")
 
-MAX_OCTAVES, MAX_LEVELS, MAX_TAPS = 16, 8, 31
+MAX_OCTAVES, MAX_LEVELS, MAX_TAPS = 16, 8, 37
 NET_AFFNET, NET_ORINET, NET_HARDNET = 0, 1, 2
 OK, ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_EMPTY = 0, -1, -2, -3, -4
 
@@ -25,6 +25,8 @@ class Config(C.Structure):
         ("first_blur_taps", C.c_int32), ("first_blur", C.c_float * (MAX_TAPS * MAX_TAPS)),
         ("level_blur_taps", C.c_int32 * MAX_LEVELS),
         ("level_blur", (C.c_float * (MAX_TAPS * MAX_TAPS)) * MAX_LEVELS),
+        ("level_blur0_taps", C.c_int32 * MAX_LEVELS),
+        ("level_blur0", (C.c_float * (MAX_TAPS * MAX_TAPS)) * MAX_LEVELS),
         ("mr_size", C.c_float), ("threshold", C.c_float),
         ("num_features", C.c_int32), ("num_prefilter", C.c_int32),
         ("max_raw_per_octave_div", C.c_int32), ("max_keep", C.c_int32), ("batch", C.c_int32), ("baum_iters", C.c_int32),
@@ -61,8 +63,6 @@ SYMBOLS = {
     "affnet_cnn32_pack_weights": (_I, [_I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _P, _P, _P, _P]),
     "affnet_cnn32_forward": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P]),
     "affnet_cnn32_forward_pyr": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
-    "affnet_cnn32_debug_timing": (_I, [_P]),
-    "affnet_cnn32_debug_layer": (_I, [_P, _I, _P, _P, _I, _P, _P]),
     "affnet_shape_filter_select": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "affnet_apply_rotation": (_I, [_P, _P, _P, _P, _I, _P]),
     "affnet_scale_lafs": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -83,13 +83,25 @@ SYMBOLS = {
     "affnet_profile_read": (_I, [_P, C.POINTER(C.c_double * 8), C.POINTER(C.c_int32)]),
     "affnet_read_counts": (_I, [_P, C.POINTER(C.c_int32 * 4), _P]),
     "affnet_host_base_grid": (_I, [_I, C.POINTER(C.c_float)]),
+}
+
+# include/affnet_hip_debug.h: parity / tuning aids, not part of the drop-in boundary
+DEBUG_SYMBOLS = {
+    "affnet_cnn32_debug_timing": (_I, [_P, _P]),
+    "affnet_cnn32_debug_layer": (_I, [_P, _I, _P, _P, _I, _P, _P]),
     "affnet_cnn32_probe": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "affnet_selftest_mfma": (_I, [_P, _P, _P, _P]),
+    "affnet_debug_stream": (_I, [_P, _P, _SZ, _I, _I, _I, _P]),
 }
 
 
 class AffnetHipError(RuntimeError):
     pass
+
+
+class AffnetEmptyError(AffnetHipError):
+    """AFFNET_ERR_EMPTY: no image of the call produced a detection (the reference raises in torch.cat([]),
+    SparseImgRepresenter.py:100)."""
 
 
 def _load():
@@ -98,9 +110,10 @@ def _load():
             "affnet_amd: %s is missing - the HIP extension is the only implementation of this path "
             "(no CPU fallback). Build it: bash affnet_amd/csrc/build.sh" % LIB_PATH)
     lib = C.CDLL(LIB_PATH)
-    for name, (res, args) in SYMBOLS.items():
-        fn = getattr(lib, name)  # raises AttributeError if the symbol is not exported
-        fn.restype, fn.argtypes = res, args
+    for table in (SYMBOLS, DEBUG_SYMBOLS):
+        for name, (res, args) in table.items():
+            fn = getattr(lib, name)  # raises AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
     return lib
 
 
@@ -110,6 +123,8 @@ lib = _load()
 def check(rc, ctx=None, what=""):
     if rc != OK:
         msg = lib.affnet_last_error(ctx).decode() if ctx else ""
+        if rc == ERR_EMPTY:
+            raise AffnetEmptyError("%s: %s" % (what or "libaffnet_hip call", msg))
         raise AffnetHipError("%s failed (code %d): %s" % (what or "libaffnet_hip call", rc, msg))
 
 

@@ -44,12 +44,22 @@ class _HipPatchNet(nn.Module):
         self._bump()
         return r
 
+    def _weights_stamp(self):
+        """Changes whenever a parameter or buffer is replaced (load_state_dict / .to()) or modified in place
+        (p.data.copy_(), BN running-stat updates, direct state-dict tensor edits all bump the tensor's `_version`)."""
+        return (self._version,) + tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+
+    def invalidate_packed(self):
+        """Drops the cached BN-folded weight blob (it is rebuilt on the next call)."""
+        self._packed = None
+
     def packed_weights(self, device):
-        """BN-folded, MFMA-ordered weight blob on `device` (cached until the parameters change)."""
-        if self._packed is None or self._packed_version != self._version or self._packed.device != device:
+        """BN-folded, MFMA-ordered weight blob on `device` (cached until the parameters / buffers change)."""
+        stamp = self._weights_stamp()
+        if self._packed is None or self._packed_version != stamp or self._packed.device != device:
             blob = engine.pack_state_dict(self.KIND, self.state_dict())
             self._packed = blob.to(device)
-            self._packed_version = self._version
+            self._packed_version = stamp
         return self._packed
 
     def _run(self, patches):

@@ -1045,8 +1045,6 @@ void aff_fill_pyr_src(const affnet_ctx* ctx, PyrSrc* t) {
     aff_base_grid(32, t->base);
 }
 
-static unsigned long long* g_dbg_time = nullptr;   // tuning aid, see affnet_cnn32_debug_timing
-
 static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const float* patches, const float* lafs, const int32_t* ids,
                       const int32_t* count, int n_max, float* out, float* scratch, int dbg_layer, float* dbg_out, hipStream_t st,
                       bool mark_head = false) {
@@ -1061,7 +1059,7 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
     CnnArgs a;
     a.packed = packed; a.off = to_offsets(L); a.patches = patches; a.lafs = lafs; a.ids = ids; a.count = count; a.n_max = n_max;
     a.out = (dbg_layer < 0) ? scratch : out;              // trunk kernels: HardNet conv5 tensor / AffNet, OriNet head partials
-    a.dbg_layer = dbg_layer; a.dbg_out = dbg_out; a.dbg_time = g_dbg_time;
+    a.dbg_layer = dbg_layer; a.dbg_out = dbg_out; a.dbg_time = ctx->dbg_time;
     PyrSrc ps;
     aff_fill_pyr_src(ctx, &ps);
     const int B = patches ? 1 : ctx->B;                  // patch tensors are single-"image"; pyramid sampling covers the batch
@@ -1097,12 +1095,14 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
 
 extern "C" int affnet_cnn32_forward(affnet_ctx* ctx, int net_kind, const float* d_packed, const float* d_patches, const int32_t* d_count,
                                     int n_max, float* d_out, float* d_scratch, void* stream) {
+    AFF_DEVICE(ctx);
     if (!ctx || !d_patches) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32_forward: null argument");
     return cnn_launch(ctx, net_kind, d_packed, d_patches, nullptr, nullptr, d_count, n_max, d_out, d_scratch, -1, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int affnet_cnn32_forward_pyr(affnet_ctx* ctx, int net_kind, const float* d_packed, const float* d_lafs, const int32_t* d_ids,
                                         const int32_t* d_count, int n_max, float* d_out, float* d_scratch, void* stream) {
+    AFF_DEVICE(ctx);
     if (!ctx) return AFFNET_ERR_INVALID;
     return cnn_launch(ctx, net_kind, d_packed, nullptr, d_lafs, d_ids, d_count, n_max, d_out, d_scratch, -1, nullptr, (hipStream_t)stream);
 }
@@ -1112,13 +1112,15 @@ int aff_hardnet_forward_pyr_marked(affnet_ctx* ctx, const float* packed, const f
     return cnn_launch(ctx, AFFNET_NET_HARDNET, packed, nullptr, lafs, ids, count, n_max, out, scratch, -1, nullptr, st, true);
 }
 
-extern "C" int affnet_cnn32_debug_timing(unsigned long long* d_stamps) {
-    g_dbg_time = d_stamps;   // device buffer of n_patches * waves * 16 uint64, or NULL to switch the stamps off
+extern "C" int affnet_cnn32_debug_timing(affnet_ctx* ctx, unsigned long long* d_stamps) {
+    if (!ctx) return AFFNET_ERR_INVALID;
+    ctx->dbg_time = d_stamps;   // device buffer of n_patches * waves * 32 uint64, or NULL to switch the stamps off (this context only)
     return AFFNET_OK;
 }
 
 extern "C" int affnet_cnn32_debug_layer(affnet_ctx* ctx, int net_kind, const float* d_packed, const float* d_patch, int layer, float* d_out,
                                         void* stream) {
+    AFF_DEVICE(ctx);
     if (!ctx || !d_patch || !d_out || layer < 0 || layer > 5) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32_debug_layer: bad argument");
     return cnn_launch(ctx, net_kind, d_packed, d_patch, nullptr, nullptr, nullptr, 1, d_out, nullptr, layer, d_out, (hipStream_t)stream);
 }

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "../../include/affnet_hip.h"
+#include "../../include/affnet_hip_debug.h"
 
 #define AFF_WAVE 64
 
@@ -81,7 +82,28 @@ struct affnet_ctx {
     bool prof_on = false;
     std::vector<hipEvent_t> prof_ev;   // ring: PROF_RING calls x PROF_EVENTS events
     int prof_calls = 0;
+    // tuning aid (include/affnet_hip_debug.h): s_memtime stamp buffer of THIS context's CNN launches, or NULL
+    unsigned long long* dbg_time = nullptr;
 };
+
+// Every entry point that launches work makes the context's device current for the duration of the call and restores
+// the caller's device afterwards (a context is bound to ONE device, affnet_ctx_create; the caller's current device
+// may be another one in a multi-GPU process).  Tolerates a host without a GPU (CPU-side argument checks still run).
+struct AffDeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    explicit AffDeviceGuard(const affnet_ctx* ctx) {
+        if (!ctx) return;
+        if (hipGetDevice(&prev) != hipSuccess) { (void)hipGetLastError(); prev = -1; return; }
+        if (prev != ctx->device) switched = hipSetDevice(ctx->device) == hipSuccess;
+    }
+    ~AffDeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    AffDeviceGuard(const AffDeviceGuard&) = delete;
+    AffDeviceGuard& operator=(const AffDeviceGuard&) = delete;
+};
+#define AFF_DEVICE(ctx) AffDeviceGuard aff_device_guard_(ctx)
 
 #define PROF_RING 256
 #define PROF_EVENTS (AFFNET_PROFILE_STAGES + 2)   // 9 stage boundaries + end-of-detector (index 9)

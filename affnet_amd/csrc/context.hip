@@ -13,7 +13,7 @@ int aff_fail(affnet_ctx* ctx, int code, const char* fmt, ...) {
     return code;
 }
 
-extern "C" const char* affnet_version(void) { return "affnet_hip 0.1 (gfx950, hipcc, fp32 MFMA 16x16x4)"; }
+extern "C" const char* affnet_version(void) { return "affnet_hip 0.2 (gfx950, hipcc, fp32 MFMA 16x16x4)"; }
 
 extern "C" const char* affnet_last_error(const affnet_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
@@ -51,6 +51,10 @@ static int validate(affnet_ctx* ctx, const affnet_config* c) {
     for (int l = 1; l < c->levels_per_octave; ++l)
         if (c->level_blur_taps[l] % 2 == 0 || c->level_blur_taps[l] < 1 || c->level_blur_taps[l] > AFFNET_MAX_TAPS)
             return aff_fail(ctx, AFFNET_ERR_INVALID, "level_blur_taps[%d]=%d", l, c->level_blur_taps[l]);
+    if (c->level_blur0_taps[1] != 0)
+        for (int l = 1; l < c->levels_per_octave; ++l)
+            if (c->level_blur0_taps[l] % 2 == 0 || c->level_blur0_taps[l] < 1 || c->level_blur0_taps[l] > AFFNET_MAX_TAPS)
+                return aff_fail(ctx, AFFNET_ERR_INVALID, "level_blur0_taps[%d]=%d", l, c->level_blur0_taps[l]);
     return AFFNET_OK;
 }
 
@@ -135,6 +139,15 @@ extern "C" int affnet_bind_workspace(affnet_ctx* ctx, void* d_workspace, size_t 
     if (!d_workspace || bytes < ctx->ws_bytes)
         return aff_fail(ctx, AFFNET_ERR_INVALID, "workspace too small: %zu < %zu", bytes, ctx->ws_bytes);
     if (((uintptr_t)d_workspace & 255) != 0) return aff_fail(ctx, AFFNET_ERR_INVALID, "workspace must be 256-byte aligned");
+    {   // the workspace must live on the context's device: a pointer of another GPU would fault (or silently run there)
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, d_workspace) == hipSuccess) {
+            if (at.type == hipMemoryTypeDevice && at.device != ctx->device)
+                return aff_fail(ctx, AFFNET_ERR_INVALID, "workspace belongs to device %d, the context to device %d", at.device, ctx->device);
+        } else {
+            (void)hipGetLastError();   // not a HIP allocation / no GPU present (CPU-side layout tests): nothing to check
+        }
+    }
     char* b = (char*)d_workspace;
     ctx->ws = b;
     ctx->pyr = (float*)(b + ctx->off_pyr);
@@ -164,6 +177,7 @@ extern "C" int affnet_bind_workspace(affnet_ctx* ctx, void* d_workspace, size_t 
 }
 
 extern "C" int affnet_read_counts(affnet_ctx* ctx, int32_t out[4], void* stream) {
+    AFF_DEVICE(ctx);
     if (!ctx || !ctx->ws) return AFFNET_ERR_INVALID;
     std::vector<int32_t> all((size_t)ctx->B * CNT_TOTAL);
     AFF_HIP(ctx, hipMemcpyAsync(all.data(), ctx->cnt, all.size() * sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
@@ -179,5 +193,7 @@ extern "C" int affnet_read_counts(affnet_ctx* ctx, int32_t out[4], void* stream)
     out[0] = host[CNT_DET]; out[1] = host[CNT_SHAPED]; out[2] = host[CNT_OVERFLOW];
     out[3] = raw;
     if (host[CNT_OVERFLOW]) return aff_fail(ctx, AFFNET_ERR_CAPACITY, "a fixed-capacity detector list overflowed (flag %d)", host[CNT_OVERFLOW]);
+    if (host[CNT_DET] == 0)
+        return aff_fail(ctx, AFFNET_ERR_EMPTY, "no keypoints detected in %d image(s) (the reference raises in torch.cat, SparseImgRepresenter.py:100)", ctx->B);
     return AFFNET_OK;
 }

@@ -264,6 +264,7 @@ __global__ __launch_bounds__(256) void hessian_resp_kernel(const float* __restri
 }
 
 extern "C" int affnet_hessian_response(affnet_ctx* ctx, const float* d_in, float* d_out, int h, int w, float sigma4, void* stream) {
+    AFF_DEVICE(ctx);
     if (!ctx || !d_in || !d_out || h < 1 || w < 1) return aff_fail(ctx, AFFNET_ERR_INVALID, "hessian_response: bad argument");
     hipLaunchKernelGGL(hessian_resp_kernel, dim3(aff_cdiv(w, 64), aff_cdiv(h, 4)), dim3(256), 0, (hipStream_t)stream, d_in, d_out, h,
                        w, sigma4);
@@ -571,11 +572,13 @@ int aff_detect_impl(affnet_ctx* ctx, const float* d_responses, float* d_resp, fl
 }
 
 extern "C" int affnet_detect(affnet_ctx* ctx, float* d_resp, float* d_lafs, int32_t* d_ids, int32_t* d_count, void* stream) {
+    AFF_DEVICE(ctx);
     return aff_detect_impl(ctx, nullptr, d_resp, d_lafs, d_ids, d_count, stream);
 }
 
 extern "C" int affnet_detect_responses(affnet_ctx* ctx, const float* d_responses, float* d_resp, float* d_lafs, int32_t* d_ids,
                                        int32_t* d_count, void* stream) {
+    AFF_DEVICE(ctx);
     if (!d_responses) return aff_fail(ctx, AFFNET_ERR_INVALID, "detect_responses: null response pyramid");
     return aff_detect_impl(ctx, d_responses, d_resp, d_lafs, d_ids, d_count, stream);
 }

@@ -160,12 +160,14 @@ int aff_handcrafted_launch(affnet_ctx* ctx, int kind, const float* patches, cons
 
 extern "C" int affnet_handcrafted_forward(affnet_ctx* ctx, int kind, const float* d_patches, int n, const float* h_weights, float* d_out,
                                           float* d_angles, void* stream) {
+    AFF_DEVICE(ctx);
     if (!ctx || !d_patches) return aff_fail(ctx, AFFNET_ERR_INVALID, "handcrafted_forward: null argument");
     return aff_handcrafted_launch(ctx, kind, d_patches, nullptr, nullptr, nullptr, n, h_weights, d_out, d_angles, (hipStream_t)stream);
 }
 
 extern "C" int affnet_handcrafted_forward_pyr(affnet_ctx* ctx, int kind, const float* d_lafs, const int32_t* d_ids, const int32_t* d_count,
                                               int n_max, const float* h_weights, float* d_out, void* stream) {
+    AFF_DEVICE(ctx);
     if (!ctx) return AFFNET_ERR_INVALID;
     return aff_handcrafted_launch(ctx, kind, nullptr, d_lafs, d_ids, d_count, n_max, h_weights, d_out, nullptr, (hipStream_t)stream);
 }

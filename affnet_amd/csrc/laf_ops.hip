@@ -70,12 +70,14 @@ static int sample_common(affnet_ctx* ctx, const float* img, int h, int w, int us
 
 extern "C" int affnet_laf_grid_sample(affnet_ctx* ctx, const float* d_img, int h, int w, const float* d_lafs, int n, int ps,
                                       float* d_out, void* stream) {
+    AFF_DEVICE(ctx);
     if (!ctx || !d_img || !d_lafs || !d_out || h < 1 || w < 1 || n < 0) return aff_fail(ctx, AFFNET_ERR_INVALID, "laf_grid_sample: bad argument");
     return sample_common(ctx, d_img, h, w, 0, d_lafs, nullptr, nullptr, n, ps, d_out, (hipStream_t)stream);
 }
 
 extern "C" int affnet_pyr_grid_sample(affnet_ctx* ctx, const float* d_lafs, const int32_t* d_ids, const int32_t* d_count, int n_max,
                                       int ps, float* d_out, void* stream) {
+    AFF_DEVICE(ctx);
     if (!ctx || !ctx->ws || !d_lafs || !d_ids || !d_out || n_max < 0) return aff_fail(ctx, AFFNET_ERR_INVALID, "pyr_grid_sample: bad argument");
     return sample_common(ctx, nullptr, 0, 0, 1, d_lafs, d_ids, d_count, n_max, ps, d_out, (hipStream_t)stream);
 }
@@ -199,6 +201,7 @@ __global__ __launch_bounds__(256) void shape_emit_kernel(const float* __restrict
 extern "C" int affnet_shape_filter_select(affnet_ctx* ctx, const float* d_resp_in, const float* d_lafs_in, const int32_t* d_ids_in,
                                           const float* d_A, const int32_t* d_count_in, float* d_resp_out, float* d_lafs_out,
                                           int32_t* d_ids_out, int32_t* d_count_out, void* stream) {
+    AFF_DEVICE(ctx);
     if (!ctx || !ctx->ws || !d_resp_in || !d_lafs_in || !d_ids_in || !d_A || !d_count_in || !d_resp_out || !d_lafs_out || !d_ids_out ||
         !d_count_out)
         return aff_fail(ctx, AFFNET_ERR_INVALID, "shape_filter_select: bad argument");
@@ -272,6 +275,7 @@ __global__ void apply_rotation_kernel(float* __restrict__ lafs, const float* __r
 }
 
 extern "C" int affnet_apply_rotation(affnet_ctx* ctx, float* d_lafs, const float* d_R, const int32_t* d_count, int n_max, void* stream) {
+    AFF_DEVICE(ctx);
     if (!ctx || !d_lafs || !d_R || n_max < 0) return aff_fail(ctx, AFFNET_ERR_INVALID, "apply_rotation: bad argument");
     if (n_max == 0) return AFFNET_OK;
     hipLaunchKernelGGL(apply_rotation_kernel, dim3(aff_cdiv(n_max, 256), ctx->B), dim3(256), 0, (hipStream_t)stream, d_lafs, d_R, d_count, n_max);
@@ -294,6 +298,7 @@ __global__ void scale_lafs_kernel(const float* __restrict__ in, float* __restric
 
 extern "C" int affnet_scale_lafs(affnet_ctx* ctx, const float* d_in, float* d_out, const int32_t* d_count, int n_max, int w, int h,
                                  int inverse, void* stream) {
+    AFF_DEVICE(ctx);
     if (!ctx || !d_in || !d_out || n_max < 0 || w < 1 || h < 1) return aff_fail(ctx, AFFNET_ERR_INVALID, "scale_lafs: bad argument");
     if (n_max == 0) return AFFNET_OK;
     const float fw = (float)w, fh = (float)h, m = fw < fh ? fw : fh;
@@ -337,6 +342,7 @@ __global__ void level_select_kernel(const float* __restrict__ lafs_px, const int
 
 extern "C" int affnet_level_select(affnet_ctx* ctx, const float* d_lafs_px, const int32_t* d_count, int n_max, int ps, int32_t* d_ids,
                                    float* d_lafs_norm, void* stream) {
+    AFF_DEVICE(ctx);
     if (!ctx || !d_lafs_px || !d_ids || !d_lafs_norm || n_max < 0 || ps < 1) return aff_fail(ctx, AFFNET_ERR_INVALID, "level_select: bad argument");
     if (n_max == 0) return AFFNET_OK;
     LevelTable lt;
@@ -384,6 +390,7 @@ __global__ void lafs2ell_kernel(const float* __restrict__ lafs, const int32_t* _
 }
 
 extern "C" int affnet_lafs_to_ellipses(affnet_ctx* ctx, const float* d_lafs, const int32_t* d_count, int n_max, float* d_out, void* stream) {
+    AFF_DEVICE(ctx);
     if (!ctx || !d_lafs || !d_out || n_max < 0) return aff_fail(ctx, AFFNET_ERR_INVALID, "lafs_to_ellipses: bad argument");
     if (n_max == 0) return AFFNET_OK;
     hipLaunchKernelGGL(lafs2ell_kernel, dim3(aff_cdiv(n_max, 256), ctx->B), dim3(256), 0, (hipStream_t)stream, d_lafs, d_count, n_max, d_out);

@@ -130,6 +130,7 @@ __global__ __launch_bounds__(1024) void snn_select_kernel(const float* __restric
 extern "C" int affnet_match_snn(affnet_ctx* ctx, const float* d_desc1, int n1, const float* d_desc2, int n2, int dim, float snn_threshold,
                                 float* d_min_dist, int32_t* d_idx, float* d_min2_dist, int32_t* d_tent, int32_t* d_count, void* d_scratch,
                                 void* stream) {
+    AFF_DEVICE(ctx);
     if (!ctx || !d_desc1 || !d_desc2 || !d_min_dist || !d_idx || !d_min2_dist || !d_tent || !d_count || !d_scratch || n1 < 0 || n2 < 1)
         return aff_fail(ctx, AFFNET_ERR_INVALID, "match_snn: bad argument");
     if (dim != 128) return aff_fail(ctx, AFFNET_ERR_INVALID, "match_snn: descriptor length %d (only 128 is built)", dim);
@@ -156,6 +157,7 @@ extern "C" int affnet_match_snn(affnet_ctx* ctx, const float* d_desc1, int n1, c
 // Full distance matrix (Losses.py:5-13) for callers that want it: d_out (n1, n2).
 extern "C" int affnet_distance_matrix(affnet_ctx* ctx, const float* d_desc1, int n1, const float* d_desc2, int n2, int dim, float* d_out,
                                       void* d_scratch, void* stream) {
+    AFF_DEVICE(ctx);
     if (!ctx || !d_desc1 || !d_desc2 || !d_out || !d_scratch || n1 < 0 || n2 < 0) return aff_fail(ctx, AFFNET_ERR_INVALID, "distance_matrix: bad argument");
     if (dim != 128) return aff_fail(ctx, AFFNET_ERR_INVALID, "distance_matrix: descriptor length %d (only 128 is built)", dim);
     if (n1 == 0 || n2 == 0) return AFFNET_OK;
@@ -201,6 +203,7 @@ __global__ void reproject_lafs_kernel(const float* __restrict__ lafs, int n, Hom
 }
 
 extern "C" int affnet_reproject_lafs(affnet_ctx* ctx, const float* d_lafs, int n, const float* h_H, float* d_out, void* stream) {
+    AFF_DEVICE(ctx);
     if (!ctx || !d_lafs || !h_H || !d_out || n < 0) return aff_fail(ctx, AFFNET_ERR_INVALID, "reproject_lafs: bad argument");
     if (n == 0) return AFFNET_OK;
     Hom H;
@@ -234,6 +237,7 @@ __global__ void centre_nn_kernel(const float* __restrict__ q, int nq, const floa
 
 extern "C" int affnet_centre_nn(affnet_ctx* ctx, const float* d_query_lafs, int nq, const float* d_ref_lafs, int nr, float* d_min_dist,
                                 int32_t* d_idx, void* stream) {
+    AFF_DEVICE(ctx);
     if (!ctx || !d_query_lafs || !d_ref_lafs || !d_min_dist || !d_idx || nq < 0 || nr < 1)
         return aff_fail(ctx, AFFNET_ERR_INVALID, "centre_nn: bad argument");
     if (nq == 0) return AFFNET_OK;

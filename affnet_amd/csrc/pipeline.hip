@@ -27,6 +27,7 @@ extern "C" int affnet_profile_enable(affnet_ctx* ctx, int on) {
 }
 
 extern "C" int affnet_profile_read(affnet_ctx* ctx, double sum_ms[AFFNET_PROFILE_STAGES], int32_t* n_calls) {
+    AFF_DEVICE(ctx);
     if (!ctx || !sum_ms || !n_calls) return AFFNET_ERR_INVALID;
     for (int s = 0; s < AFFNET_PROFILE_STAGES; ++s) sum_ms[s] = 0.0;
     *n_calls = ctx->prof_calls;
@@ -60,6 +61,7 @@ int aff_detect_impl(affnet_ctx* ctx, const float* d_responses, float* d_resp, fl
 // every level and hands over the response pyramid; candidates go to the context's internal list for
 // affnet_describe_detected.
 extern "C" int affnet_detect_image_responses(affnet_ctx* ctx, const float* d_responses, void* stream) {
+    AFF_DEVICE(ctx);
     if (!ctx || !ctx->ws || !d_responses) return aff_fail(ctx, AFFNET_ERR_INVALID, "detect_image_responses: context not bound or null responses");
     hipStream_t st = (hipStream_t)stream;
     aff_prof_mark(ctx, 0, st);
@@ -71,6 +73,7 @@ extern "C" int affnet_detect_image_responses(affnet_ctx* ctx, const float* d_res
 }
 
 extern "C" int affnet_detect_image(affnet_ctx* ctx, const float* d_img, void* stream) {
+    AFF_DEVICE(ctx);
     if (!ctx || !ctx->ws || !d_img) return aff_fail(ctx, AFFNET_ERR_INVALID, "detect_image: context not bound or null image");
     hipStream_t st = (hipStream_t)stream;
     aff_prof_mark(ctx, 0, st);
@@ -85,6 +88,7 @@ extern "C" int affnet_detect_image(affnet_ctx* ctx, const float* d_img, void* st
 
 extern "C" int affnet_describe_detected(affnet_ctx* ctx, const affnet_nets* nets, int do_ori, float* d_lafs_px, float* d_resp,
                                         int32_t* d_ids, float* d_desc, int32_t* d_count, void* stream) {
+    AFF_DEVICE(ctx);
     if (!ctx || !ctx->ws || !nets || !d_lafs_px || !d_resp || !d_ids || !d_count)
         return aff_fail(ctx, AFFNET_ERR_INVALID, "describe_detected: context not bound or null argument");
     if (do_ori && !nets->d_orinet && !nets->h_orientation_window)
@@ -168,6 +172,7 @@ extern "C" int affnet_describe_detected(affnet_ctx* ctx, const affnet_nets* nets
 
 extern "C" int affnet_extract_features(affnet_ctx* ctx, const affnet_nets* nets, const float* d_img, int do_ori, float* d_lafs_px,
                                        float* d_resp, int32_t* d_ids, float* d_desc, int32_t* d_count, void* stream) {
+    AFF_DEVICE(ctx);
     int rc = affnet_detect_image(ctx, d_img, stream);
     if (rc) return rc;
     return affnet_describe_detected(ctx, nets, do_ori, d_lafs_px, d_resp, d_ids, d_desc, d_count, stream);

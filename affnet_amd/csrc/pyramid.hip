@@ -162,8 +162,19 @@ static int blur_dispatch(affnet_ctx* ctx, const float* in, float* out, float* de
         case 17: launch_blur<17>(in, out, dec, h, w, batch, in_stride, out_stride, taps, st); break;
         case 19: launch_blur<19>(in, out, dec, h, w, batch, in_stride, out_stride, taps, st); break;
         case 21: launch_blur<21>(in, out, dec, h, w, batch, in_stride, out_stride, taps, st); break;
+        case 23: launch_blur<23>(in, out, dec, h, w, batch, in_stride, out_stride, taps, st); break;
+        case 25: launch_blur<25>(in, out, dec, h, w, batch, in_stride, out_stride, taps, st); break;
+        case 27: launch_blur<27>(in, out, dec, h, w, batch, in_stride, out_stride, taps, st); break;
+        case 29: launch_blur<29>(in, out, dec, h, w, batch, in_stride, out_stride, taps, st); break;
+        case 31: launch_blur<31>(in, out, dec, h, w, batch, in_stride, out_stride, taps, st); break;
+        case 33: launch_blur<33>(in, out, dec, h, w, batch, in_stride, out_stride, taps, st); break;
+        case 35: launch_blur<35>(in, out, dec, h, w, batch, in_stride, out_stride, taps, st); break;
+        case 37: launch_blur<37>(in, out, dec, h, w, batch, in_stride, out_stride, taps, st); break;
+        case 1: {   // a 1 x 1 "Gaussian" (sigma < 1/6): conv2d with the single tap w = 1 -> fma(x, 1, 0) = x
+            launch_blur<1>(in, out, dec, h, w, batch, in_stride, out_stride, taps, st); break;
+        }
         default:
-            return aff_fail(ctx, AFFNET_ERR_INVALID, "unsupported Gaussian size %d (supported: odd 3..21)", k);
+            return aff_fail(ctx, AFFNET_ERR_INVALID, "unsupported Gaussian size %d (supported: odd 1..37)", k);
     }
     AFF_LAUNCH_CHECK(ctx);
     return AFFNET_OK;
@@ -171,11 +182,13 @@ static int blur_dispatch(affnet_ctx* ctx, const float* in, float* out, float* de
 
 extern "C" int affnet_gauss_blur(affnet_ctx* ctx, const float* d_in, float* d_out, int h, int w, const float* h_taps, int k,
                                  void* stream) {
+    AFF_DEVICE(ctx);
     if (!ctx || !d_in || !d_out || !h_taps || h < 1 || w < 1) return aff_fail(ctx, AFFNET_ERR_INVALID, "gauss_blur: bad argument");
     return blur_dispatch(ctx, d_in, d_out, nullptr, h, w, h_taps, k, (hipStream_t)stream);
 }
 
 extern "C" int affnet_pyramid_build(affnet_ctx* ctx, const float* d_img, void* stream) {
+    AFF_DEVICE(ctx);
     if (!ctx || !ctx->ws || !d_img) return aff_fail(ctx, AFFNET_ERR_INVALID, "pyramid_build: context not bound or null image");
     hipStream_t st = (hipStream_t)stream;
     const affnet_config& c = ctx->cfg;
@@ -198,8 +211,9 @@ extern "C" int affnet_pyramid_build(affnet_ctx* ctx, const float* d_img, void* s
         for (int l = 1; l < L; ++l) {
             float* dec = nullptr;
             if (l == dec_level && o + 1 < c.n_octaves) dec = ctx->pyr + ctx->oct[o + 1].pyr_off;
-            int rc = blur_dispatch(ctx, base + (l - 1) * lvl, base + l * lvl, dec, g.h, g.w, c.level_blur[l], c.level_blur_taps[l], st,
-                                   ctx->B, ctx->pyr_stride, ctx->pyr_stride);
+            const bool own = (o == 0 && c.level_blur0_taps[1] > 0);      // octave 0 with its own blur sequence (init_sigma <= 0.5)
+            int rc = blur_dispatch(ctx, base + (l - 1) * lvl, base + l * lvl, dec, g.h, g.w, own ? c.level_blur0[l] : c.level_blur[l],
+                                   own ? c.level_blur0_taps[l] : c.level_blur_taps[l], st, ctx->B, ctx->pyr_stride, ctx->pyr_stride);
             if (rc) return rc;
         }
     }

@@ -64,10 +64,14 @@ class Context(object):
             pyr.append(levels)
         return pyr
 
-    def read_counts(self):
+    def read_counts(self, allow_empty=False):
+        """The one host read-back: [rows after detection, rows after the shape filter, overflow flag, raw maxima] summed over
+        the batch.  Raises AffnetHipError on a capacity overflow (results would be truncated) and AffnetEmptyError when no
+        image produced a detection (allow_empty=True: return the zeros instead - batches may legitimately hold flat images)."""
         out = (C.c_int32 * 4)()
         rc = lib.affnet_read_counts(self.handle, C.byref(out), stream_of(self.device))
-        check(rc, self.handle, "affnet_read_counts")
+        if not (allow_empty and rc == _lib.ERR_EMPTY):
+            check(rc, self.handle, "affnet_read_counts")
         return list(out)
 
     def __del__(self):

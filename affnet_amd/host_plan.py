@@ -35,7 +35,7 @@ class PyramidPlan(object):
             self.first_blur_sigma = float(np.sqrt(init_sigma ** 2 - cur ** 2))
             cur = init_sigma
         self.sizes, self.sigmas, self.pix_dists = [], [], []
-        self.blur_sigmas = None
+        self.blur_sigmas_per_octave = []
         h, w, pix = self.height, self.width, 1.0
         while True:
             lev, blur = [cur], []
@@ -43,8 +43,9 @@ class PyramidPlan(object):
                 blur.append(float(cur * np.sqrt(step * step - 1.0)))
                 cur *= step
                 lev.append(cur)
-            if self.blur_sigmas is None:
-                self.blur_sigmas = blur  # identical for every octave: curSigma restarts at init_sigma
+            # curSigma restarts at init_sigma after every octave (HandCraftedModules.py:49): octaves >= 1 all share one blur
+            # sequence; octave 0 has the same one unless init_sigma <= 0.5 (it then starts at curSigma = 0.5, :25-31)
+            self.blur_sigmas_per_octave.append(blur)
             self.sizes.append((h, w))
             self.sigmas.append(lev)
             self.pix_dists.append([pix] * len(lev))
@@ -55,6 +56,7 @@ class PyramidPlan(object):
                 break
             h, w = nh, nw
         self.n_octaves = len(self.sizes)
+        self.blur_sigmas = self.blur_sigmas_per_octave[0]
         self.levels_per_octave = n_levels + 2
 
     def fill_config(self, mr_size, threshold, num_features, num_prefilter, max_keep=16384, raw_div=4, batch=1, baum_iters=0):
@@ -71,16 +73,24 @@ class PyramidPlan(object):
                 c.level_sigma_px[o][l] = float(np.array(s) * np.array(self.pix_dists[o][l]))
         if self.first_blur_sigma is not None:
             t = gaussian_taps(self.first_blur_sigma)
+            if t.shape[0] > _lib.MAX_TAPS:
+                raise ValueError("initial Gaussian of %d taps not supported (max %d)" % (t.shape[0], _lib.MAX_TAPS))
             c.first_blur_taps = t.shape[0]
-            for i, v in enumerate(t.reshape(-1)):
-                c.first_blur[i] = v
-        for l, s in enumerate(self.blur_sigmas, start=1):
-            t = gaussian_taps(s)
-            if t.shape[0] > 21:
-                raise ValueError("Gaussian of %d taps not supported by the blur kernel (max 21)" % t.shape[0])
-            c.level_blur_taps[l] = t.shape[0]
-            for i, v in enumerate(t.reshape(-1)):
-                c.level_blur[l][i] = v
+            flat = t.reshape(-1)
+            c.first_blur[:flat.size] = flat.tolist()
+        def put(sigmas, taps_field, table_field):
+            for l, s in enumerate(sigmas, start=1):
+                t = gaussian_taps(s)
+                if t.shape[0] > _lib.MAX_TAPS:
+                    raise ValueError("Gaussian of %d taps not supported by the blur kernel (max %d)" % (t.shape[0], _lib.MAX_TAPS))
+                taps_field[l] = t.shape[0]
+                flat = t.reshape(-1)
+                table_field[l][:flat.size] = flat.tolist()
+
+        later = self.blur_sigmas_per_octave[1] if self.n_octaves > 1 else self.blur_sigmas_per_octave[0]
+        put(later, c.level_blur_taps, c.level_blur)
+        if self.blur_sigmas_per_octave[0] != later:          # init_sigma <= 0.5: octave 0 blurs with its own kernels
+            put(self.blur_sigmas_per_octave[0], c.level_blur0_taps, c.level_blur0)
         c.mr_size, c.threshold = float(mr_size), float(threshold)
         c.num_features, c.num_prefilter = int(num_features), int(num_prefilter)
         c.max_raw_per_octave_div, c.max_keep = int(raw_div), int(max_keep)

@@ -1,27 +1,36 @@
 #!/usr/bin/env python
 """Benchmark of the hot path on MI355X (see the contract in DESIGN.md "Measurement").
 
-    python bench.py --gpus 1 --steps 3 --warmup 1
+    python bench.py                                   # N = 1, BASELINE.json configs[2] (the metric's configuration)
+    python bench.py --gpus 8                          # self-spawns 8 ranks (one per GPU, RCCL), prints ONE JSON line
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W        # same, launched by torchrun (RANK / LOCAL_RANK / WORLD_SIZE from the env)
+    python bench.py --config2                         # BASELINE configs[1]: single-image latency (graf img1, 2000 kp, H2D included)
+    python bench.py --config5                         # BASELINE configs[4]: 3840x2160, 8000 kp
+    python bench.py --include-h2d                     # headline loop with every step's images uploaded on a copy stream
 
 A "step" = one pass of the whole hot path (pyramid -> Hessian/NMS detector -> AffNet -> filter ->
 OriNet -> level select -> HardNet) over one batch of 64 synthetic 1024x768 images, 2000 keypoints
 each (BASELINE.json configs[2], the configuration the metric is quoted on), per rank (weak scaling),
-images resident in HBM before the timed region, processed as 4 fused library calls of 16 images (every
-kernel launch covers 16 images), followed for N > 1 by the all_gather of the padded
-(count, LAFs, responses, descriptors) records.  value = keypoints returned by all ranks / max-over-ranks time.
+images resident in HBM before the timed region, processed as 2 fused library calls of 32 images (every
+kernel launch covers 32 images), followed for N > 1 by the gather of the padded
+(count, LAFs, responses, descriptors) records (all_gather, or --gather rank0).  value = keypoints returned by
+all ranks / max-over-ranks time.
 
-roofline   : dominant kernel = fused HardNet trunk (cnn32_trunk_kernel<2>, fp32 MFMA).  achieved =
-             algorithmic FLOPs per launch / mean launch duration measured with HIP events around that
-             launch on its own stream inside the timed region (affnet_profile_*).
-cpu_baseline: the CPU oracle (port of the reference, same torch CPU operators) on this host's cores
-             on a bounded sample of the same workload (rank 0, N == 1 only).
+roofline           : dominant kernel = fused HardNet trunk (cnn32_trunk_kernel<2>, fp32 MFMA).  achieved = algorithmic FLOPs
+                     per launch / mean launch duration measured with HIP events around that launch on its own stream inside
+                     the timed region (affnet_profile_*).
+secondary_rooflines: the HBM-bound scale-space / sampler kernels: algorithmic bytes / HIP-event time, fraction of 8 TB/s.
+cpu_baseline       : the CPU oracle (port of the reference, same torch CPU operators) on this host's cores on a bounded
+                     sample of the same workload (rank 0, N == 1 only): thread-count sweep, then median of 5 images.
+parity_check       : the GPU rows of the bench's own batched launches compared with the oracle outputs of the same seeds.
 """
 import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,8 +44,11 @@ H, W, NKP, BATCH = 768, 1024, 2000, 64
 FLOP_AFF, FLOP_ORI, FLOP_HARD = 19193856.0, 19316736.0, 78184448.0
 FLOP_HARD_HEAD = 2.0 * 8192 * 128
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
+PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; ~6.3 TB/s achievable)
+GRAF = os.path.join(ROOT, "tests", "golden", "graf_img1.png")
 
 
+# ----------------------------------------------------------------------------------------------------------------------
 def pmc_traffic(images_per_launch):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
     in separate passes, tools/gpu_full.sh + tools/pmc_traffic.py; counters cannot be read from inside this process)."""
@@ -45,37 +57,159 @@ def pmc_traffic(images_per_launch):
     if not files:
         return None, None
     d = json.load(open(files[-1]))
-    k = d["kernels"].get("void cnn32_trunk_kernel<2, 8>")
+    k = d["kernels"].get("void cnn32_trunk_kernel<2, 8, false>") or d["kernels"].get("void cnn32_trunk_kernel<2, 8>")
     if not k:
         return None, None
     scale = images_per_launch / float(d["images_per_launch"])
-    note = ("%s: 2 x FETCH_SIZE (gfx950 correction for wide reads; the sampler's narrow gathers are uncalibrated, raw = %.3g B) "
-            "+ WRITE_SIZE, scaled to %d images per launch" % (os.path.basename(files[-1]), k["fetch_bytes_raw"] * scale, images_per_launch))
+    note = "%s: %s; scaled to %d images per launch" % (os.path.basename(files[-1]), d.get("correction", "2 x FETCH_SIZE + WRITE_SIZE"),
+                                                     images_per_launch)
     return k["hbm_bytes"] * scale, note
 
 
-def cpu_baseline(n_timed=2):
+def host_threads():
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or avail
+    except Exception:
+        phys = avail
+    return avail, min(phys, avail)
+
+
+def cpu_baseline(n_timed=5, n_keep=2):
+    """the oracle harness on this host's cores, same inputs as the GPU run: sweep the intra-op thread
+    count on one image (128 SMT threads lose to 32-64 on the GPU box: oversubscribed small convolutions), then 1 warm-up +
+    n_timed images at the best setting, median.  Returns (record, oracle outputs of the first n_keep timed images)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import affnet_oracle as orc
-    # torch's default intra-op thread count (respects the container's CPU affinity / quota)
     sd = {k: torch.load(os.path.join(ROOT, "pretrained", k + ".pth"), map_location="cpu", weights_only=False)["state_dict"]
           for k in ("AffNet", "OriNet")}
     hard = orc.synthetic_hardnet_state(0)
-    kp, t = 0, 0.0
-    for i in range(n_timed + 1):
-        x = orc.synthetic_image(H, W, i)
+
+    def one(seed):
+        x = orc.synthetic_image(H, W, seed)
         ex = orc.OracleExtractor(mrSize=5.192, num_features=NKP, border=5, num_Baum_iters=1, affnet_sd=sd["AffNet"],
                                  orinet_sd=sd["OriNet"], reproduce_wasted_extraction=True)
         t0 = time.perf_counter()
         L, r, P, D = orc.describe(x, ex, hard, do_ori=True, ps=32)
-        dt = time.perf_counter() - t0
-        if i > 0:                       # first image = warm-up
-            kp += L.shape[0]
-            t += dt
-    return {"value": kp / t, "unit": "keypoints/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": "%d synthetic 1024x768 images x 2000 kp (seeds 1..%d) after 1 warm-up, %.1f s of CPU work; "
-                      "oracle/affnet_oracle.py = the reference's torch-CPU operator sequence incl. its discarded extra extraction"
-                      % (n_timed, n_timed, t)}
+        return time.perf_counter() - t0, {"keys": ex.keys.numpy().copy(), "LAFs": L.numpy().copy(), "resp": r.numpy().copy(),
+                                          "desc": D.numpy().copy()}
+
+    avail, phys = host_threads()
+    default_threads = torch.get_num_threads()
+    cand = sorted({t for t in (8, 16, 32, 64, phys, avail) if 1 <= t <= avail})
+    one(0)                                              # warm-up (allocator, oneDNN primitive caches)
+    sweep = {}
+    for t in cand:
+        torch.set_num_threads(t)
+        sweep[t] = one(0)[0]
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    one(0)                                              # warm-up at the chosen setting
+    times, kps, kept = [], [], []
+    for i in range(1, n_timed + 1):
+        dt, out = one(i)
+        times.append(dt)
+        kps.append(out["LAFs"].shape[0])
+        if len(kept) < n_keep:
+            kept.append((i, out))
+    torch.set_num_threads(default_threads)
+    order = sorted(range(n_timed), key=lambda i: times[i])
+    med = order[n_timed // 2]
+    par = torch.__config__.parallel_info().split("\n")
+    rec = {"value": kps[med] / times[med], "unit": "keypoints/s", "cores": best, "kind": "port",
+           "threads_used": best, "threads_available": avail, "physical_cores": phys,
+           "thread_sweep_s_per_image": {str(k): round(v, 3) for k, v in sweep.items()},
+           "seconds_per_image": [round(t, 3) for t in times], "spread": (max(times) - min(times)) / times[med],
+           "parallel_info": "; ".join(l.strip() for l in par if "thread" in l.lower() or "OpenMP" in l or "MKL" in l)[:300],
+           "sample": "median of %d synthetic %dx%d images x %d kp (seeds 1..%d) after a thread-count sweep on seed 0 and 1 warm-up, "
+                     "%.1f s of timed CPU work; oracle/affnet_oracle.py = the reference's torch-CPU operator sequence incl. its "
+                     "discarded extra extraction (SparseImgRepresenter.py:178-179)" % (n_timed, W, H, NKP, n_timed, sum(times))}
+    return rec, kept
+
+
+def parity_check(kept, fetch):
+    """GPU rows of the benchmark's own batched launches vs the oracle outputs of the same seeds (north_star: LAFs and
+    descriptors within 1e-3).  fetch(seed) -> dict(ids, LAFs, resp, desc) numpy arrays of that image from the LAST timed step."""
+    import numpy as np
+    key = lambda a: a[:, 0].astype(np.int64) * (1 << 40) + a[:, 1].astype(np.int64) * (1 << 32) + a[:, 2].astype(np.int64)
+    tot = {"images": 0, "seeds": [], "keypoints": 0, "matched": 0, "laf_max_px": 0.0, "laf_rows_within_1e-3": 0, "desc_max": 0.0,
+           "desc_rows_within_1e-3": 0, "responses_equal": True, "same_row_order": True}
+    for seed, want in kept:
+        got = fetch(seed)
+        kg, kw = key(got["ids"]), key(want["keys"])
+        pos = {k: i for i, k in enumerate(kw)}
+        gi = np.array([i for i, k in enumerate(kg) if k in pos], dtype=np.int64)
+        wi = np.array([pos[kg[i]] for i in gi], dtype=np.int64)
+        dl = np.abs(got["LAFs"][gi] - want["LAFs"][wi]).reshape(len(gi), -1).max(axis=1)
+        dd = np.abs(got["desc"][gi] - want["desc"][wi]).max(axis=1)
+        tot["images"] += 1
+        tot["seeds"].append(seed)
+        tot["keypoints"] += len(kw)
+        tot["matched"] += len(gi)
+        tot["laf_max_px"] = max(tot["laf_max_px"], float(dl.max()))
+        tot["laf_rows_within_1e-3"] += int((dl < 1e-3).sum())
+        tot["desc_max"] = max(tot["desc_max"], float(dd.max()))
+        tot["desc_rows_within_1e-3"] += int((dd < 1e-3).sum())
+        tot["responses_equal"] &= bool(np.array_equal(got["resp"][gi], want["resp"][wi]))
+        tot["same_row_order"] &= bool(len(gi) == len(kw) and np.array_equal(gi, wi))
+    tot["match_rate"] = tot["matched"] / max(tot["keypoints"], 1)
+    tot["pass"] = bool(tot["match_rate"] >= 0.995 and tot["laf_rows_within_1e-3"] >= 0.995 * tot["matched"] and
+                       tot["desc_rows_within_1e-3"] >= 0.995 * tot["matched"] and tot["responses_equal"])
+    tot["reference"] = "oracle/affnet_oracle.py (bit-identical to the unmodified reference, oracle/check_restatement.py) on this host"
+    return tot
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this script (one per device), relay their output,
+    fail loudly if fewer devices exist or any rank fails.  Rank 0 prints the one JSON line."""
+    n = args.gpus
+    one_device = bool(os.environ.get("AFFNET_BENCH_ONE_DEVICE"))
+    if not args.dry_run:
+        have = torch.cuda.device_count()
+        if have < n and not one_device:
+            sys.stderr.write("bench.py: --gpus %d needs %d visible GPUs, found %d (set AFFNET_BENCH_ONE_DEVICE=1 only for a "
+                             "single-device dry run of the multi-rank path)\n" % (n, n, have))
+            return 2
+    env = dict(os.environ, WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               AFFNET_BENCH_SPAWNED="1")
+    procs = []
+    for r in range(n):
+        e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=e))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for q in pending:              # one rank failed: the others would hang in the next collective
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    if rc != 0:
+        sys.stderr.write("bench.py: a rank exited with code %d - no result\n" % rc)
+    return rc
 
 
 def main():
@@ -91,11 +225,87 @@ def main():
     ap.add_argument("--pipeline", type=int, default=int(os.environ.get("AFFNET_BENCH_PIPELINE", "0")),
                     help="1 (with --streams 1): pyramid + detector of chunk i+1 run on a second stream next to the CNN stages of "
                          "chunk i (two contexts alternate); the CNN kernels stay serialised on one stream")
+    ap.add_argument("--gather", choices=("all", "rank0"), default="all",
+                    help="N > 1 exchange of the padded records: all_gather (default) or gather to rank 0 (7/8 less xGMI traffic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the stand-alone sampler timing behind secondary_rooflines")
+    ap.add_argument("--include-h2d", action="store_true",
+                    help="every step's images come from pinned host memory: uploaded on a copy stream into a double-buffered device "
+                         "buffer while the previous step computes (a separately labelled, PCIe-inclusive line - never the headline value)")
+    ap.add_argument("--config2", action="store_true",
+                    help="BASELINE.json configs[1]: latency of ONE image (tests/golden/graf_img1.png = test-graf/img1.png, 2000 kp, "
+                         "B = 1), pinned host -> device upload included; cold (context creation) and warm")
     ap.add_argument("--config5", action="store_true",
                     help="BASELINE.json configs[4] instead of the headline configs[2]: 3840x2160 images, 8000 kp each (deep pyramid stress); "
                          "batch / chunk default to 8 / 8")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: ranks rendezvous (backend from AFFNET_BENCH_BACKEND, default gloo here), exchange fake records and "
+                         "print the JSON skeleton - exercises the launch / world-size / gather bookkeeping on a CPU host")
     args = ap.parse_args()
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_spawn(args))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and not os.environ.get("AFFNET_BENCH_SELF_GATHER"):
+        sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: refusing to report a run whose n_gpus would be wrong\n" % (args.gpus, world))
+        sys.exit(2)
+    if args.config2:
+        return config2_latency(args)
+    run(args, world)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def config2_latency(args):
+    """BASELINE configs[1] (hesaffnet.py:35-60 on test-graf/img1.png, 2000 kp): what a caller of the single-image API
+    waits for.  Cold = first call of a fresh process state (context + workspace creation, weight packing + upload, module
+    load); warm = median of the following calls; both include the pinned-host -> device upload of the image."""
+    import numpy as np
+    from PIL import Image
+    import affnet_amd
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    img = np.mean(np.array(Image.open(GRAF).convert("RGB")), axis=2).astype(np.float32)          # hesaffnet.py:35-36
+    host = torch.from_numpy(img).view(1, 1, img.shape[0], img.shape[1]).pin_memory()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    A = affnet_amd.AffNetFast(PS=32)
+    A.load_state_dict(torch.load(os.path.join(ROOT, "pretrained", "AffNet.pth"), map_location="cpu", weights_only=False)["state_dict"])
+    O = affnet_amd.OriNetFast(PS=32)
+    O.load_state_dict(torch.load(os.path.join(ROOT, "pretrained", "OriNet.pth"), map_location="cpu", weights_only=False)["state_dict"])
+    Hn = affnet_amd.HardNet()
+    Hn.load_state_dict(affnet_amd.synthetic_hardnet_state(0))
+    A, O, Hn = A.to(dev), O.to(dev), Hn.to(dev)
+    det = affnet_amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=2000, border=5, num_Baum_iters=1, AffNet=A, OriNet=O).to(dev)
+    x = host.to(dev, non_blocking=True)
+    r = det.run(x, do_ori=True, desc=Hn)
+    torch.cuda.synchronize()
+    cold = time.perf_counter() - t0
+    n = int(r["LAFs"].shape[0])
+    lat = []
+    for _ in range(max(args.steps, 5) * 4):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        x = host.to(dev, non_blocking=True)
+        r = det.run(x, do_ori=True, desc=Hn)            # includes the one count read-back (= a stream sync)
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t0)
+    lat.sort()
+    warm = lat[len(lat) // 2]
+    out = {"metric": "latency per image (hesaffnet.py test-graf/img1.png, 2000 kp, detect+AffNet+OriNet+HardNet, B=1, H2D included)",
+           "value": warm * 1e3, "unit": "ms", "n_gpus": 1, "steps": len(lat), "warmup": 1, "ms_per_step": warm * 1e3,
+           "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "tests/golden/graf_img1.png (byte copy of test-graf/img1.png)",
+           "config": {"workload": "BASELINE.json configs[1]: hesaffnet.py test-graf/img1.png 2000 kp, full path on 1 MI355X, single-image API "
+                                  "(ScaleSpaceAffinePatchExtractor.run), %dx%d, pinned host image uploaded inside the timed call" % (img.shape[1], img.shape[0]),
+                      "keypoints": n},
+           "cold_ms": cold * 1e3, "warm_ms_min": lat[0] * 1e3, "warm_ms_p90": lat[int(0.9 * len(lat))] * 1e3,
+           "keypoints_per_s_warm": n / warm,
+           "note": "cold = weight load + BN folding + packing + upload, context / workspace creation, HIP module load and the first call"}
+    print(json.dumps(out), flush=True)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+def run(args, world):
     global H, W, NKP
     if args.config5:
         H, W, NKP = 2160, 3840, 8000
@@ -103,27 +313,45 @@ def main():
             args.batch = 8
         if args.chunk == 32:
             args.chunk = 8
-
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch.distributed as dist
-    if os.environ.get("AFFNET_BENCH_ONE_DEVICE"):
+    DRY = args.dry_run
+    one_device = bool(os.environ.get("AFFNET_BENCH_ONE_DEVICE"))
+    if one_device:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    # AFFNET_BENCH_SELF_GATHER=1 (single process): a 1-rank RCCL group, so that the stream-ordered all-gather of the N > 1
-    # path runs on a 1-GPU box (tools/gpu_dist_dryrun.sh); AFFNET_BENCH_BACKEND=gloo + AFFNET_BENCH_ONE_DEVICE=1: 2 ranks on one GPU
+    # AFFNET_BENCH_SELF_GATHER=1 (single process): a 1-rank RCCL group, so that the stream-ordered gather of the N > 1
+    # path runs on a 1-GPU box (tools/gpu_dist_dryrun.sh); AFFNET_BENCH_BACKEND=gloo + AFFNET_BENCH_ONE_DEVICE=1: N ranks on one GPU
     SELF = world == 1 and bool(os.environ.get("AFFNET_BENCH_SELF_GATHER"))
     DIST = world > 1 or SELF
+    backend = os.environ.get("AFFNET_BENCH_BACKEND", "gloo" if DRY else "nccl")
+    if not DRY:
+        if local_rank >= torch.cuda.device_count():
+            sys.stderr.write("bench.py: rank %d needs device %d but only %d are visible\n" % (rank, local_rank, torch.cuda.device_count()))
+            sys.exit(2)
+        torch.cuda.set_device(local_rank)
+    dev = torch.device("cpu") if DRY else torch.device("cuda", local_rank)
     if DIST:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29541")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(os.environ.get("AFFNET_BENCH_BACKEND", "nccl"), rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
+        assert dist.get_world_size() == world == max(args.gpus, 1), "world size %d != --gpus %d" % (dist.get_world_size(), args.gpus)
+        # one DISTINCT device per rank (a mis-set LOCAL_RANK / HIP_VISIBLE_DEVICES would otherwise stack ranks on one GPU)
+        ident = "cpu-%d" % rank if DRY else "%s|%s" % (getattr(torch.cuda.get_device_properties(local_rank), "uuid", local_rank), local_rank)
+        idents = [None] * world
+        dist.all_gather_object(idents, ident)
+        if len(set(idents)) != world and not one_device:
+            sys.stderr.write("bench.py: %d ranks share devices %s - refusing (AFFNET_BENCH_ONE_DEVICE=1 allows it for dry runs)\n" % (world, idents))
+            sys.exit(2)
+    gather_dst = 0 if args.gather == "rank0" else None
+
+    from affnet_amd import sharded
+    if DRY:
+        return dry_run(args, world, rank, dist, sharded, DIST, gather_dst, backend)
 
     import affnet_amd
-    from affnet_amd import _lib, sharded
+    from affnet_amd import _lib
     from affnet_amd.synthetic import synthetic_image
 
     def load(name, cls):
@@ -138,8 +366,18 @@ def main():
     # global image i of a step lives on rank i % world (weak scaling: `batch` images per rank per step)
     seeds = [rank + world * j for j in range(args.batch)]
     CH = max(1, min(args.chunk, args.batch))
-    imgs = torch.cat([synthetic_image(H, W, s) for s in seeds], 0).to(dev)           # (batch,1,H,W) resident in HBM
-    chunks = [imgs[i:i + CH] for i in range(0, args.batch, CH)]
+    host_imgs = torch.cat([synthetic_image(H, W, s) for s in seeds], 0)
+    H2D = args.include_h2d
+    if H2D:
+        host_imgs = host_imgs.pin_memory()
+        dev_bufs = [torch.empty_like(host_imgs, device=dev) for _ in range(2)]      # double buffer: upload k+1 while k computes
+        copy_stream = torch.cuda.Stream(device=dev)
+        imgs = dev_bufs[0]
+    else:
+        imgs = host_imgs.to(dev)                                                       # (batch,1,H,W) resident in HBM
+    n_chunks = (args.batch + CH - 1) // CH
+    chunk_of = lambda buf: [buf[i:i + CH] for i in range(0, args.batch, CH)]
+    chunks = chunk_of(imgs)
     S = max(1, args.streams)
     PIPE = bool(args.pipeline) and S == 1
     if PIPE:
@@ -155,7 +393,7 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     det_stream = torch.cuda.Stream(device=dev) if PIPE else None
 
-    pending = [None]                   # finish() of the previous step's all-gather (overlaps with this step's compute)
+    pending = [None]                   # finish() of the previous step's gather (overlaps with this step's compute)
     # Steps are enqueued back to back; nothing inside the timed region waits on the host (the keypoint counts are
     # summed on the device and read once after the closing synchronize, the RCCL gather of step k is ordered behind
     # step k's kernels by stream semantics and waited for, on the stream, in step k+1).  A host-side sync + count
@@ -163,12 +401,34 @@ def main():
     LAZY = not PIPE and S == 1 and not (DIST and dist.get_backend() != "nccl")
     kp_dev = torch.zeros((), dtype=torch.int64, device=dev)
     inflight = []
+    step_no = [0]
+    upload_done = [None, None]         # events: buffer b holds the images of its step
+    compute_done = [None, None]        # events: the step that read buffer b has finished (buffer may be overwritten)
+
+    def upload(b):
+        with torch.cuda.stream(copy_stream):
+            if compute_done[b] is not None:
+                copy_stream.wait_event(compute_done[b])
+            dev_bufs[b].copy_(host_imgs, non_blocking=True)
+            upload_done[b] = torch.cuda.Event()
+            upload_done[b].record(copy_stream)
 
     def step():
-        results = [None] * len(chunks)
-        for ci, c in enumerate(chunks):
+        cur_chunks = chunks
+        b = step_no[0] & 1
+        if H2D:
+            if upload_done[b] is None:
+                upload(b)                                       # first step: nothing to overlap with
+            cur_chunks = chunk_of(dev_bufs[b])
+            for s in streams:
+                s.wait_event(upload_done[b])
+            upload_done[b] = None
+            upload(b ^ 1)                                       # next step's images travel while this step computes
+        results = [None] * len(cur_chunks)
+        for ci, c in enumerate(cur_chunks):
             with torch.cuda.stream(streams[0] if PIPE else streams[ci % S]):
                 results[ci] = dets[(ci % S, c.size(0))].enqueue(c, do_ori=True, desc=Hn, det_stream=det_stream, input_ready=False)
+        step_no[0] += 1
         if LAZY:
             with torch.cuda.stream(streams[0]):
                 if len(inflight) >= 2:
@@ -177,20 +437,25 @@ def main():
                 if DIST:
                     if pending[0] is not None:
                         pending[0]()                            # stream-side wait for the previous step's gather
-                    pending[0] = sharded.gather_features_async(sharded.pack_batched_records(results, NKP), args.batch * world, force=SELF)
+                    pending[0] = sharded.gather_features_async(sharded.pack_batched_records(results, NKP), args.batch * world, force=SELF,
+                                                               dst=gather_dst)
                 ev = torch.cuda.Event()
                 ev.record()
                 inflight.append(ev)
+                if H2D:
+                    compute_done[b] = ev
             return results
         for s in streams:
             s.synchronize()
         kp_dev.add_(sum(int(r["count"].sum().item()) for r in results))
+        if H2D:
+            compute_done[b] = None
         if DIST:
             if pending[0] is not None:
                 pending[0]()                                    # records of the previous step have arrived
             rec = sharded.pack_batched_records(results, NKP)
             torch.cuda.synchronize()
-            pending[0] = sharded.gather_features_async(rec, args.batch * world, force=SELF)
+            pending[0] = sharded.gather_features_async(rec, args.batch * world, force=SELF, dst=gather_dst)
         return results
 
     def drain():
@@ -216,17 +481,22 @@ def main():
     kp_dev.zero_()
     barrier()
     t0 = time.perf_counter()
+    last = None
     for _ in range(args.steps):
-        step()
+        last = step()
     drain()                            # every step's kernels and the last gather complete inside the timed region
     barrier()
     dt = time.perf_counter() - t0
     kp = int(kp_dev.item())
+    # a list that overflowed would have truncated the keypoint set the rate is computed on: fail instead of reporting it
+    for d in dets.values():
+        d._ctx.read_counts(allow_empty=True)
     # stage timings recorded by HIP events on the launch streams during the timed region
     sums, calls, call_imgs = [0.0] * 8, 0, 0
     for (_, nimg), d in dets.items():
         buf, n = (C.c_double * 8)(), C.c_int32(0)
         _lib.check(_lib.lib.affnet_profile_read(d._ctx.handle, C.byref(buf), C.byref(n)), d._ctx.handle, "profile_read")
+        _lib.check(_lib.lib.affnet_profile_enable(d._ctx.handle, 0), d._ctx.handle, "profile_enable")
         calls += n.value
         call_imgs += n.value * nimg
         sums = [a + b for a, b in zip(sums, list(buf))]
@@ -245,31 +515,181 @@ def main():
         flops_launch = kp_per_img * img_per_launch * (FLOP_HARD - FLOP_HARD_HEAD)
         achieved = flops_launch / (trunk_ms * 1e-3) / 1e12 if trunk_ms > 0 else 0.0
         traffic, traffic_note = pmc_traffic(img_per_launch)
+        cfg_idx = 4 if args.config5 else 2
+        metric = "keypoints/sec (detect+AffNet+OriNet+HardNet) per image, %d kp @%dx%d" % (NKP, W, H)
+        if H2D:
+            metric += " [PCIe-inclusive: images uploaded from pinned host memory every step]"
         out = {
-            "metric": "keypoints/sec (detect+AffNet+OriNet+HardNet) per image, %d kp @%dx%d" % (NKP, W, H),
+            "metric": metric,
             "value": kps / tmax, "unit": "keypoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": tmax / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[%d]: batch of %d synthetic %dx%d grayscale images per GPU per step, "
                                    "%d kp each, full path detect+AffNet+OriNet+HardNet; AffNet/OriNet shipped weights, "
-                                   "HardNet seeded synthetic weights (HardNet++.pth is a missing blob)" % (4 if args.config5 else 2, args.batch, W, H, NKP),
+                                   "HardNet seeded synthetic weights (HardNet++.pth is a missing blob)%s"
+                                   % (cfg_idx, args.batch, W, H, NKP,
+                                      " = BASELINE.json configs[3] (512-image stream, image-per-GPU over 8 GPUs) per step" if world == 8 and not args.config5 else ""),
                        "global_batch": args.batch * world, "keypoints_per_image": kp_per_img,
                        "images_per_launch": CH,
                        "streams_per_gpu": "1 CNN stream + 1 detector stream (2 contexts alternate)" if PIPE else S,
-                       "parallelism": "image-per-GPU x%d, all_gather of padded records" % world if world > 1 else "1 GPU"},
+                       "h2d": "every step uploads its images from pinned host memory on a copy stream (double-buffered)" if H2D
+                              else "images resident in HBM before the timed region",
+                       "parallelism": ("image-per-GPU x%d, %s of padded {int32 count, LAFs, responses, descriptors} records over RCCL"
+                                       % (world, "all_gather" if gather_dst is None else "gather to rank 0")) if world > 1 else "1 GPU"},
             "ms_per_image": tmax / (args.steps * args.batch) * 1e3,
             "stage_ms_per_image": dict(zip(names, [round(v, 4) for v in stage_ms])),
             "roofline": {"kernel": "cnn32_trunk_kernel<HardNet> (fp32 MFMA 16x16x4, fused sampler+norm+6 convs)", "bound": "mfma",
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": traffic, "traffic_source": traffic_note, "flops_per_launch": flops_launch, "launch_ms": trunk_ms,
                          "all_cnn_tflops": kp_per_img * (1.5 * FLOP_AFF + FLOP_ORI + FLOP_HARD) /
-                                           (max(stage_ms[2] + stage_ms[4] + stage_ms[6] + stage_ms[7], 1e-9) * 1e-3) / 1e12},
+                                           (max(stage_ms[2] + stage_ms[4] + stage_ms[6] + stage_ms[7], 1e-9) * 1e-3) / 1e12,
+                         "affnet_tflops": 1.5 * kp_per_img * FLOP_AFF / (max(stage_ms[2], 1e-9) * 1e-3) / 1e12,
+                         "orinet_tflops": kp_per_img * FLOP_ORI / (max(stage_ms[4], 1e-9) * 1e-3) / 1e12},
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
+        if not args.no_secondary:
+            out["secondary_rooflines"] = secondary_rooflines(dets, chunks, stage_ms, dev)
+        if world == 1 and not args.no_cpu_baseline and not args.config5:
+            base, kept = cpu_baseline()
+            out["cpu_baseline"] = base
+
+            def fetch(seed):                                         # image `seed` of the last timed step (rank 0, world 1: seed == index)
+                r = last[seed // CH]
+                b = seed % CH
+                n = int(r["count"].view(-1)[b].item())
+                g = lambda k: (r[k] if r["count"].numel() > 1 else r[k].unsqueeze(0))[b, :n].cpu().numpy()
+                return {"ids": g("ids"), "LAFs": g("LAFs"), "resp": g("responses"), "desc": g("descriptors")}
+            kept = [(s, w) for s, w in kept if s < args.batch]
+            if kept:
+                out["parity_check"] = parity_check(kept, fetch)
         print(json.dumps(out), flush=True)
     if DIST:
         dist.destroy_process_group()
+
+
+def secondary_rooflines(dets, chunks, stage_ms, dev):
+    """north_star: HBM GB/s of the scale-space / grid-sample kernels against chip peak.  Algorithmic bytes (SURVEY.md section
+    8d) / HIP-event time: pyramid and detector from the stage events of the timed region, the sampler from a stand-alone run
+    of affnet_pyr_grid_sample over 7000 patches per image (3000 detector candidates + 2 x 2000 level-selected final frames)."""
+    import numpy as np
+    from affnet_amd import _lib, engine
+    from affnet_amd._lib import lib, ptr, check
+    det = next(iter(dets.values()))
+    ctx = det._ctx
+    plan = ctx.plan
+    P0 = H * W
+    P = sum(h * w for h, w in plan.sizes)
+    L = plan.levels_per_octave
+    out = []
+    pyr_bytes = (P0 + (L - 1) * P + L * P) * 4.0            # read the image + L-1 levels, write L levels (decimated copies are part of P)
+    det_bytes = L * P * 4.0                                  # every level read once; responses never reach HBM
+    for name, bts, ms, note in (("blur2d_kernel<K> (pyramid build: %d launches per call, exact 2-D taps)" % (1 + (L - 1) * plan.n_octaves), pyr_bytes,
+                                 stage_ms[0], "VALU-bound by design: the bit-exact k x k tap order costs ~6x the MACs of a separable blur"),
+                                ("hessian_nms_kernel (+ level_resolve / select kernels = detector stage)", det_bytes, stage_ms[1],
+                                 "Hessian + 3-D NMS + centroid fused, responses stay on chip")):
+        gbs = bts / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out.append({"kernel": name, "bound": "hbm", "algorithmic_bytes_per_image": bts, "ms_per_image": ms, "achieved": gbs, "peak": PEAK_HBM_GBS,
+                    "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS, "note": note})
+    # stand-alone sampler on the pyramids of the chunk processed last
+    x = chunks[0]
+    if x.size(0) != ctx.batch:
+        return out
+    B, Pc, F = ctx.batch, ctx.cap_pre, ctx.cap_final
+    st = engine.stream_of(dev)
+    r = det.enqueue(x, do_ori=True, desc=None)              # leaves pyramid + final LAFs
+    lafs_px = (r["LAFs"] if B > 1 else r["LAFs"].unsqueeze(0)).contiguous()
+    cnt = r["count"]
+    d_resp = torch.empty(B, Pc, dtype=torch.float32, device=dev)
+    d_lafs = torch.empty(B, Pc, 2, 3, dtype=torch.float32, device=dev)
+    d_ids = torch.empty(B, Pc, 3, dtype=torch.int32, device=dev)
+    d_cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    check(lib.affnet_detect(ctx.handle, ptr(d_resp), ptr(d_lafs), ptr(d_ids), ptr(d_cnt), st), ctx.handle, "affnet_detect")
+    f_ids = torch.empty(B, F, 3, dtype=torch.int32, device=dev)
+    f_norm = torch.empty(B, F, 2, 3, dtype=torch.float32, device=dev)
+    check(lib.affnet_level_select(ctx.handle, ptr(lafs_px), ptr(cnt), F, 32, ptr(f_ids), ptr(f_norm), st), ctx.handle, "affnet_level_select")
+    out_c = torch.empty(B, Pc, 32, 32, dtype=torch.float32, device=dev)
+    out_f = torch.empty(B, F, 32, 32, dtype=torch.float32, device=dev)
+
+    def sample_all():
+        check(lib.affnet_pyr_grid_sample(ctx.handle, ptr(d_lafs), ptr(d_ids), ptr(d_cnt), Pc, 32, ptr(out_c), st), ctx.handle, "grid_sample")
+        for _ in range(2):
+            check(lib.affnet_pyr_grid_sample(ctx.handle, ptr(f_norm), ptr(f_ids), ptr(cnt), F, 32, ptr(out_f), st), ctx.handle, "grid_sample")
+    for _ in range(2):
+        sample_all()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 5
+    e0.record()
+    for _ in range(reps):
+        sample_all()
+    e1.record()
+    torch.cuda.synchronize()
+    ms_img = e0.elapsed_time(e1) / reps / B
+    # algorithmic bytes: 4096 B written per patch + the source footprint (bounding box of the sampled frame in level pixels, + 1 px
+    # for the bilinear neighbours) read once
+    sizes = np.array(plan.sizes, dtype=np.float64)
+
+    def footprint(lafs, ids, counts):
+        lafs, ids, counts = lafs.cpu().numpy().astype(np.float64), ids.cpu().numpy(), counts.cpu().numpy()
+        tot, n = 0.0, 0
+        for b in range(lafs.shape[0]):
+            k = int(counts[b])
+            o = np.clip(ids[b, :k, 0], 0, len(sizes) - 1)
+            h, w = sizes[o, 0], sizes[o, 1]
+            m = np.minimum(h, w)
+            A = lafs[b, :k, :, :2] * m[:, None, None] * (31.0 / 32.0)     # half extents in level px (grid = +-(ps-1)/ps)
+            hx = np.abs(A[:, 0, 0]) + np.abs(A[:, 0, 1])
+            hy = np.abs(A[:, 1, 0]) + np.abs(A[:, 1, 1])
+            tot += float((np.minimum(2 * hx + 2, w) * np.minimum(2 * hy + 2, h)).sum()) * 4.0
+            n += k
+        return tot, n
+    fc, nc = footprint(d_lafs, d_ids, d_cnt)
+    ff, nf = footprint(f_norm, f_ids, cnt)
+    patches = nc + 2 * nf
+    bts = (fc + 2 * ff + 4096.0 * patches) / B
+    gbs = bts / (ms_img * 1e-3) / 1e9
+    out.append({"kernel": "grid_sample_kernel stand-alone (affnet_pyr_grid_sample, PS 32, %.0f patches per image = C + 2N)" % (patches / B), "bound": "hbm",
+                "algorithmic_bytes_per_image": bts, "bytes_per_patch": bts * B / max(patches, 1), "ms_per_image": ms_img, "achieved": gbs,
+                "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": gbs / PEAK_HBM_GBS,
+                "note": "in the product path the sampler is fused into the CNN trunk prologues (no patch tensor in HBM); this is the "
+                        "stand-alone kernel the foreign-slot path and extract_patches_from_pyr use"})
+    return out
+
+
+def dry_run(args, world, rank, dist, sharded, DIST, gather_dst, backend):
+    """CPU bookkeeping run of the multi-rank path: rendezvous, world-size / device checks, round-robin seeds, record
+    packing and the gather, one JSON line from rank 0.  No kernels, no timing claims."""
+    n_cap = 5
+    got = None
+    for step in range(max(1, args.steps)):
+        seeds = [rank + world * j for j in range(args.batch)]
+        res = []
+        for s in seeds:
+            g = torch.Generator().manual_seed(1000 * step + s)
+            n = 1 + s % n_cap
+            r = {"count": torch.tensor([n], dtype=torch.int32), "LAFs": torch.zeros(n_cap, 2, 3), "responses": torch.zeros(n_cap),
+                 "descriptors": torch.zeros(n_cap, 128)}
+            r["LAFs"][:n] = torch.rand(n, 2, 3, generator=g)
+            r["responses"][:n] = float(s)
+            res.append(r)
+        rec = sharded.pack_records(res, n_cap, torch.device("cpu"))
+        got = sharded.gather_features_async(rec, args.batch * world, dst=gather_dst)() if DIST else rec
+    ok = True
+    if got is not None:
+        cnt = sharded.record_counts(got).tolist()
+        ok = cnt == [1 + i % n_cap for i in range(args.batch * world)]
+        ok &= all(float(sharded.unpack_record(got[i], n_cap)["responses"][0]) == float(i) for i in range(args.batch * world))
+    flag = torch.tensor([1.0 if ok else 0.0])
+    if DIST:
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "metric": "keypoints/sec (detect+AffNet+OriNet+HardNet) per image, %d kp @%dx%d" % (NKP, W, H),
+                          "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": "weak",
+                          "config": {"global_batch": args.batch * world, "gather": "all_gather" if gather_dst is None else "gather to rank 0",
+                                     "backend": backend},
+                          "records_in_global_order": bool(flag.item() == 1.0)}), flush=True)
+    if DIST:
+        dist.destroy_process_group()
+    if flag.item() != 1.0:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

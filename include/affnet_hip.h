@@ -17,7 +17,11 @@
  *  - all functions return AFFNET_OK (0) or a negative error code; affnet_last_error(ctx)
  *    returns a human readable message for the last failure on that context;
  *  - a context is not re-entrant: one thread / one stream at a time per context (the
- *    reference object is stateful in the same way, SparseImgRepresenter.py:55);
+ *    reference object is stateful in the same way, SparseImgRepresenter.py:55); DIFFERENT contexts may be
+ *    driven from different host threads / streams concurrently - the library keeps no process-global state;
+ *  - a context is bound to one HIP device (affnet_ctx_create): every entry point makes that device current for
+ *    the duration of the call and restores the caller's current device before returning, so a multi-GPU process
+ *    does not have to hipSetDevice around library calls.  Pointers must belong to the context's device;
  *  - batching: a context created with cfg->batch = B processes B equally sized images per call.  Every
  *    per-image array then has a leading batch dimension: d_img (B,H,W); row arrays (B,cap,...) with image
  *    b's rows at b*cap (cap = affnet_capacity_prefilter / _final as documented per entry point, or the
@@ -40,11 +44,13 @@ extern "C" {
 #define AFFNET_ERR_INVALID (-1)   /* bad argument / unsupported configuration          */
 #define AFFNET_ERR_HIP (-2)       /* a HIP runtime call failed (message has details)   */
 #define AFFNET_ERR_CAPACITY (-3)  /* a fixed-capacity device list overflowed           */
-#define AFFNET_ERR_EMPTY (-4)     /* no detections (reference: torch.cat([]) raises)   */
+#define AFFNET_ERR_EMPTY (-4)     /* no detections in any image of the call: returned by
+                                   * affnet_read_counts (reference: torch.cat([]) raises,
+                                   * SparseImgRepresenter.py:100)                       */
 
 #define AFFNET_MAX_OCTAVES 16
 #define AFFNET_MAX_LEVELS 8       /* n_levels + 2 <= 8                                 */
-#define AFFNET_MAX_TAPS 31        /* Gaussian kernels up to 31 x 31                    */
+#define AFFNET_MAX_TAPS 37        /* Gaussian kernels up to 37 x 37 (nlevels = 1: 35)  */
 
 /* Network kinds for the 32x32-patch CNNs. */
 #define AFFNET_NET_AFFNET 0       /* architectures.py:204-252 AffNetFast               */
@@ -72,6 +78,11 @@ typedef struct affnet_config {
     float first_blur[AFFNET_MAX_TAPS * AFFNET_MAX_TAPS];       /* k x k, row-major                    */
     int32_t level_blur_taps[AFFNET_MAX_LEVELS];                /* blur producing level l (l>=1)       */
     float level_blur[AFFNET_MAX_LEVELS][AFFNET_MAX_TAPS * AFFNET_MAX_TAPS];
+    /* Octave 0 only, when its blurs differ from the later octaves' (init_sigma <= 0.5: octave 0 starts at curSigma = 0.5,
+     * every later octave restarts at init_sigma, HandCraftedModules.py:25-31,49).  level_blur0_taps[1] == 0: octave 0 uses
+     * level_blur like every other octave (the usual case, init_sigma > 0.5). */
+    int32_t level_blur0_taps[AFFNET_MAX_LEVELS];
+    float level_blur0[AFFNET_MAX_LEVELS][AFFNET_MAX_TAPS * AFFNET_MAX_TAPS];
     float mr_size;                         /* mrSize (ctor kwarg, SparseImgRepresenter.py:19)          */
     float threshold;                       /* th; responses are clamp(resp - th, 0) (:77)              */
     int32_t num_features;                  /* N; <= 0: keep everything (th given => num = -1, :33-35)  */
@@ -100,6 +111,7 @@ const char* affnet_version(void);
  * CNN scratch).  Offsets into it are exposed so the host mirror can present the pyramid as
  * tensors (`scale_pyr`, SparseImgRepresenter.py:55). */
 size_t affnet_workspace_bytes(const affnet_ctx* ctx);
+/* d_workspace must be 256-byte aligned device memory of the context's device (checked with hipPointerGetAttributes). */
 int affnet_bind_workspace(affnet_ctx* ctx, void* d_workspace, size_t bytes);
 /* Float offset (from the workspace base) of pyramid level (o, l) of image 0; -1 if out of range. */
 int64_t affnet_pyramid_level_offset(const affnet_ctx* ctx, int octave, int level);
@@ -192,16 +204,6 @@ int affnet_cnn32_forward(affnet_ctx* ctx, int net_kind, const float* d_packed, c
 int affnet_cnn32_forward_pyr(affnet_ctx* ctx, int net_kind, const float* d_packed, const float* d_lafs,
                              const int32_t* d_ids, const int32_t* d_count, int n_max, float* d_out,
                              float* d_scratch, void* stream);
-
-/* Debug / parity aid: runs the trunk on ONE patch and copies the activation tensor after
- * trunk layer `layer` (0..5, post BN+ReLU, (C,H,W) fp32) to d_out. */
-int affnet_cnn32_debug_layer(affnet_ctx* ctx, int net_kind, const float* d_packed, const float* d_patch,
-                             int layer, float* d_out, void* stream);
-
-/* Tuning aid: when d_stamps != NULL every following CNN launch writes s_memtime stamps
- * [patch][wave][16] (uint64) at its phase boundaries (0 start, 1 input ready, 2 conv0 done, then per
- * conv layer k = 1..5: 2k+1 MFMA loop done, 2k+2 outputs stored).  NULL switches it off.  Process-global. */
-int affnet_cnn32_debug_timing(unsigned long long* d_stamps);
 
 /* ---- hand-crafted slot fillers --------------------------------------- */
 
@@ -328,23 +330,14 @@ int affnet_profile_read(affnet_ctx* ctx, double sum_ms[AFFNET_PROFILE_STAGES], i
 
 /* The one optional read-back: copies counters to the host after synchronising `stream`:
  * out[0] = rows after detection, out[1] = rows after shape filter, out[2] = capacity-overflow
- * flag (non-zero => AFFNET_ERR_CAPACITY semantics), out[3] = raw maxima found
- * (sums / OR over the images of the batch). */
+ * flag, out[3] = raw maxima found (sums / OR over the images of the batch).
+ * Returns AFFNET_ERR_CAPACITY when a fixed-capacity device list overflowed (results would be truncated: treat as an
+ * error), AFFNET_ERR_EMPTY when no image of the call produced a detection (out[] is still filled), else AFFNET_OK. */
 int affnet_read_counts(affnet_ctx* ctx, int32_t out[4], void* stream);
 
 /* Host helper (no GPU): out[ps] = affine_grid base coordinates (linspace(-1,1,ps)*(ps-1))/ps with
  * torch's CPU rounding; exported so the CPU test-suite can pin it against torch.linspace. */
 int affnet_host_base_grid(int ps, float* out);
-
-/* Tuning aid: runs the MFMA loop of one layer in isolation `reps` times per workgroup on `n_blocks` workgroups (same LDS
- * footprint as the trunk kernel).  layer 1 / 5: HardNet conv1 / conv5 (d_packed = HardNet's packed weights); 13 / 14 / 15:
- * AffNet conv3 as 2 x 2 tiles / conv3 as 4 x 1 tiles / conv5 (d_packed = AffNet's).  probe bit 0: no weight loads inside
- * the loop, bit 1: no activation loads, bit 2: accumulators in AGPRs, bit 3: lane-consecutive LDS read pattern (HardNet
- * layers only) - separates matrix-pipe issue efficiency from L2 / LDS effects.  d_out: 2 floats (sink). */
-int affnet_cnn32_probe(const float* d_packed, int layer, int probe, int reps, int n_blocks, float* d_out, void* stream);
-
-/* 16x16x4 fp32 MFMA layout self-test: d_out (16,16) = A (16,4) * B (4,16). */
-int affnet_selftest_mfma(const float* d_A, const float* d_B, float* d_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -67,6 +67,32 @@ def run(fast=False):
             ok &= same("th=-1 LAFs", L.numpy(), L2.numpy())
             ok &= same("th=-1 responses", r.numpy(), r2.numpy())
             ok &= same("LAFs2ell", ns.LAF.LAFs2ell(L.numpy()), orc.lafs_to_ellipses(L2.numpy()))
+    # constructor variants the mirror accepts: nlevels = 1 (35-tap Gaussian), init_sigma <= 0.5 (octave 0 unblurred, own blur sequence),
+    # and the 1024x768 synthetic image of BASELINE configs[2] (the metric's configuration)
+    x = orc.synthetic_image(240, 320, 1)
+    for kw in (dict(nlevels=1), dict(init_sigma=0.4), dict(init_sigma=0.5, nlevels=2)):
+        det = ns.SparseImgRepresenter.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=0, **kw)
+        with torch.no_grad(), rh.quiet():
+            L, r = det(x)
+        o = orc.OracleExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=0, **kw)
+        L2, r2 = o(x)
+        pyr_ok = all(torch.equal(a, b) for oi in range(len(det.scale_pyr)) for a, b in zip(det.scale_pyr[oi], o.scale_pyr[oi]))
+        print("== variant %s: pyramid identical: %s" % (kw, pyr_ok))
+        ok &= pyr_ok and len(det.scale_pyr) == len(o.scale_pyr)
+        ok &= same("  LAFs", L.numpy(), L2.numpy())
+        ok &= same("  responses", r.numpy(), r2.numpy())
+    if not fast:
+        x = orc.synthetic_image(768, 1024, 1)
+        print("== synthetic 768x1024 seed 1 (configs[2]), N=2000")
+        det = ns.SparseImgRepresenter.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=2000, border=5, num_Baum_iters=1, AffNet=A, OriNet=O)
+        with torch.no_grad(), rh.quiet():
+            L, r = det(x, do_ori=True)
+            D = Hn(det.extract_patches_from_pyr(L, PS=32))
+        o = orc.OracleExtractor(mrSize=5.192, num_features=2000, border=5, num_Baum_iters=1, affnet_sd=aff_sd, orinet_sd=ori_sd)
+        L2, r2, P2, D2 = orc.describe(x, o, hard_sd, do_ori=True, ps=32)
+        ok &= same("LAFs", L.numpy(), L2.numpy())
+        ok &= same("responses", r.numpy(), r2.numpy())
+        ok &= same("descriptors", D.numpy(), D2.numpy())
     print("ALL IDENTICAL" if ok else "MISMATCH")
     return ok
 

@@ -41,3 +41,32 @@ def load_gray(path):
     from PIL import Image
     img = np.mean(np.array(Image.open(path).convert("RGB")), axis=2)
     return torch.from_numpy(img.astype(np.float32)).view(1, 1, img.shape[0], img.shape[1])
+
+
+# ---- parity report: the GPU parity tests record what they measured (pytest -q swallows prints); written once per session
+PARITY_REPORT = {}
+
+
+def record_parity(name, **numbers):
+    PARITY_REPORT[name] = numbers
+
+
+def pytest_sessionfinish(session, exitstatus):
+    if not PARITY_REPORT:
+        return
+    import json
+    path = os.environ.get("AFFNET_PARITY_REPORT", os.path.join(ROOT, "gpurun_out", "parity_report.json"))
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        doc = {"what": "measured parity of the HIP path vs oracle/affnet_oracle.py (run live on this host) and vs tests/golden "
+                       "(unmodified reference on the authoring host); written by tests/test_gpu_parity.py",
+               "exitstatus": int(exitstatus), "cases": PARITY_REPORT}
+        try:
+            import torch
+            if torch.cuda.is_available():
+                doc["device"] = torch.cuda.get_device_name(0)
+        except Exception:
+            pass
+        json.dump(doc, open(path, "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass

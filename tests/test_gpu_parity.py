@@ -20,7 +20,7 @@ import pytest
 import torch
 
 import affnet_oracle as orc
-from conftest import load_gray
+from conftest import load_gray, record_parity
 
 pytestmark = pytest.mark.gpu
 
@@ -46,7 +46,28 @@ def _report(name, got, want):
     got, want = np.asarray(got, dtype=np.float64), np.asarray(want, dtype=np.float64)
     d = np.abs(got - want)
     print("%s: max abs diff %.3g, mismatching elements %d / %d" % (name, d.max() if d.size else 0, int((d > 0).sum()), d.size))
+    record_parity(name, max_abs_diff=float(d.max() if d.size else 0), mismatching_elements=int((d > 0).sum()), elements=int(d.size))
     return d
+
+
+def _row_stats(name, ids_g, L, D, r, keys_w, Lw, Dw, rw, extra=None):
+    """Key-matched comparison of one image's rows with the oracle's; records the numbers in the parity report."""
+    gi, wi = _match(ids_g, keys_w)
+    n = len(keys_w)
+    dl = np.abs(L[gi] - Lw[wi]).reshape(len(gi), -1).max(axis=1)
+    worst = int(np.argmax(dl)) if len(gi) else 0
+    rec = {"keypoints": int(n), "matched": int(len(gi)), "match_rate": len(gi) / float(max(n, 1)), "same_row_order": bool(len(gi) == n and np.array_equal(gi, wi)),
+           "laf_p50_px": float(np.percentile(dl, 50)), "laf_p99_px": float(np.percentile(dl, 99)), "laf_max_px": float(dl.max()),
+           "laf_rows_within_1e-3": float((dl < 1e-3).mean()), "worst_row_key_octave_level_pixel": [int(v) for v in np.asarray(ids_g)[gi[worst]]],
+           "responses_equal": bool(np.array_equal(r[gi], rw[wi]))}
+    dd = None
+    if D is not None:
+        dd = np.abs(D[gi] - Dw[wi]).max(axis=1)
+        rec.update({"desc_max": float(dd.max()), "desc_p99": float(np.percentile(dd, 99)), "desc_rows_within_1e-3": float((dd < 1e-3).mean())})
+    rec.update(extra or {})
+    record_parity(name, **rec)
+    print(name, rec)
+    return gi, wi, dl, dd, rec
 
 
 # ------------------------------------------------------------------------------------------------
@@ -228,7 +249,7 @@ def _match(ids_got, keys_want):
     return np.array(gi, dtype=np.int64), np.array(wi, dtype=np.int64)
 
 
-def _check_full(amd, nets, x, n, weights, want=None, min_match=0.995):
+def _check_full(amd, nets, x, n, weights, want=None, min_match=0.995, name=None):
     A, O, H = nets
     ex = _oracle(x, n, weights)
     Lw, rw, Pw, Dw = orc.describe(x, ex, weights["HardNet"], do_ori=True, ps=32)
@@ -249,8 +270,11 @@ def _check_full(amd, nets, x, n, weights, want=None, min_match=0.995):
     row_err = dl.reshape(len(gi), -1).max(axis=1)
     inside = row_err < 1e-3 + 1e-6 * np.abs(Lw.numpy()).max()
     print("rows within 1e-3 px: %.4f ; worst row %.3g px" % (inside.mean(), row_err.max()))
+    _row_stats(name or "full path %dx%d n=%d" % (x.size(3), x.size(2), n), res["ids"].cpu().numpy(), L, D, r, ex.keys.numpy(), Lw.numpy(), Dw.numpy(),
+               rw.numpy())
     assert inside.mean() >= 0.995 and row_err.max() < 1e-2, "LAF error above tolerance"
     assert dd[inside].max() < 1e-3 and np.percentile(dd, 99.5) < 1e-3, "descriptor error above 1e-3"
+    assert np.array_equal(r[gi], rw.numpy()[wi]), "responses of matched keypoints must be bit-identical"
     # patches through the public API (level choice on the device instead of host scipy)
     P = det.extract_patches_from_pyr(res["LAFs"], PS=32).cpu().numpy()
     dp = np.abs(P[gi] - Pw.numpy()[wi])
@@ -266,17 +290,17 @@ def _check_full(amd, nets, x, n, weights, want=None, min_match=0.995):
 
 def test_full_path_synthetic_golden(amd, nets, weights, golden_dir):
     g = np.load(os.path.join(golden_dir, "synth_240x320_s1_n300.npz"))
-    _check_full(amd, nets, orc.synthetic_image(240, 320, 1), 300, weights, want=g)
+    _check_full(amd, nets, orc.synthetic_image(240, 320, 1), 300, weights, want=g, name="synthetic 320x240 seed 1, 300 kp")
 
 
 def test_full_path_graf_img1_golden_n500(amd, nets, weights, golden_dir):
     g = np.load(os.path.join(golden_dir, "graf_img1_n500.npz"))
-    _check_full(amd, nets, load_gray(os.path.join(golden_dir, "graf_img1.png")), 500, weights, want=g)
+    _check_full(amd, nets, load_gray(os.path.join(golden_dir, "graf_img1.png")), 500, weights, want=g, name="graf img1 800x640, 500 kp")
 
 
 def test_full_path_graf_img1_n2000_config2(amd, nets, weights, golden_dir):
     """BASELINE.json configs[1]: test-graf/img1.png, 2000 kp, full path."""
-    _check_full(amd, nets, load_gray(os.path.join(golden_dir, "graf_img1.png")), 2000, weights)
+    _check_full(amd, nets, load_gray(os.path.join(golden_dir, "graf_img1.png")), 2000, weights, name="configs[1]: graf img1 800x640, 2000 kp")
 
 
 def test_threshold_mode_hesaffnet_as_shipped(amd, nets, weights, golden_dir):
@@ -299,9 +323,16 @@ def test_threshold_mode_hesaffnet_as_shipped(amd, nets, weights, golden_dir):
     assert len(gi) >= 0.995 * Lw.shape[0]
     assert np.abs(L.cpu().numpy()[gi] - Lw.numpy()[wi]).max() < 1e-3
     assert np.array_equal(r.cpu().numpy()[gi], rw.numpy()[wi])
-    if L.shape[0] == g["LAFs"].shape[0]:
-        ell = amd.LAF.LAFs2ell(L.cpu().numpy())
-        np.testing.assert_allclose(ell, g["ells"], rtol=5e-3, atol=1e-6)
+    # ellipses of the rows both have, against the reference's own output file content (golden, authoring host): matched by centre
+    ell = amd.LAF.LAFs2ell(L.cpu().numpy())
+    ge = g["ells"]
+    pos = {(round(float(e[0]), 2), round(float(e[1]), 2)): i for i, e in enumerate(ge)}
+    pairs = [(i, pos[(round(float(e[0]), 2), round(float(e[1]), 2))]) for i, e in enumerate(ell) if (round(float(e[0]), 2), round(float(e[1]), 2)) in pos]
+    record_parity("threshold mode (hesaffnet.py as shipped) 320x240", detected=int(counts[0]), rows=int(L.shape[0]), oracle_rows=int(Lw.shape[0]),
+                  golden_rows=int(ge.shape[0]), ellipses_matched_by_centre=len(pairs))
+    assert len(pairs) >= 0.995 * ge.shape[0], "only %d of %d ellipses of the reference's output found" % (len(pairs), ge.shape[0])
+    a, b = np.array([p[0] for p in pairs]), np.array([p[1] for p in pairs])
+    np.testing.assert_allclose(ell[a], ge[b], rtol=5e-3, atol=1e-6)
 
 
 def test_foreign_slots_staged_path_equals_fused(amd, nets, weights):
@@ -604,6 +635,118 @@ def test_full_size_properties_config3(amd, nets, weights):
     assert len(np.unique(_keys(r1["ids"].cpu().numpy()))) == 2000
 
 
+def test_metric_configuration_batched_b32_vs_oracle(amd, nets, weights, golden_dir):
+    """SURVEY section 8 row g1 - parity AT THE METRIC'S CONFIGURATION: bench.py's fused call = 32 synthetic 1024x768 images per
+    launch, 2000 kp each (BASELINE.json configs[2]).  First, middle and last image of the batch against the oracle (keys, responses,
+    LAFs, DESCRIPTORS), and batched == single-image bit-equality at this size."""
+    A, O, H = nets
+    B, seeds = 32, list(range(32))
+    xb = torch.cat([orc.synthetic_image(768, 1024, s) for s in seeds], 0).to(DEV)
+    mk = lambda: amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=2000, border=5, num_Baum_iters=1, AffNet=A, OriNet=O).to(DEV)
+    det = mk()
+    batched = det.run_batch(xb, do_ori=True, desc=H)
+    assert len(batched) == B and all(b["LAFs"].shape == (2000, 2, 3) and b["descriptors"].shape == (2000, 128) for b in batched)
+    # every image of the batch: unit descriptors, sorted responses, unique keys (cheap, covers all 32)
+    for b in batched:
+        assert np.all(np.diff(b["responses"].cpu().numpy()) <= 0)
+        assert np.abs(np.linalg.norm(b["descriptors"].cpu().numpy(), axis=1) - 1.0).max() < 1e-4
+        assert len(np.unique(_keys(b["ids"].cpu().numpy()))) == 2000
+    single = mk()
+    for i in (0, 15, 31):
+        got = batched[i]
+        one = single.run(xb[i:i + 1], do_ori=True, desc=H)
+        for k in ("LAFs", "responses", "descriptors", "ids"):
+            assert torch.equal(got[k], one[k]), "image %d of the batch differs from its single-image call in %s" % (i, k)
+        ex = _oracle(None, 2000, weights)
+        Lw, rw, Pw, Dw = orc.describe(orc.synthetic_image(768, 1024, seeds[i]), ex, weights["HardNet"], do_ori=True, ps=32)
+        gi, wi, dl, dd, rec = _row_stats("configs[2] metric configuration: image %d of a 32-image batch, 1024x768, 2000 kp" % i,
+                                         got["ids"].cpu().numpy(), got["LAFs"].cpu().numpy(), got["descriptors"].cpu().numpy(),
+                                         got["responses"].cpu().numpy(), ex.keys.numpy(), Lw.numpy(), Dw.numpy(), rw.numpy())
+        assert rec["match_rate"] >= 0.995, rec
+        assert rec["responses_equal"], "responses of matched keypoints must be bit-identical"
+        assert rec["laf_rows_within_1e-3"] >= 0.995 and rec["laf_max_px"] < 1e-2, rec
+        assert rec["desc_rows_within_1e-3"] >= 0.995, rec
+        assert dd[dl < 1e-3].max() < 1e-3, "descriptor of a geometrically matching row off by more than 1e-3"
+    # image 31 against the UNMODIFIED reference's own output on the authoring host (tests/golden/make_golden_config3.py); rows
+    # matched through the response bit pattern (the reference emits no integer keys)
+    g = np.load(os.path.join(golden_dir, "synth_768x1024_s31_n2000.npz"))
+    assert int(g["seed"]) == seeds[31]
+    got = batched[31]
+    rg, rw = got["responses"].cpu().numpy().view(np.uint32), g["resp"].view(np.uint32)
+    uniq = {v for v, c in zip(*np.unique(rw, return_counts=True)) if c == 1}
+    pos = {v: i for i, v in enumerate(rw)}
+    gi = np.array([i for i, v in enumerate(rg) if v in uniq], dtype=np.int64)
+    wi = np.array([pos[rg[i]] for i in gi], dtype=np.int64)
+    dl = np.abs(got["LAFs"].cpu().numpy()[gi] - g["LAFs"][wi]).reshape(len(gi), -1).max(axis=1)
+    dd = np.abs(got["descriptors"].cpu().numpy()[gi] - g["desc"][wi]).max(axis=1)
+    record_parity("configs[2] metric configuration: image 31 of the batch vs the reference's golden output", keypoints=2000, matched=int(len(gi)),
+                  same_row_order=bool(np.array_equal(gi, wi)), laf_max_px=float(dl.max()), laf_rows_within_1e_3=float((dl < 1e-3).mean()),
+                  desc_max=float(dd.max()), desc_rows_within_1e_3=float((dd < 1e-3).mean()))
+    assert len(gi) >= 0.995 * 2000 and (dl < 1e-3).mean() >= 0.995 and (dd < 1e-3).mean() >= 0.995 and dl.max() < 1e-2
+
+
+def test_two_contexts_two_host_threads(amd, nets):
+    """include/affnet_hip.h: different contexts may be driven from different host threads / streams concurrently (the library
+    keeps no process-global state).  Two threads, each with its own extractor (= context) and stream, alternate over images; every
+    result must be bit-identical to the single-threaded one."""
+    import threading
+    A, O, H = nets
+    imgs = [orc.synthetic_image(240, 320, s).to(DEV) for s in (1, 2, 3, 4)]
+    mk = lambda: amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=1, AffNet=A, OriNet=O).to(DEV)
+    ref = [mk().run(x, do_ori=True, desc=H) for x in imgs]
+    A.packed_weights(torch.device(DEV)); O.packed_weights(torch.device(DEV)); H.packed_weights(torch.device(DEV))   # shared, read-only from here on
+    torch.cuda.synchronize()
+    out, errs = {}, []
+
+    def worker(tid):
+        try:
+            det, st = mk(), torch.cuda.Stream(device=DEV)
+            with torch.cuda.stream(st):
+                for rep in range(6):
+                    for i, x in enumerate(imgs):
+                        r = det.run(x, do_ori=True, desc=H)
+                        out[(tid, rep, i)] = {k: r[k].clone() for k in ("LAFs", "responses", "descriptors", "ids")}
+            st.synchronize()
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs, errs
+    assert len(out) == 2 * 6 * len(imgs)
+    for (tid, rep, i), r in out.items():
+        for k in ("LAFs", "responses", "descriptors", "ids"):
+            assert torch.equal(r[k], ref[i][k]), (tid, rep, i, k)
+
+
+@pytest.mark.parametrize("kw", [dict(nlevels=1), dict(init_sigma=0.4), dict(init_sigma=0.5, nlevels=2)])
+def test_pyramid_variants_exact(amd, kw):
+    """Constructor kwargs the mirror accepts must give the reference's pyramid: nlevels = 1 (a 35 x 35 Gaussian) and
+    init_sigma <= 0.5 (octave 0 keeps the raw image and its own blur sequence, later octaves restart at init_sigma:
+    HandCraftedModules.py:25-31,49).  Pyramid levels and detections bit-exact vs the oracle."""
+    x = orc.synthetic_image(240, 320, 1)
+    det = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=0, **kw).to(DEV)
+    L, r = det(x.to(DEV))
+    ex = orc.OracleExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=0, **kw)
+    Lw, rw = ex(x)
+    assert len(det.scale_pyr) == len(ex.scale_pyr) and det.sigmas == ex.sigmas
+    worst = 0.0
+    for o in range(len(ex.scale_pyr)):
+        assert len(det.scale_pyr[o]) == len(ex.scale_pyr[o])
+        for l in range(len(ex.scale_pyr[o])):
+            worst = max(worst, float(np.abs(det.scale_pyr[o][l].cpu().numpy() - ex.scale_pyr[o][l].numpy()).max()))
+    record_parity("pyramid variant %s" % kw, pyramid_max_abs_diff=worst, rows=int(L.shape[0]), oracle_rows=int(Lw.shape[0]))
+    assert worst == 0.0, "pyramid differs by %g" % worst
+    assert L.shape == Lw.shape and np.array_equal(r.cpu().numpy(), rw.numpy())
+    assert np.abs(L.cpu().numpy() - Lw.numpy()).max() < 1e-4
+    # changing nlevels on a live object rebuilds the plan (the context cache key includes it)
+    if "nlevels" not in kw:
+        det.nlevels = 2
+        det(x.to(DEV))
+        assert len(det.scale_pyr[0]) == 4
+
+
 def test_cli_entry_points(amd, golden_dir, tmp_path):
     """L4 scripts run unchanged in spirit: same argv, same output files."""
     import subprocess, sys
@@ -627,16 +770,29 @@ def test_cli_entry_points(amd, golden_dir, tmp_path):
 
 
 def test_config5_4k_deep_pyramid(amd, nets, weights):
-    """BASELINE.json configs[4]: 3840x2160, 8000 kp, 8 octaves.  Detector identities must equal the oracle's."""
+    """BASELINE.json configs[4]: 3840x2160, 8000 kp, 8 octaves.  Detector identities must equal the oracle's; LAFs and DESCRIPTORS
+    within 1e-3; the batched path (bench.py --config5: 8 images per launch) bit-identical to single-image calls."""
     A, O, H = nets
     x = orc.synthetic_image(2160, 3840, 0)
     det = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=8000, border=5, num_Baum_iters=1, AffNet=A, OriNet=O).to(DEV)
     res = det.run(x.to(DEV), do_ori=True, desc=H)
     assert len(det.scale_pyr) == 8 and res["LAFs"].shape == (8000, 2, 3) and res["descriptors"].shape == (8000, 128)
     ex = _oracle(x, 8000, weights)
-    Lw, rw = ex(x, do_ori=True)
-    gi, wi = _match(res["ids"].cpu().numpy(), ex.keys.numpy())
-    row_err = np.abs(res["LAFs"].cpu().numpy()[gi] - Lw.numpy()[wi]).reshape(len(gi), -1).max(axis=1)
-    print("4K: matched %.4f, rows within 1e-3 px %.4f, worst %.3g" % (len(gi) / 8000.0, (row_err < 2e-3).mean(), row_err.max()))
-    assert len(gi) >= 0.995 * 8000 and (row_err < 1e-3 + 1e-6 * 3840).mean() >= 0.995
-    assert np.array_equal(res["responses"].cpu().numpy()[gi], rw.numpy()[wi])
+    Lw, rw, Pw, Dw = orc.describe(x, ex, weights["HardNet"], do_ori=True, ps=32)
+    gi, wi, dl, dd, rec = _row_stats("configs[4]: 3840x2160 seed 0, 8000 kp", res["ids"].cpu().numpy(), res["LAFs"].cpu().numpy(),
+                                     res["descriptors"].cpu().numpy(), res["responses"].cpu().numpy(), ex.keys.numpy(), Lw.numpy(), Dw.numpy(), rw.numpy())
+    assert rec["match_rate"] >= 0.995 and (dl < 1e-3 + 1e-6 * 3840).mean() >= 0.995, rec
+    assert rec["responses_equal"]
+    assert rec["desc_rows_within_1e-3"] >= 0.995 and dd[dl < 1e-3].max() < 1e-3, rec
+    # batched: 8 images per launch (seed 0 first and last so that one oracle run covers both positions)
+    del det
+    torch.cuda.empty_cache()
+    xb = torch.cat([x] + [orc.synthetic_image(2160, 3840, s) for s in range(1, 7)] + [x], 0).to(DEV)
+    det8 = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=8000, border=5, num_Baum_iters=1, AffNet=A, OriNet=O).to(DEV)
+    batched = det8.run_batch(xb, do_ori=True, desc=H)
+    assert len(batched) == 8
+    for i in (0, 7):
+        for k in ("LAFs", "responses", "descriptors", "ids"):
+            assert torch.equal(batched[i][k], res[k]), "4K batch image %d differs from the single-image call in %s" % (i, k)
+    for b in batched:
+        assert b["LAFs"].shape == (8000, 2, 3) and np.abs(np.linalg.norm(b["descriptors"].cpu().numpy(), axis=1) - 1.0).max() < 1e-4

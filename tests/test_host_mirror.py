@@ -16,14 +16,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_library_exports_every_declared_symbol():
     from affnet_amd import _lib
-    hdr = open(os.path.join(ROOT, "include", "affnet_hip.h")).read()
-    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
-    declared = set(re.findall(r"\b(affnet_[a-z0-9_]+)\s*\(", hdr))
-    assert declared, "no declarations parsed"
-    assert declared == set(_lib.SYMBOLS), (declared ^ set(_lib.SYMBOLS))
     raw = C.CDLL(_lib.LIB_PATH)
-    for name in declared:
-        assert hasattr(raw, name), name
+    # the boundary header and the debug / tuning header (kept apart: only the first is the drop-in ABI)
+    for fname, table in (("affnet_hip.h", _lib.SYMBOLS), ("affnet_hip_debug.h", _lib.DEBUG_SYMBOLS)):
+        hdr = open(os.path.join(ROOT, "include", fname)).read()
+        hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+        declared = set(re.findall(r"\b(affnet_[a-z0-9_]+)\s*\(", hdr))
+        assert declared, "no declarations parsed in " + fname
+        assert declared == set(table), (fname, declared ^ set(table))
+        for name in declared:
+            assert hasattr(raw, name), name
+    assert not [n for n in _lib.SYMBOLS if "debug" in n or "probe" in n or "selftest" in n], "debug entry points leaked into the boundary"
     assert b"gfx950" in _lib.lib.affnet_version()
     assert C.sizeof(_lib.Config) > 30000  # struct mirrors the 8 x 31x31 tap tables
 

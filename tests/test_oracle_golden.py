@@ -135,3 +135,15 @@ def test_handcrafted_slot_fillers_vs_reference_golden(golden_dir):
     ex = orc.OracleExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=4)
     L, r = ex(x, do_ori=False)
     assert np.array_equal(r.numpy(), g["baum4_resp"]) and np.abs(L.numpy() - g["baum4_LAFs"]).max() < 1e-3
+
+
+def test_metric_configuration_1024x768_n2000(golden_dir, weights):
+    """The oracle at BASELINE.json configs[2] (the metric's configuration) against the unmodified reference's output on the
+    benchmark's own synthetic image (tests/golden/make_golden_config3.py)."""
+    g = np.load(os.path.join(golden_dir, "synth_768x1024_s31_n2000.npz"))
+    x = orc.synthetic_image(768, 1024, int(g["seed"]))
+    ex, (L, r, P, D) = _full(x, 2000, weights)
+    assert len(ex.scale_pyr) == 6 and L.shape == (2000, 2, 3)
+    _close(r.numpy(), g["resp"], 1e-2, "responses")
+    _close(L.numpy(), g["LAFs"], 1e-3, "LAFs px")
+    _close(D.numpy(), g["desc"], 1e-4, "descriptors")

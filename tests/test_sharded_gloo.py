@@ -4,6 +4,7 @@ image order.  (On the GPU node the same code runs on backend "nccl" = RCCL over 
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -32,6 +33,9 @@ def _worker(rank, world, port, out):
     full = sharded.gather_features(rec, N_IMG)
     ok = full.shape == (N_IMG, 1 + N_CAP * 135)
     ok &= torch.equal(sharded.gather_features_async(rec, N_IMG)(), full)     # the overlapped form bench.py uses
+    to0 = sharded.gather_features_async(rec, N_IMG, dst=0)()                  # gather to rank 0 only (--gather rank0)
+    ok &= (to0 is None) if rank != 0 else torch.equal(to0, full)
+    ok &= sharded.record_counts(full).dtype == torch.int32 and sharded.record_counts(full).tolist() == [1 + i % N_CAP for i in range(N_IMG)]
     for i in range(N_IMG):
         want, got = _fake_result(i), sharded.unpack_record(full[i], N_CAP)
         n = int(want["count"])
@@ -65,3 +69,36 @@ def test_single_process_passthrough_and_generators_agree():
     assert torch.equal(synthetic_image(48, 64, 3), orc.synthetic_image(48, 64, 3))
     a, b = synthetic_hardnet_state(0), orc.synthetic_hardnet_state(0)
     assert all(torch.equal(a[k], b[k]) for k in b) and set(a) == set(b)
+
+
+def _bench(*argv, env=None):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), env=e, capture_output=True, text=True, timeout=300)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p.returncode, [json.loads(l) for l in lines], p.stderr
+
+
+@pytest.mark.parametrize("gather", ["all", "rank0"])
+def test_bench_self_spawns_n_ranks(gather):
+    """`python bench.py --gpus 2` (the shape of the driver's command, no launcher, no WORLD_SIZE): bench.py starts the 2 ranks itself,
+    they rendezvous (gloo here, RCCL on the GPU node), exchange the padded records and rank 0 prints ONE line with n_gpus = 2."""
+    rc, out, err = _bench("--gpus", "2", "--steps", "2", "--warmup", "0", "--batch", "3", "--dry-run", "--gather", gather)
+    assert rc == 0, err
+    assert len(out) == 1, out
+    assert out[0]["n_gpus"] == 2 and out[0]["config"]["global_batch"] == 6 and out[0]["records_in_global_order"] is True
+    assert out[0]["config"]["gather"] == ("all_gather" if gather == "all" else "gather to rank 0")
+
+
+def test_bench_refuses_wrong_world_or_missing_devices():
+    # a launcher-provided WORLD_SIZE that disagrees with --gpus must not silently report n_gpus = WORLD_SIZE
+    rc, out, err = _bench("--gpus", "4", "--dry-run", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc == 2 and not out and "WORLD_SIZE" in err
+    # the real (non dry-run) path on a host with fewer devices than --gpus fails loudly instead of running one rank
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        rc, out, err = _bench("--gpus", "2", "--steps", "1", "--warmup", "0")
+        assert rc == 2 and not out and "visible GPUs" in err

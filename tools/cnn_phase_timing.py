@@ -8,6 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import affnet_amd
 from affnet_amd._lib import lib, ptr
+from affnet_amd import engine
 
 dev = torch.device("cuda:0")
 n = int(os.environ.get("PHASE_PATCHES", "2048"))      # 256 = one workgroup per CU: the phases without a co-resident workgroup
@@ -19,9 +20,9 @@ names = ["input+norm", "conv0", "conv1 mfma", "conv1 store", "conv2 mfma", "conv
 for net, nm, nw in [(A, "AffNet", 8), (H, "HardNet", 8)]:
     net(p); torch.cuda.synchronize()
     st = torch.zeros(n * nw * 32, dtype=torch.int64, device=dev)
-    lib.affnet_cnn32_debug_timing(ptr(st))
+    lib.affnet_cnn32_debug_timing(engine.utility_ctx(dev), ptr(st))
     net(p); torch.cuda.synchronize()
-    lib.affnet_cnn32_debug_timing(None)
+    lib.affnet_cnn32_debug_timing(engine.utility_ctx(dev), None)
     t = st.cpu().numpy().reshape(n, nw, 32).astype(np.float64)
     nst = 12
     d = np.diff(t[:, :, :nst], axis=2)              # cycles per phase per wave
@@ -75,7 +76,7 @@ for net, nm, nw in [(A, "AffNet", 8), (H, "HardNet", 8)]:
     print("  CUs seen %d; mean resident WGs per CU %.2f; median end->next-start gap %.0f ticks (p90 %.0f)" %
           (len(util), np.mean(util), np.median(gaps), np.percentile(gaps, 90)))
     # wall time of the same launch without stamps
-    lib.affnet_cnn32_debug_timing(None)
+    lib.affnet_cnn32_debug_timing(engine.utility_ctx(dev), None)
     big = (torch.rand(48000, 1, 32, 32) * 255).to(dev)
     net(big); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
