@@ -11,6 +11,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import affnet_oracle as orc  # noqa: E402
+import onepass_oracle as opo  # noqa: E402
 import ref_harness as rh  # noqa: E402
 
 
@@ -93,6 +94,30 @@ def run(fast=False):
         ok &= same("LAFs", L.numpy(), L2.numpy())
         ok &= same("responses", r.numpy(), r2.numpy())
         ok &= same("descriptors", D.numpy(), D2.numpy())
+    # OnePassSIR (fully-convolutional AffNet once per octave) - oracle/onepass_oracle.py
+    print("== OnePassSIR path (AffNetFastFullConv with the shipped AffNet.pth, border = 15 as in the reference's scripts)")
+    x = orc.synthetic_image(240, 320, 1)
+    FC = ns.architectures.AffNetFastFullConv(); FC.load_state_dict(aff_sd); FC.eval()
+    with torch.no_grad():
+        ok &= same("LocalNorm2d(33)", FC.lrn(x).numpy(), opo.local_norm2d(x).numpy())
+        ok &= same("AffNetFastFullConv", FC(x).numpy(), opo.affnet_fullconv_forward(aff_sd, x).numpy())
+    nms2 = ns.HandCraftedModules.NMS2d.__new__(ns.HandCraftedModules.NMS2d)      # as shipped the ctor raises under py3 (float padding)
+    torch.nn.Module.__init__(nms2)
+    nms2.MP, nms2.eps, nms2.th = torch.nn.MaxPool2d(3, stride=1, return_indices=False, padding=1), 1e-5, 0
+    r = orc.hessian_response(orc.gaussian_blur(x, 1.6), 1.6)
+    ok &= same("NMS2d (int padding shim)", nms2(r).numpy(), opo.nms2d(r).numpy())
+    sir = rh.import_onepass_sir()
+    cases = [(300, True, x), (5000, False, x)]
+    if not fast:
+        cases.append((2000, True, orc.synthetic_image(768, 1024, 1)))
+    for n, do_ori, xx in cases:
+        det = sir.OnePassSIR(mrSize=5.192, num_features=n, border=15, num_Baum_iters=1, AffNet=FC, OriNet=O)
+        with torch.no_grad(), rh.quiet():
+            L, r = det(xx, do_ori=do_ori)
+        o = opo.OnePassOracle(mrSize=5.192, num_features=n, border=15, affnet_sd=aff_sd, orinet_sd=ori_sd)
+        L2, r2 = o(xx, do_ori=do_ori)
+        ok &= same("OnePassSIR %dx%d N=%d LAFs" % (xx.size(3), xx.size(2), n), L.numpy(), L2.numpy())
+        ok &= same("OnePassSIR responses", r.numpy(), r2.numpy())
     print("ALL IDENTICAL" if ok else "MISMATCH")
     return ok
 

@@ -76,3 +76,17 @@ def load_state_dict(name):
     import torch
     ck = torch.load(os.path.join(REF_ROOT, "pretrained", name), map_location="cpu", weights_only=False)
     return ck["state_dict"]
+
+
+def import_onepass_sir():
+    """OnePassSIR.py cannot be imported under Python 3: its forward() holds ONE Python-2 statement
+    (`print time.time() - t, 'detection multiscale'`, OnePassSIR.py:144).  The source is read from the reference, that single
+    statement is rewritten IN MEMORY and the module is executed - nothing is written anywhere, no reference source enters this
+    repository.  Returns the module (class OnePassSIR)."""
+    import_reference()
+    src = open(os.path.join(REF_ROOT, "OnePassSIR.py")).read()
+    bad = "print time.time() - t, 'detection multiscale'"
+    assert src.count(bad) == 1, "OnePassSIR.py changed: expected exactly one Python-2 print statement"
+    mod = types.ModuleType("OnePassSIR")
+    exec(compile(src.replace(bad, "pass"), os.path.join(REF_ROOT, "OnePassSIR.py"), "exec"), mod.__dict__)
+    return mod
