@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libaffnet_hip.so")
 
 MAX_OCTAVES, MAX_LEVELS, MAX_TAPS = 16, 8, 37
-NET_AFFNET, NET_ORINET, NET_HARDNET = 0, 1, 2
+NET_AFFNET, NET_ORINET, NET_HARDNET, NET_AFFNET_FULLCONV = 0, 1, 2, 3
 OK, ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_EMPTY = 0, -1, -2, -3, -4
 
 
@@ -63,6 +63,10 @@ SYMBOLS = {
     "affnet_cnn32_pack_weights": (_I, [_I, C.POINTER(_P), C.POINTER(_P), C.POINTER(_P), _P, _P, _P, _P, _P]),
     "affnet_cnn32_forward": (_I, [_P, _I, _P, _P, _P, _I, _P, _P, _P]),
     "affnet_cnn32_forward_pyr": (_I, [_P, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
+    "affnet_local_norm": (_I, [_P, _P, _P, _I, _I, _P]),
+    "affnet_fullconv_scratch_bytes": (_SZ, [_I, _I]),
+    "affnet_fullconv_forward": (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
+    "affnet_nms2d": (_I, [_P, _P, _P, _I, _I, C.c_float, _P]),
     "affnet_shape_filter_select": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "affnet_apply_rotation": (_I, [_P, _P, _P, _P, _I, _P]),
     "affnet_scale_lafs": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -27,27 +27,15 @@ class _HipPatchNet(nn.Module):
 
     def __init__(self):
         super(_HipPatchNet, self).__init__()
-        self._packed = None       # (device, tensor)
-        self._packed_version = -1
-        self._version = 0
-
-    def _bump(self):
-        self._version += 1
-
-    def load_state_dict(self, *a, **k):
-        r = super(_HipPatchNet, self).load_state_dict(*a, **k)
-        self._bump()
-        return r
-
-    def _apply(self, fn, *a, **k):
-        r = super(_HipPatchNet, self)._apply(fn, *a, **k)
-        self._bump()
-        return r
+        self._packed = None            # BN-folded, MFMA-ordered blob on the device
+        self._packed_version = None    # _weights_stamp() it was built from
 
     def _weights_stamp(self):
-        """Changes whenever a parameter or buffer is replaced (load_state_dict / .to()) or modified in place
-        (p.data.copy_(), BN running-stat updates, direct state-dict tensor edits all bump the tensor's `_version`)."""
-        return (self._version,) + tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        """Changes whenever a parameter or buffer is replaced (.to(other device), .float()) or modified in place (load_state_dict,
+        p.data.copy_(), BN running-stat updates, direct state-dict tensor edits all bump the tensor's `_version`).  A no-op
+        `.to(same device)` - e.g. moving an extractor that holds this net - leaves it unchanged, so the packed blob is NOT
+        rebuilt (and never freed) under kernels that may still be reading it on another stream."""
+        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
 
     def invalidate_packed(self):
         """Drops the cached BN-folded weight blob (it is rebuilt on the next call)."""
@@ -85,6 +73,31 @@ class AffNetFast(_HipPatchNet):
         """(n,1,32,32) -> (n,2,2) rectified affine shape.  The second positional argument is the
         kwargs dict batched_forward passes positionally (Utils.py:54)."""
         return self._run(input)
+
+
+class AffNetFastFullConv(_HipPatchNet):
+    """architectures.py:629-674: the fully-convolutional AffNet of the OnePassSIR path.  Same `features` layout as AffNetFast, so
+    `load_state_dict(torch.load('AffNet.pth')['state_dict'])` works (the reference ships no dedicated checkpoint).
+    forward((1,1,H,W) image, 0..255) -> (1,4,H,W) per-pixel rectified shape (a11, 0, a21, a22); H, W >= 34."""
+    KIND = _lib.NET_AFFNET_FULLCONV
+
+    def __init__(self, PS=32, stride=2):
+        super(AffNetFastFullConv, self).__init__()
+        if PS != 32 or stride != 2:
+            raise NotImplementedError("the HIP kernels are specialised for PS=32, stride=2 (the reference's defaults)")
+        self.features = _container([16, 16, 32, 32, 64, 64], 3, 8, 0, True)
+        self.features = nn.Sequential(*list(self.features.children())[:20])   # the reference's Sequential ends with the 8x8 conv
+        self.stride, self.PS = stride, PS
+        self.halfPS = int(PS / 2)
+        self.eval()
+
+    def forward(self, input, return_A_matrix=False):
+        if self.training:
+            raise RuntimeError("affnet_amd nets are inference-only (call .eval()); training is out of scope")
+        engine.require_cuda(input, "image")
+        if input.dim() != 4 or input.size(0) != 1 or input.size(1) != 1:
+            raise ValueError("expected a (1,1,H,W) image")
+        return engine.fullconv_forward(self.packed_weights(input.device), input)
 
 
 class OriNetFast(_HipPatchNet):

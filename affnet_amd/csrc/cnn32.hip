@@ -5,122 +5,37 @@
 // ReLU, the heads, rectifyAffineTransformationUpIsUp (LAF.py:285-291), get_rotation_matrix
 // (LAF.py:276-283) and L2Norm (HardNet.py:12-19).
 //
-// Design (one workgroup = 8 wavefronts = one patch, whole trunk resident on the CU):
-//   * the patch is sampled (or loaded), standardised (mean / unbiased std + 1e-7) and conv0
-//     (K = 9, VALU) writes its planes into ONE LDS activation buffer, planar [c][H+2][W+2] with a
-//     zero halo (so the 3x3 taps are plain address offsets and padding costs nothing);
-//   * conv1..conv5 are implicit GEMMs on v_mfma_f32_16x16x4_f32 (exact fp32, 32 cycles):
-//     M = output pixels (16 consecutive pixels per tile -> conflict-free ds_read_b32 A fragments:
-//     lane = (pixel, k) with k = 4 consecutive input channels one plane apart), N = 16 output
-//     channels per tile, K = (tap, cin).  B fragments stream from the packed weights in L2
-//     ([k][n], n fastest -> coalesced 64-byte segments).  The 8 waves split the M x N tile grid
-//     (TM x TN register blocking per wave);
-//   * a layer's complete output lives in the accumulators (<= 64 VGPR/lane) until every wave has
-//     finished reading the input; then bias + ReLU are applied and the planes are written back IN
-//     PLACE over the input.  One activation buffer (<= 148 KB of the 160 KB LDS), no HBM traffic
-//     between layers: per patch the kernel reads 4 KB (or samples the pyramid) + the L2-resident
-//     weights and writes 16 B (AffNet/OriNet) or the 32 KB conv5 tensor (HardNet);
-//   * AffNet / OriNet heads (K = 4096, N <= 3) run on the VALU in the same kernel; the HardNet
-//     head (8192 x 128, 4.2 MB of weights) is a separate GEMM over all patches so the weights are
-//     read once per 16 patches instead of once per patch, with BN + L2 normalisation fused.
+// Design (one workgroup = 8 wavefronts = one patch, whole trunk resident on the CU; details in DESIGN.md section 4):
+//   * the patch is sampled from the pyramid (or loaded), standardised (mean / unbiased std + 1e-7, DPP wave reductions)
+//     and stored as a zero-haloed 34 x 34 LDS tile;
+//   * ALL six convolutions run on v_mfma_f32_16x16x4_f32 (exact fp32): conv0 with K = 9 taps padded to 12 and the
+//     accumulators initialised with the bias, conv1..5 as implicit GEMMs (cnn_mfma.h: conv3x3_mfma) with the WEIGHTS as the
+//     MFMA A operand and the ACTIVATIONS as the B operand, so a lane ends up with 4 consecutive channels of one pixel;
+//   * activations live in ONE LDS buffer, channel-interleaved by 4 ((c/4)*PSG + pixel*4 + c%4): one ds_read_b128 per lane =
+//     the activation operands of four k-steps, one ds_write_b128 per tile in the epilogue (bias + ReLU), written IN PLACE
+//     over the layer's input after a barrier.  No HBM traffic between layers;
+//   * packed weights [tap][cin/16][kq][cout][4] stream from L2 through a buffer descriptor (one buffer_load_dwordx4 per
+//     lane = the weight operands of four k-steps), software-pipelined one chunk ahead, loads interleaved between the MFMAs;
+//   * heads: HardNet stores its conv5 tile [pixel][channel] to HBM and an 8192 x 128 split-K MFMA GEMM over all patches
+//     (hardnet_head_kernel + hardnet_finish_kernel: BN bias + L2 norm) follows; AffNet / OriNet reduce their heads' dot
+//     products per wave straight from the conv5 accumulators (head_partials) and cnn16_finish_kernel combines the eight
+//     partials per patch in fixed order (tanh, rectification / atan2).
 #include <math.h>
 #include <stdlib.h>
 
 #include "common.h"
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-// LDS activation layout: channel-interleaved by 4.  A tensor [C][H][H] lives as C/4 "plane groups"; element
-// (c, y, x) of the zero-haloed (H+2)-square image sits at  (c/4)*PSG + ((y+1)*WP + x+1)*4 + c%4  (floats).  One
-// ds_read_b128 of lane (pixel m, kq) then delivers the A operands of FOUR MFMA k-steps (channels 4*(4G+kq)+j,
-// j = 0..3) - a quarter of the LDS instructions and half the LDS cycles of per-k-step ds_read_b32, which is what
-// kept the matrix pipe waiting: under 16-32 waves of MFMA loops an LDS read returns after several hundred cycles and
-// lgkmcnt (4 bits) cannot cover more than 15 reads in flight.  The packed weights are interleaved the same way, so a
-// B fragment is one coalesced global_load_dwordx4 per 4 k-steps (1 KB per wave instruction).
-//
-// Each buffer is written by one layer's epilogue and read by the next layer's implicit GEMM; (WP, PSG) are chosen for
-// the READER (ds_read_b128 services lanes {0-3,12-15,20-27},{4-11,16-19,28-31},... per cycle over 64 banks):
-//   stride-1 reader: 16 consecutive pixels = 64 banks; the kq = 1 lanes of a group must land on the other half:
-//                    H = 32/16: PSG == 0 (mod 64);  H = 8 (a tile = 2 rows): WP = 16, PSG == 32 (mod 64);
-//   stride-2 reader: pixels 2 apart hit banks == 0..3 (mod 8) -> PSG == 4 (mod 8) (and WP == 0 (mod 8) when a tile
-//                    spans two output rows, 16 -> 8) - these also make the epilogue's ds_write_b32 conflict free.
-//
-// Operand roles: the WEIGHTS are the MFMA "A" operand (rows = 16 output channels) and the ACTIVATIONS the "B" operand
-// (columns = 16 pixels), i.e. each 16x16 tile is out^T[channel][pixel].  A lane then owns FOUR CONSECUTIVE CHANNELS of one
-// pixel (rows 4g..4g+3 of column lane&15) = exactly one float4 of the interleaved layout, so the epilogue is one
-// conflict-free ds_write_b128 per tile instead of four 4-way-conflicting ds_write_b32.
-// LDS reads of the MFMA loops go through an explicit 32-bit LDS byte address: one address VGPR per K group (made
-// opaque to the optimiser) + a compile-time immediate per tile.  Left to itself the compiler folds the chunk constant
-// into every tile offset, overflows the 16-bit DS offset field and spends one v_add_u32 per ds_read_b128 inside the
-// MFMA stream (conv1: 8 per 64 MFMAs, -12 % MFMA rate in tools/mfma_probe.py).
-typedef __attribute__((address_space(3))) const f32x4 LdsF4;
-__device__ __forceinline__ unsigned lds_byte_addr(const float* p) {
-    return (unsigned)(size_t)(__attribute__((address_space(3))) const float*)p;
-}
-__device__ __forceinline__ f32x4 lds_read4(unsigned byte_addr) { return *(LdsF4*)(size_t)byte_addr; }
-
-// Weight fragments of the MFMA loops come through a buffer descriptor: the lane offset is one loop-invariant 32-bit
-// VGPR, the chunk offset an SGPR, the tile offset an immediate - no 64-bit VALU pointer arithmetic between the MFMAs and
-// half the address payload of a flat global_load_dwordx4 per instruction.
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t weight_rsrc(const float* base, int n_floats) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, n_floats * 4, 0x00020000);
-}
-__device__ __forceinline__ f32x4 buf_read4(__amdgpu_buffer_rsrc_t r, int lane_byte_off, int uniform_byte_off) {
-    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, lane_byte_off, uniform_byte_off, 0));
-}
-
-template <int H_, int WP_, int PSG_>
-struct Lay {
-    static constexpr int H = H_, WP = WP_, PSG = PSG_;
-    __device__ static __forceinline__ int at(int c, int y, int x) { return (c >> 2) * PSG + ((y + 1) * WP + x + 1) * 4 + (c & 3); }
-};
-typedef Lay<32, 34, 4672> LayC0;   // conv0 out -> conv1 (stride 1)
-typedef Lay<32, 34, 4628> LayC1;   // conv1 out -> conv2 (stride 2)
-typedef Lay<16, 18, 1344> LayC2;   // conv2 out -> conv3 (stride 1)
-typedef Lay<16, 24, 1732> LayC3;   // conv3 out -> conv4 (stride 2, tile = 2 output rows)
-typedef Lay<8, 16, 672> LayC4;     // conv4 out -> conv5 (stride 1, tile = 2 rows)
-typedef Lay<8, 16, 672> LayC5;     // conv5 out -> AffNet / OriNet heads
-#define WP32 34
-#define HEAD_K 8192
-
-// ---- packed weight layout --------------------------------------------------------------------------
-struct NetLayout {
-    int cb;                 // base width: 16 (AffNet/OriNet) or 32 (HardNet)
-    int cin[6], cout[6];
-    size_t w_off[6], b_off[6];
-    size_t head_w, head_b;  // head weights / bias (HardNet: BN-folded [8192][128] + bias[128])
-    size_t total;
-};
-
-static NetLayout net_layout(int kind) {
-    NetLayout L;
-    L.cb = (kind == AFFNET_NET_HARDNET) ? 32 : 16;
-    const int ch[7] = {1, L.cb, L.cb, 2 * L.cb, 2 * L.cb, 4 * L.cb, 4 * L.cb};
-    size_t off = 0;
-    for (int i = 0; i < 6; ++i) {
-        L.cin[i] = ch[i]; L.cout[i] = ch[i + 1];
-        L.w_off[i] = off; off += (i == 0) ? (size_t)12 * ch[1] : (size_t)9 * ch[i] * ch[i + 1];   // conv0: K = 9 padded to 12
-        L.b_off[i] = off; off += ch[i + 1];
-        off = (off + 3) & ~(size_t)3;
-    }
-    L.head_w = off;
-    if (kind == AFFNET_NET_AFFNET) { off += 3 * 4096; L.head_b = off; off += 4; }
-    else if (kind == AFFNET_NET_ORINET) { off += 2 * 4096; L.head_b = off; off += 4; }
-    else { off += (size_t)HEAD_K * 128; L.head_b = off; off += 128; }
-    L.total = off;
-    return L;
-}
+#include "cnn_mfma.h"
 
 extern "C" size_t affnet_cnn32_packed_floats(int net_kind) {
-    if (net_kind < 0 || net_kind > 2) return 0;
+    if (net_kind < 0 || net_kind > AFFNET_NET_AFFNET_FULLCONV) return 0;
     return net_layout(net_kind).total;
 }
 
 extern "C" int affnet_cnn32_pack_weights(int kind, const float* const* conv_w, const float* const* bn_mean, const float* const* bn_var,
                                          const float* head_w, const float* head_b, const float* head_bn_mean, const float* head_bn_var,
                                          float* out) {
-    if (kind < 0 || kind > 2 || !conv_w || !bn_mean || !bn_var || !head_w || !out) return AFFNET_ERR_INVALID;
+    if (kind < 0 || kind > AFFNET_NET_AFFNET_FULLCONV || !conv_w || !bn_mean || !bn_var || !head_w || !out) return AFFNET_ERR_INVALID;
     const NetLayout L = net_layout(kind);
     memset(out, 0, L.total * sizeof(float));
     for (int i = 0; i < 6; ++i) {
@@ -150,6 +65,14 @@ extern "C" int affnet_cnn32_pack_weights(int kind, const float* const* conv_w, c
                     out[L.head_w + (((k >> 4) * 4 + ((k >> 2) & 3)) * 128 + n) * 4 + (k & 3)] = head_w[(size_t)n * HEAD_K + c * 64 + pp] * s;
                 }
         }
+    } else if (kind == AFFNET_NET_AFFNET_FULLCONV) {
+        if (!head_b) return AFFNET_ERR_INVALID;
+        // dense 8 x 8 head (architectures.py:652): [tap pp = ky * 8 + kx][channel group c / 4][output o][c % 4] - what one thread of
+        // fullconv_head_kernel multiplies with the float4 (4 channels of one pixel) it loads
+        for (int o = 0; o < 3; ++o)
+            for (int c = 0; c < 64; ++c)
+                for (int pp = 0; pp < 64; ++pp) out[L.head_w + (((size_t)pp * 16 + c / 4) * 3 + o) * 4 + c % 4] = head_w[((size_t)o * 64 + c) * 64 + pp];
+        memcpy(out + L.head_b, head_b, 3 * sizeof(float));
     } else {
         const int no = kind == AFFNET_NET_AFFNET ? 3 : 2;
         if (!head_b) return AFFNET_ERR_INVALID;
@@ -160,391 +83,6 @@ extern "C" int affnet_cnn32_pack_weights(int kind, const float* const* conv_w, c
         memcpy(out + L.head_b, head_b, no * sizeof(float));
     }
     return AFFNET_OK;
-}
-
-struct NetOffsets {        // device-side copy of the offsets (by-value kernel argument)
-    int w[6], b[6], head_w, head_b;
-};
-
-static NetOffsets to_offsets(const NetLayout& L) {
-    NetOffsets o;
-    for (int i = 0; i < 6; ++i) { o.w[i] = (int)L.w_off[i]; o.b[i] = (int)L.b_off[i]; }
-    o.head_w = (int)L.head_w; o.head_b = (int)L.head_b;
-    return o;
-}
-
-// ---- device helpers ------------------------------------------------------------------------------
-// Wave-wide sum on the VALU only (DPP row reductions + 4 readlanes).  __shfl_xor compiles to ds_bpermute_b32,
-// i.e. six DEPENDENT trips through the LDS queue, which the MFMA loops of the co-resident waves keep hundreds of
-// requests deep: the two input-norm reductions cost ~15k cycles per patch that way (profiles/r01_s2b_cnn_phase_timing).
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v) {
-    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float wave_sum(float v) {
-    v = dpp_add<0xB1>(v);     // quad_perm [1,0,3,2]
-    v = dpp_add<0x4E>(v);     // quad_perm [2,3,0,1]
-    v = dpp_add<0x141>(v);    // row_half_mirror: 8 lanes
-    v = dpp_add<0x140>(v);    // row_mirror: every lane holds the sum of its row of 16
-    const int iv = __float_as_int(v);
-    const float r0 = __int_as_float(__builtin_amdgcn_readlane(iv, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(iv, 16));
-    const float r2 = __int_as_float(__builtin_amdgcn_readlane(iv, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(iv, 48));
-    return (r0 + r1) + (r2 + r3);
-}
-
-// Sum `v` over the NW wavefronts of the workgroup.  `slot` must hold NW floats that nothing else touches during the
-// kernel (each reduction of a kernel gets its own slot), so ONE barrier suffices.
-template <int NW>
-__device__ __forceinline__ float block_sum(float v, float* slot) {
-    v = wave_sum(v);
-    if ((threadIdx.x & 63) == 0) slot[threadIdx.x >> 6] = v;
-    __syncthreads();
-    float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < NW; ++w) t += slot[w];
-    return t;
-}
-
-// Zero the 1-pixel halo of the C/4 plane groups of layout L (16-byte stores).
-template <typename L, int NTHR>
-__device__ __forceinline__ void zero_halo(float* act, int channels, int tid = threadIdx.x) {
-    constexpr int H = L::H, CELLS = 4 * (H + 1);
-    const int groups = channels >> 2;
-    for (int i = tid; i < groups * CELLS; i += NTHR) {
-        const int g = i / CELLS, e = i - g * CELLS;
-        int y, x;
-        if (e < H + 2) { y = 0; x = e; }
-        else if (e < 2 * (H + 2)) { y = H + 1; x = e - (H + 2); }
-        else { const int r = e - 2 * (H + 2); y = 1 + (r >> 1); x = (r & 1) ? H + 1 : 0; }
-        *reinterpret_cast<f32x4*>(&act[g * L::PSG + (y * L::WP + x) * 4]) = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-}
-
-// Plane groups (16 input channels = 4 MFMA k-steps) per pipeline chunk: grow the chunk until it holds `target`
-// MFMAs, as long as the two A register sets stay within `max_a_regs` VGPRs.
-constexpr int pick_groups(int cin, int tm, int tn, int target, int max_a_regs) {
-    int g = 1;
-    while (g * 2 <= cin / 16 && (cin / 16) % (g * 2) == 0 && 4 * tm * tn * g < target && 2 * (g * 2) * tm * 4 <= max_a_regs) g *= 2;
-    return g;
-}
-
-// Implicit-GEMM 3x3 convolution (padding 1) of the LDS tensor `act` (layout LI, CIN channels) with packed weights
-// Wg [tap][CIN/16][kq][COUT][4]; leaves the TM x TN tiles (16 px x 16 ch) of this wave in `acc` (pre-activation, no
-// bias).  HOUT = LI::H / STRIDE.  K is walked in chunks of GRP plane groups (a chunk never straddles a tap).
-// Software pipeline, one chunk deep, two statically named register sets: while the MFMAs of chunk c issue, the A
-// (ds_read_b128) and B (global_load_dwordx4) fragments of chunk c+1 are in flight; loads and MFMAs interleave per
-// plane group so that few LDS reads are outstanding at any wait (lgkmcnt has 4 bits).
-template <int GRP, int TM, int TN>
-struct Frag {
-    f32x4 a[GRP][TM];
-    f32x4 b[GRP][TN];
-};
-
-// B fragments of chunk 0 of a layer (and its bias values): they do not depend on the activations, so the kernel requests
-// them BEFORE the barriers / epilogue of the previous layer and their L2 latency (1-2k cycles under load) is hidden.
-template <int NW, int COUT, int HOUT, int TM, int TN, int GRP>
-__device__ __forceinline__ void prefetch_b0(const float* __restrict__ Wg, f32x4 (&b0)[GRP][TN], int wave, int lane) {
-    constexpr int MG = (HOUT * HOUT / 16) / TM;
-    const int ng = wave / MG, m = lane & 15, kq = lane >> 4;
-#pragma unroll
-    for (int u = 0; u < GRP; ++u)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b0[u][j] = *reinterpret_cast<const f32x4*>(&Wg[u * 16 * COUT + (kq * COUT + (ng * TN + j) * 16 + m) * 4]);
-}
-template <int NW, int HOUT, int TM, int TN>
-__device__ __forceinline__ void prefetch_bias(const float* __restrict__ bias, f32x4 (&bv)[TN], int wave, int lane) {
-    constexpr int MG = (HOUT * HOUT / 16) / TM;
-    const int ng = wave / MG;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const f32x4*>(&bias[(ng * TN + j) * 16 + 4 * (lane >> 4)]);   // channels 4g..4g+3
-}
-
-// PROBE (tuning aid, affnet_cnn32_probe): bit 0 = skip the weight loads, bit 1 = skip the activation loads inside the loop,
-// bit 3 = activation reads from lane-consecutive addresses (bank-conflict-free reference pattern).
-template <int NW, int CIN, int COUT, typename LI, int STRIDE, int TM, int TN, int GRP, int PROBE = 0>
-__device__ __forceinline__ void conv3x3_mfma(const float* act, const float* __restrict__ Wg, const f32x4 (&b0)[GRP][TN],
-                                             f32x4 (&acc)[TM][TN], int wave, int lane) {
-    constexpr int HOUT = LI::H / STRIDE;
-    constexpr int MT = HOUT * HOUT / 16, NT = COUT / 16;
-    constexpr int MG = MT / TM, NG = NT / TN;
-    constexpr int NGRP = CIN / 16, NCHUNK = 9 * NGRP / GRP;
-    static_assert(MG * NG == NW, "the waves must tile the layer exactly");
-    static_assert(CIN % 16 == 0 && NGRP % GRP == 0, "bad chunking");
-    const int mg = wave % MG, ng = wave / MG;
-    const int m = lane & 15, kq = lane >> 4;
-    // lane address of tile 0 / N-tile 0; the other tiles of the wave sit at compile-time offsets (immediates)
-    static_assert(HOUT == 8 || (TM * 16) % HOUT == 0 || HOUT % (TM * 16) == 0, "tile offsets must be wave-uniform constants");
-    int a_lane;
-    {
-        const int p = mg * TM * 16 + m;
-        const int oy = p / HOUT, ox = p - oy * HOUT;
-        a_lane = kq * LI::PSG + ((oy * STRIDE) * LI::WP + ox * STRIDE) * 4;
-    }
-    const int b_lane = (kq * COUT + ng * TN * 16 + m) * 4;
-    if (PROBE & 8) a_lane = lane * 4;                      // probe: 64 consecutive float4 per read = the conflict-free ideal
-    const unsigned a_addr0 = lds_byte_addr(act) + a_lane * 4;
-    auto a_imm = [](int i) {                               // byte offset of tile i from tile 0 (compile-time after unrolling)
-        return 4 * ((PROBE & 8) ? i * 256 : (HOUT == 8 ? i * 2 * STRIDE * LI::WP * 4 : (((i * 16) / HOUT) * STRIDE * LI::WP + ((i * 16) % HOUT) * STRIDE) * 4));
-    };
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    Frag<GRP, TM, TN> f0, f1;
-
-    auto a_chunk_off = [](int ch) {
-        const int q0 = ch * GRP;
-        const int tap = q0 / NGRP, g0 = q0 - tap * NGRP;
-        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;          // tap / 3, tap % 3 for tap < 9
-        return g0 * 4 * LI::PSG + (ky * LI::WP + kx) * 4;
-    };
-    const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(Wg, 9 * CIN * COUT);
-    auto load_group = [&](Frag<GRP, TM, TN>& f, int u, int a_off, int w_off) {
-        if (!(PROBE & 2)) {
-            unsigned ab = a_addr0 + (a_off + u * 4 * LI::PSG) * 4;
-            asm("" : "+v"(ab));
-#pragma unroll
-            for (int i = 0; i < TM; ++i) f.a[u][i] = lds_read4(ab + a_imm(i));
-        }
-        if (!(PROBE & 1)) {
-#pragma unroll
-            for (int j = 0; j < TN; ++j) f.b[u][j] = buf_read4(wrsrc, b_lane * 4 + j * 256, (w_off + u * 16 * COUT) * 4);
-        }
-    };
-    auto mfma_group = [&](const Frag<GRP, TM, TN>& f, int u) {
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(f.b[u][j][s4], f.a[u][i][s4], acc[i][j], 0, 0, 0);   // W^T x act
-    };
-    // compute the chunk held in `cur` while loading chunk `nxt_ch` into `nxt`
-    auto stage = [&](const Frag<GRP, TM, TN>& cur, Frag<GRP, TM, TN>& nxt, int nxt_ch) {
-        const int a_off = a_chunk_off(nxt_ch);
-        const int w_off = nxt_ch * (GRP * 16 * COUT);
-#pragma unroll
-        for (int u = 0; u < GRP; ++u) {
-            load_group(nxt, u, a_off, w_off);
-            mfma_group(cur, u);
-            // Schedule: the TM ds_read_b128 and TN global_load_dwordx4 of this group are spread BETWEEN its MFMAs (one load
-            // after every Q MFMAs) instead of being issued as a burst in front of them.  A wave cannot issue an MFMA while it
-            // issues a load (a 1 KB dwordx4 wave-load holds the issue slot for tens of cycles); with bursts at the group
-            // boundaries both waves of a SIMD tended to be in their bursts together and the pipe idled ~8 % of the loop
-            // (tools/mfma_probe.py: conv1 81.7 % -> 88.5 % of peak with the weight loads removed).
-            constexpr int NM = 4 * TM * TN, NL = ((PROBE & 2) ? 0 : TM) + ((PROBE & 1) ? 0 : TN), Q = NL ? NM / (NL + 1) : NM;
-            // weight loads (L2, long latency) first, activation loads (LDS) after them
-#pragma unroll
-            for (int l = 0; l < ((PROBE & 1) ? 0 : TN); ++l) {
-                if (l == 0) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                else __builtin_amdgcn_sched_group_barrier(0x008, Q, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            }
-#pragma unroll
-            for (int l = 0; l < ((PROBE & 2) ? 0 : TM); ++l) {
-                __builtin_amdgcn_sched_group_barrier(0x008, Q, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);      // whatever MFMAs remain
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-    {
-        const int a_off = a_chunk_off(0);
-#pragma unroll
-        for (int u = 0; u < GRP; ++u) {
-            const unsigned ab = a_addr0 + (a_off + u * 4 * LI::PSG) * 4;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) f0.a[u][i] = lds_read4(ab + a_imm(i));
-#pragma unroll
-            for (int j = 0; j < TN; ++j) f0.b[u][j] = b0[u][j];
-        }
-    }
-    if (PROBE) f1 = f0;
-    // (The two waves of a workgroup that share a SIMD do not advance evenly - the older one wins the arbitration and leaves
-    // the loop ~12 % earlier.  Alternating s_setprio between them evens that out but the pair's finish time, set by the
-    // MFMA pipe, does not move: measured, not kept.)
-#pragma unroll 1
-    for (int ch = 0; ch + 1 < NCHUNK; ch += 2) {
-        stage(f0, f1, ch + 1);
-        stage(f1, f0, (ch + 2 < NCHUNK) ? ch + 2 : ch + 1);         // past the end: re-read the last chunk (in bounds, unused)
-    }
-    if (NCHUNK & 1) {
-#pragma unroll
-        for (int u = 0; u < GRP; ++u) mfma_group(f0, u);
-    }
-}
-
-// Same contraction with ONE A register set that is reloaded in place (for TM = 8 under a 128-VGPR budget, where two
-// sets of 8 float4 do not fit): chunk = one plane group; the tiles are processed in pairs - 8 * TN MFMAs on 2 * TN
-// independent accumulators - and as soon as a pair's MFMAs have issued, its two A registers are reloaded with the next
-// chunk's data, so every load is (TM - 2) / TM of a chunk ahead of its use.  B fragments keep two sets.
-template <int NW, int CIN, int COUT, typename LI, int STRIDE, int TM, int TN>
-__device__ __forceinline__ void conv3x3_mfma_roll(const float* act, const float* __restrict__ Wg, const f32x4 (&b0)[1][TN],
-                                                  f32x4 (&acc)[TM][TN], int wave, int lane) {
-    constexpr int HOUT = LI::H / STRIDE;
-    constexpr int MT = HOUT * HOUT / 16, NT = COUT / 16;
-    constexpr int MG = MT / TM, NG = NT / TN;
-    constexpr int NGRP = CIN / 16, NCHUNK = 9 * NGRP;
-    static_assert(MG * NG == NW && TM % 2 == 0 && CIN % 16 == 0, "bad tiling");
-    const int mg = wave % MG, ng = wave / MG;
-    const int m = lane & 15, kq = lane >> 4;
-    // lane address of tile 0 / N-tile 0; the other tiles of the wave sit at compile-time offsets (immediates)
-    static_assert(HOUT == 8 || (TM * 16) % HOUT == 0 || HOUT % (TM * 16) == 0, "tile offsets must be wave-uniform constants");
-    int a_lane;
-    {
-        const int p = mg * TM * 16 + m;
-        const int oy = p / HOUT, ox = p - oy * HOUT;
-        a_lane = kq * LI::PSG + ((oy * STRIDE) * LI::WP + ox * STRIDE) * 4;
-    }
-    const int b_lane = (kq * COUT + ng * TN * 16 + m) * 4;
-    const unsigned a_addr0 = lds_byte_addr(act) + a_lane * 4;
-    auto a_imm = [](int i) {                               // byte offset of tile i from tile 0 (compile-time after unrolling)
-        return 4 * (HOUT == 8 ? i * 2 * STRIDE * LI::WP * 4 : (((i * 16) / HOUT) * STRIDE * LI::WP + ((i * 16) % HOUT) * STRIDE) * 4);
-    };
-    const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(Wg, 9 * CIN * COUT);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    auto a_chunk_off = [](int ch) {
-        const int tap = ch / NGRP, g0 = ch - tap * NGRP;
-        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
-        return g0 * 4 * LI::PSG + (ky * LI::WP + kx) * 4;
-    };
-    f32x4 fa[TM], fb0[TN], fb1[TN];
-    {
-        const int a_off = a_chunk_off(0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[i] = lds_read4(a_addr0 + a_off * 4 + a_imm(i));
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb0[j] = b0[0][j];
-    }
-    auto chunk = [&](const f32x4 (&bc)[TN], f32x4 (&bn)[TN], int nxt_ch) {
-        unsigned ab = a_addr0 + a_chunk_off(nxt_ch) * 4;
-        asm("" : "+v"(ab));
-#pragma unroll
-        for (int j = 0; j < TN; ++j) bn[j] = buf_read4(wrsrc, b_lane * 4 + j * 256, nxt_ch * (16 * COUT) * 4);
-#pragma unroll
-        for (int ip = 0; ip < TM; ip += 2) {
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-                for (int i = ip; i < ip + 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bc[j][s4], fa[i][s4], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = ip; i < ip + 2; ++i) fa[i] = lds_read4(ab + a_imm(i));
-        }
-    };
-#pragma unroll 1
-    for (int ch = 0; ch + 1 < NCHUNK; ch += 2) {
-        chunk(fb0, fb1, ch + 1);
-        chunk(fb1, fb0, (ch + 2 < NCHUNK) ? ch + 2 : ch + 1);
-    }
-    if (NCHUNK & 1) {
-#pragma unroll
-        for (int s4 = 0; s4 < 4; ++s4)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb0[j][s4], fa[i][s4], acc[i][j], 0, 0, 0);
-    }
-}
-
-// conv0 (1 -> COUT channels, K = 9 taps padded to 12) on the matrix cores as well: A[m][k] = the padded standardised
-// patch at (pixel m, tap k), B = packed [12][COUT] taps (rows 9..11 zero), accumulators start at the bias, so the result
-// is the fmaf chain bias, tap 0, ..., tap 8 (+ three exact fma(x, 0, acc)).  3 MFMAs per tile instead of 9 * COUT VALU
-// FMAs per pixel behind dependent LDS weight reads.
-template <int NW, int COUT, int TM, int TN>
-__device__ __forceinline__ void conv0_load_w(const float* __restrict__ W0, const float* __restrict__ bias, float (&b)[3][TN],
-                                             f32x4 (&bv)[TN], int wave, int lane) {
-    constexpr int MG = 64 / TM;
-    const int ng = wave / MG, m = lane & 15, kq = lane >> 4;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = (ng * TN + j) * 16 + m;
-#pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3) b[s3][j] = W0[(4 * s3 + kq) * COUT + n];
-        bv[j] = *reinterpret_cast<const f32x4*>(&bias[(ng * TN + j) * 16 + 4 * kq]);     // accumulator rows 4g..4g+3 = channels
-    }
-}
-
-template <int NW, int COUT, int TM, int TN>
-__device__ __forceinline__ void conv0_mfma(const float* patch, const float (&b)[3][TN], const f32x4 (&bv)[TN], f32x4 (&acc)[TM][TN],
-                                           int wave, int lane) {
-    constexpr int MT = 64, NT = COUT / 16, MG = MT / TM, NG = NT / TN;
-    static_assert(MG * NG == NW, "the waves must tile the layer exactly");
-    const int mg = wave % MG;
-    const int m = lane & 15, kq = lane >> 4;
-    int toff[3];
-#pragma unroll
-    for (int s3 = 0; s3 < 3; ++s3) {
-        const int t = 4 * s3 + kq;
-        toff[s3] = t < 9 ? (t / 3) * WP32 + (t % 3) : 0;            // taps 9..11: any valid address (weight is zero)
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int i = 0; i < TM; ++i) acc[i][j] = bv[j];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int p = (mg * TM + i) * 16 + m;
-        const int base = (p >> 5) * WP32 + (p & 31);
-        float av[3];
-#pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3) av[s3] = patch[base + toff[s3]];
-#pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s3][j], av[s3], acc[i][j], 0, 0, 0);
-    }
-}
-
-// Epilogue: (+ bias,) ReLU, write the wave's tiles into the LDS layout LO read by the NEXT layer: lane (n = pixel of the
-// tile, g) holds channels 4g..4g+3 -> one float4 of plane group (N-tile * 4 + g).
-template <int COUT, typename LO, int TM, int TN, bool ADD_BIAS = true>
-__device__ __forceinline__ void store_tiles_lds(float* act, const f32x4 (&bias)[TN], const f32x4 (&acc)[TM][TN], int wave, int lane) {
-    constexpr int HOUT = LO::H;
-    constexpr int MT = HOUT * HOUT / 16, MG = MT / TM;
-    const int mg = wave % MG, ng = wave / MG;
-    const int n = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int p = (mg * TM + i) * 16 + n;
-        const int oy = p / HOUT, ox = p - oy * HOUT;
-        const int pbase = ((oy + 1) * LO::WP + ox + 1) * 4;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            f32x4 v = acc[i][j];
-            if (ADD_BIAS) v += bias[j];
-            v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
-            *reinterpret_cast<f32x4*>(&act[((ng * TN + j) * 4 + g) * LO::PSG + pbase]) = v;
-        }
-    }
-}
-
-// Same for the last trunk layer of HardNet: global [pixel p][channel c] = the head GEMM's K order (float4 = 4 channels).
-template <int COUT, int TM, int TN>
-__device__ __forceinline__ void store_tiles_global(float* __restrict__ dst, const f32x4 (&bias)[TN], const f32x4 (&acc)[TM][TN],
-                                                   int wave, int lane) {
-    constexpr int MT = 4, MG = MT / TM;
-    const int mg = wave % MG, ng = wave / MG;
-    const int n = lane & 15, g = lane >> 4;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int p = (mg * TM + i) * 16 + n;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            f32x4 v = acc[i][j] + bias[j];
-            v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
-            *reinterpret_cast<f32x4*>(dst + p * COUT + (ng * TN + j) * 16 + 4 * g) = v;
-        }
-    }
 }
 
 // AffNet / OriNet heads, first half, straight from the conv5 accumulators (no conv5 tensor in HBM): a lane owns channels

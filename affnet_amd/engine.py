@@ -96,6 +96,8 @@ def pack_state_dict(kind, sd):
     vars_ = [f32("features.%d.running_var" % i) for i in bn_idx]
     head_w = f32("features.19.weight")
     head_b = f32("features.19.bias") if "features.19.bias" in sd else None
+    if kind == _lib.NET_AFFNET_FULLCONV and head_b is None:
+        raise ValueError("AffNetFastFullConv: features.19.bias missing from the state dict")
     hbm = f32("features.20.running_mean") if kind == _lib.NET_HARDNET else None
     hbv = f32("features.20.running_var") if kind == _lib.NET_HARDNET else None
     keep += convs + means + vars_ + [head_w, head_b, hbm, hbv]
@@ -128,6 +130,31 @@ def cnn_forward(kind, packed, patches, scratch=None):
     ctx = utility_ctx(dev)
     rc = lib.affnet_cnn32_forward(ctx, kind, ptr(packed), ptr(patches), None, n, ptr(out), ptr(scratch), stream_of(dev))
     check(rc, ctx, "affnet_cnn32_forward")
+    return out
+
+
+def fullconv_forward(packed, img):
+    """(1,1,H,W) cuda fp32 -> (1,4,H,W): dense AffNetFastFullConv map (architectures.py:666-674)."""
+    img = img.contiguous().float()
+    h, w = img.size(2), img.size(3)
+    nbytes = lib.affnet_fullconv_scratch_bytes(h, w)
+    if nbytes == 0:
+        raise ValueError("image %dx%d too small for AffNetFastFullConv (LocalNorm2d(33) needs H, W >= 34; the reference raises too)" % (w, h))
+    dev = img.device
+    scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    out = torch.empty(1, 4, h, w, dtype=torch.float32, device=dev)
+    ctx = utility_ctx(dev)
+    check(lib.affnet_fullconv_forward(ctx, ptr(packed), ptr(img), h, w, ptr(out), ptr(scratch), stream_of(dev)), ctx, "affnet_fullconv_forward")
+    return out
+
+
+def local_norm(img):
+    """LocalNorm2d(33) (architectures.py:21-31) of a (1,1,H,W) cuda image."""
+    require_cuda(img, "image")
+    img = img.contiguous().float()
+    out = torch.empty_like(img)
+    ctx = utility_ctx(img.device)
+    check(lib.affnet_local_norm(ctx, ptr(img), ptr(out), img.size(2), img.size(3), stream_of(img.device)), ctx, "affnet_local_norm")
     return out
 
 

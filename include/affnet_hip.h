@@ -56,6 +56,8 @@ extern "C" {
 #define AFFNET_NET_AFFNET 0       /* architectures.py:204-252 AffNetFast               */
 #define AFFNET_NET_ORINET 1       /* architectures.py:33-82   OriNetFast               */
 #define AFFNET_NET_HARDNET 2      /* HardNet.py:61-101        HardNet                  */
+#define AFFNET_NET_AFFNET_FULLCONV 3 /* architectures.py:629-674 AffNetFastFullConv: same state-dict layout as AffNetFast (the
+                                      * shipped AffNet.pth loads unchanged), evaluated densely on whole images (OnePassSIR)   */
 
 typedef struct affnet_ctx affnet_ctx;
 
@@ -204,6 +206,26 @@ int affnet_cnn32_forward(affnet_ctx* ctx, int net_kind, const float* d_packed, c
 int affnet_cnn32_forward_pyr(affnet_ctx* ctx, int net_kind, const float* d_packed, const float* d_lafs,
                              const int32_t* d_ids, const int32_t* d_count, int n_max, float* d_out,
                              float* d_scratch, void* stream);
+
+/* ---- fully-convolutional AffNet + 2-D NMS (the OnePassSIR path) ------------------------------- */
+
+/* LocalNorm2d(33): (x - mean33) / (sqrt|E33[x^2] - mean33^2| + 1e-10) clamped to [-6, 6], reflect padding; the 33 x 33 box sums are
+ * accumulated in the reference's CPU order, so the result is bit-identical.  Replaces architectures.py:21-31.  h, w >= 17. */
+int affnet_local_norm(affnet_ctx* ctx, const float* d_in, float* d_out, int h, int w, void* stream);
+
+/* Bytes of device scratch affnet_fullconv_forward needs for an h x w image (0 if the image is too small: h, w >= 34). */
+size_t affnet_fullconv_scratch_bytes(int h, int w);
+
+/* Dense affine-shape map of one image: d_img (h, w) fp32 0..255 -> d_out (4, h, w) planar (a11, 0, a21, a22) = the rectified
+ * per-pixel shape matrix.  d_packed: affnet_cnn32_pack_weights(AFFNET_NET_AFFNET_FULLCONV, ...) blob on the device.
+ * Replaces AffNetFastFullConv.forward, architectures.py:666-674 (LocalNorm2d, reflect pad 14, six conv+BN+ReLU, 8x8 head,
+ * bilinear upsampling, tanh, rectifyAffineTransformationUpIsUpFullyConv LAF.py:293-297). */
+int affnet_fullconv_forward(affnet_ctx* ctx, const float* d_packed, const float* d_img, int h, int w, float* d_out, float* d_scratch,
+                            void* stream);
+
+/* NMS2d: out = x where x - maxpool3x3(x) + 1e-5 > 0 (and x > threshold when threshold > 1e-5), else 0.
+ * Replaces HandCraftedModules.py:194-206 (as shipped its constructor raises under Python 3: `padding = kernel_size/2`). */
+int affnet_nms2d(affnet_ctx* ctx, const float* d_in, float* d_out, int h, int w, float threshold, void* stream);
 
 /* ---- hand-crafted slot fillers --------------------------------------- */
 

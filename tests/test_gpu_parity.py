@@ -697,10 +697,11 @@ def test_two_contexts_two_host_threads(amd, nets):
     A.packed_weights(torch.device(DEV)); O.packed_weights(torch.device(DEV)); H.packed_weights(torch.device(DEV))   # shared, read-only from here on
     torch.cuda.synchronize()
     out, errs = {}, []
+    dets = [mk(), mk()]                 # built by the main thread: nn.Module.to() on the shared nets is not a thread-safe operation
 
     def worker(tid):
         try:
-            det, st = mk(), torch.cuda.Stream(device=DEV)
+            det, st = dets[tid], torch.cuda.Stream(device=DEV)
             with torch.cuda.stream(st):
                 for rep in range(6):
                     for i, x in enumerate(imgs):

@@ -1,0 +1,18 @@
+#!/bin/bash
+# Copies the judged summaries of a tools/gpu_full.sh run from gpurun_out/ (scratch) into profiles/ (tracked).  Usage: collect_profiles.sh r02_s1
+T=${1:?tag, e.g. r02_s1}
+cp gpurun_out/parity_report.json profiles/${T}_parity_report.json
+grep '^{' gpurun_out/bench_default.log > profiles/${T}_bench_default.json
+grep '^{' gpurun_out/bench_config2.log > profiles/${T}_bench_config2_latency.json
+grep '^{' gpurun_out/bench_h2d.log > profiles/${T}_bench_include_h2d.json
+grep '^{' gpurun_out/bench_spawn2_onedev.log > profiles/${T}_bench_gpus2_selfspawn_onedevice_gloo.json
+grep '^{' gpurun_out/bench_self_gather.log > profiles/${T}_bench_self_gather_rccl_1rank.json
+tail -n 1 gpurun_out/bench_gpus2_refused.log > profiles/${T}_bench_gpus2_refused_on_1gpu_box.txt
+cp gpurun_out/prof/run_kernel_stats.csv profiles/${T}_kernel_stats.csv
+cp gpurun_out/fetch_calibration.json profiles/${T}_fetch_calibration.json
+cp gpurun_out/pmc_summary.txt profiles/${T}_pmc_summary.txt
+cp gpurun_out/traffic.json profiles/${T}_traffic.json
+grep -E "passed|failed" gpurun_out/pytest_gpu.log | tail -n 1 > profiles/${T}_pytest_gpu_summary.txt
+grep -E "^(PASSED|FAILED)" gpurun_out/pytest_gpu.log >> profiles/${T}_pytest_gpu_summary.txt
+tail -n 1 gpurun_out/smoke.log >> profiles/${T}_pytest_gpu_summary.txt
+ls -la profiles/${T}_*
