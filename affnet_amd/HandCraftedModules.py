@@ -79,3 +79,24 @@ class AffineShapeEstimator(_HipHandCrafted):
         """(n,1,19,19) -> (n,2,2) rectified shape.  Extra positional arguments are ignored: the reference's batched_forward
         passes a kwargs dict positionally (Utils.py:54), which its own AffineShapeEstimator.forward rejects (TypeError)."""
         return self._run(x)[0]
+
+
+class NMS2d(nn.Module):
+    """HandCraftedModules.py:194-206: keeps x where x - maxpool3x3(x) + 1e-5 > 0 (and x > threshold when threshold > 1e-5).  The
+    reference's constructor raises under Python 3 (`padding = kernel_size/2` is a float); the integer padding it meant is used."""
+
+    def __init__(self, kernel_size=3, threshold=0):
+        super(NMS2d, self).__init__()
+        if kernel_size != 3:
+            raise NotImplementedError("the HIP kernel is the 3 x 3 NMS the reference uses")
+        self.eps, self.th = 1e-5, threshold
+
+    def forward(self, x):
+        engine.require_cuda(x, "response map")
+        if x.dim() != 4 or x.size(0) != 1 or x.size(1) != 1:
+            raise ValueError("expected a (1,1,H,W) response map")
+        x = x.contiguous().float()
+        out = torch.empty_like(x)
+        ctx = engine.utility_ctx(x.device)
+        check(lib.affnet_nms2d(ctx, ptr(x), ptr(out), x.size(2), x.size(3), float(self.th), engine.stream_of(x.device)), ctx, "affnet_nms2d")
+        return out

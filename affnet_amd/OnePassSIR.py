@@ -1,0 +1,116 @@
+"""OnePassSIR with the reference's constructor and forward() (OnePassSIR.py:14-153), executed on MI355X by libaffnet_hip.so:
+the affine shape comes from ONE dense evaluation of a fully-convolutional AffNet per pyramid octave instead of one CNN
+evaluation per candidate patch.
+
+* AffNet = affnet_amd.architectures.AffNetFastFullConv (native): one C call builds the pyramid, evaluates the dense net on level 0
+  of every octave (csrc/fullconv.hip) and runs the detector with the per-level top-k, the frame boundary test and the LAF
+  composition s * A_map[pixel] * mrSize (csrc/detect.hip); a second C call does orientation, denormalisation and descriptors;
+* AffNet = any callable image (1,1,h,w) -> (1,4,h,w) (the reference's slot signature, OnePassSIR.py:69): evaluated per octave by this
+  mirror, the maps are copied into the workspace and the same detector runs on them.
+
+As in the reference every pyramid octave must be at least 34 px wide / high (LocalNorm2d(33) reflect-pads by 16): construct with
+border >= 15 like the reference's scripts (extract_geom_and_desc_upisup.py:63).  The reference's own default AffNet slot
+(AffineShapeEstimator, a per-patch module) cannot produce a dense map and fails there as well: AffNet is required here.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib, engine
+from ._lib import lib, check, ptr
+from .architectures import _HipPatchNet, AffNetFastFullConv
+from .HandCraftedModules import OrientationDetector, _HipHandCrafted
+
+
+class OnePassSIR(nn.Module):
+    def __init__(self, border=16, num_features=500, patch_size=32, mrSize=3.0, nlevels=3, th=None, num_Baum_iters=0, init_sigma=1.6,
+                 RespNet=None, OriNet=None, AffNet=None):
+        super(OnePassSIR, self).__init__()
+        self.mrSize, self.PS, self.b = mrSize, patch_size, border
+        self.num, self.th = num_features, th
+        if th is not None:          # OnePassSIR.py:31-34
+            self.num = -1
+        else:
+            self.th = 0
+        self.nlevels, self.num_Baum_iters, self.init_sigma = nlevels, num_Baum_iters, init_sigma
+        if RespNet is not None:
+            raise NotImplementedError("OnePassSIR mirror: custom RespNet slot not wired (ScaleSpaceAffinePatchExtractor supports it)")
+        if AffNet is None:
+            raise ValueError("OnePassSIR needs a dense AffNet (AffNetFastFullConv or any image -> (1,4,h,w) callable); the reference's default "
+                             "AffineShapeEstimator is a per-patch module and fails in OnePassSIR.py:69 as well")
+        self.AffNet = AffNet
+        self.OriNet = OriNet if OriNet is not None else OrientationDetector(patch_size=19)       # OnePassSIR.py:44-47
+        if not isinstance(self.OriNet, (_HipPatchNet, _HipHandCrafted)):
+            raise NotImplementedError("OnePassSIR mirror: OriNet must be affnet_amd.OriNetFast or the default OrientationDetector")
+        self.scale_pyr = self.sigmas = self.pix_dists = self.aff_maps = None
+        self.max_keep, self.raw_div = 16384, 4
+        self._ctx = self._ctx_key = None
+        self.last_ids = None
+
+    def _context(self, x):
+        engine.require_cuda(x, "image")
+        if x.dim() != 4 or x.size(1) != 1 or x.size(0) < 1:
+            raise ValueError("expected a (B,1,H,W) image batch (B = 1: the reference's shape)")
+        key = (x.size(0), x.size(2), x.size(3), x.device, self.num, float(self.th), self.mrSize, self.b, self.init_sigma, self.nlevels, self.max_keep,
+               self.raw_div)
+        if self._ctx is None or self._ctx_key != key:
+            self._ctx = engine.Context(x.size(2), x.size(3), x.device, self.nlevels, self.init_sigma, self.b, self.mrSize, float(self.th), self.num,
+                                       self.num, self.max_keep, batch=x.size(0), baum_iters=0, raw_div=self.raw_div, onepass=True)
+            self._ctx_key = key
+        return self._ctx
+
+    def enqueue(self, x, do_ori=True, desc=None):
+        """Whole path without host synchronisation; x (B,1,H,W).  Returns capacity-sized device tensors + the device row counts."""
+        ctx = self._context(x)
+        dev, st = x.device, engine.stream_of(x.device)
+        img = x.contiguous().float()
+        B, F = x.size(0), ctx.cap_final
+        lafs = torch.empty(B, F, 2, 3, dtype=torch.float32, device=dev)
+        resp = torch.empty(B, F, dtype=torch.float32, device=dev)
+        ids = torch.empty(B, F, 3, dtype=torch.int32, device=dev)
+        count = torch.zeros(B, dtype=torch.int32, device=dev)
+        dsc = torch.empty(B, F, 128, dtype=torch.float32, device=dev) if desc is not None else None
+        if isinstance(self.AffNet, AffNetFastFullConv):
+            check(lib.affnet_detect_image_onepass(ctx.handle, ptr(self.AffNet.packed_weights(dev)), ptr(img), st), ctx.handle,
+                  "affnet_detect_image_onepass")
+        else:                       # foreign dense AffNet slot: any callable image -> (1,4,h,w), evaluated per octave (OnePassSIR.py:69)
+            check(lib.affnet_pyramid_build(ctx.handle, ptr(img), st), ctx.handle, "affnet_pyramid_build")
+            with torch.no_grad():
+                for b in range(B):
+                    pyr, maps = ctx.pyramid_views(b), ctx.affmap_views(b)
+                    for o in range(len(pyr)):
+                        maps[o].copy_(self.AffNet(pyr[o][0]).to(dev, torch.float32))
+            check(lib.affnet_detect_image_onepass(ctx.handle, None, None, st), ctx.handle, "affnet_detect_image_onepass")
+        nets = _lib.Nets()
+        if do_ori:
+            if isinstance(self.OriNet, _HipHandCrafted):
+                nets.h_orientation_window = C.cast(self.OriNet.window(), C.c_void_p)
+            else:
+                nets.d_orinet = self.OriNet.packed_weights(dev).data_ptr()
+        nets.d_hardnet = desc.packed_weights(dev).data_ptr() if desc is not None else None
+        check(lib.affnet_describe_detected(ctx.handle, C.byref(nets), int(bool(do_ori)), ptr(lafs), ptr(resp), ptr(ids), ptr(dsc), ptr(count), st),
+              ctx.handle, "affnet_describe_detected")
+        return {"LAFs": lafs, "responses": resp, "ids": ids, "descriptors": dsc, "count": count, "_img": img}
+
+    def run(self, x, do_ori=True, desc=None):
+        """x (1,1,H,W) -> dict(LAFs px (N,2,3), responses (N,), ids (N,3) = (octave, level - 1, pixel), descriptors (N,128) | None)."""
+        if x.size(0) != 1:
+            raise ValueError("run() / forward() are batch-size-1 like the reference; use enqueue() for batches")
+        r = self.enqueue(x, do_ori=do_ori, desc=desc)
+        ctx = self._ctx
+        self.scale_pyr = ctx.pyramid_views()
+        self.sigmas = [list(s) for s in ctx.plan.sigmas]
+        self.pix_dists = [list(p) for p in ctx.plan.pix_dists]
+        self.aff_maps = ctx.affmap_views()
+        ctx.read_counts()               # raises on capacity overflow / "no keypoints detected"
+        n = int(r["count"].item())
+        self.last_ids = r["ids"][0, :n]
+        dsc = r["descriptors"]
+        return {"LAFs": r["LAFs"][0, :n], "responses": r["responses"][0, :n], "ids": r["ids"][0, :n],
+                "descriptors": None if dsc is None else dsc[0, :n]}
+
+    def forward(self, x, do_ori=True):
+        """OnePassSIR.py:139-153: (LAFs in pixels (N,2,3), responses (N,))."""
+        r = self.run(x, do_ori=do_ori)
+        return r["LAFs"], r["responses"]

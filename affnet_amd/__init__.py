@@ -4,7 +4,8 @@ libaffnet_hip.so (affnet_amd/csrc, C ABI in include/affnet_hip.h); importing thi
 fails loudly if the library has not been built."""
 from . import _lib  # noqa: F401  (raises ImportError when libaffnet_hip.so is missing)
 from .SparseImgRepresenter import ScaleSpaceAffinePatchExtractor, get_geometry_and_descriptors  # noqa: F401
-from .architectures import AffNetFast, OriNetFast  # noqa: F401
+from .architectures import AffNetFast, OriNetFast, AffNetFastFullConv  # noqa: F401
+from .OnePassSIR import OnePassSIR  # noqa: F401
 from .HardNet import HardNet  # noqa: F401
 from . import LAF, HandCraftedModules, Losses, ReprojectionStuff  # noqa: F401
 from .synthetic import synthetic_image, synthetic_hardnet_state  # noqa: F401

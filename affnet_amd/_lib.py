@@ -27,6 +27,7 @@ class Config(C.Structure):
         ("level_blur", (C.c_float * (MAX_TAPS * MAX_TAPS)) * MAX_LEVELS),
         ("level_blur0_taps", C.c_int32 * MAX_LEVELS),
         ("level_blur0", (C.c_float * (MAX_TAPS * MAX_TAPS)) * MAX_LEVELS),
+        ("onepass", C.c_int32),
         ("mr_size", C.c_float), ("threshold", C.c_float),
         ("num_features", C.c_int32), ("num_prefilter", C.c_int32),
         ("max_raw_per_octave_div", C.c_int32), ("max_keep", C.c_int32), ("batch", C.c_int32), ("baum_iters", C.c_int32),
@@ -82,6 +83,9 @@ SYMBOLS = {
     "affnet_extract_features": (_I, [_P, C.POINTER(Nets), _P, _I, _P, _P, _P, _P, _P, _P]),
     "affnet_detect_image": (_I, [_P, _P, _P]),
     "affnet_detect_image_responses": (_I, [_P, _P, _P]),
+    "affnet_detect_image_onepass": (_I, [_P, _P, _P, _P]),
+    "affnet_affmap_offset": (C.c_int64, [_P, _I]),
+    "affnet_affmap_image_stride": (C.c_int64, [_P]),
     "affnet_describe_detected": (_I, [_P, C.POINTER(Nets), _I, _P, _P, _P, _P, _P, _P]),
     "affnet_profile_enable": (_I, [_P, _I]),
     "affnet_profile_read": (_I, [_P, C.POINTER(C.c_double * 8), C.POINTER(C.c_int32)]),

@@ -26,6 +26,7 @@ enum {
     CNT_DET,                                 // rows emitted by the detector
     CNT_SHAPED,                              // rows after the shape filter
     CNT_SURVIVED,                            // survivors of the shape filter before top-N
+    CNT_CAND2,                               // OnePassSIR: candidates that passed the per-level top-k and the boundary test
     CNT_POS0 = AFFNET_MAX_OCTAVES + 16,      // CNT_POS0 + (level-1)*AFFNET_MAX_OCTAVES + o : positive maxima of (octave, level)
     CNT_TOTAL = AFFNET_MAX_OCTAVES + 16 + (AFFNET_MAX_LEVELS - 2) * AFFNET_MAX_OCTAVES
 };
@@ -58,6 +59,15 @@ struct affnet_ctx {
     OctaveGeom oct[AFFNET_MAX_OCTAVES];
     // workspace layout (byte offsets from the workspace base)
     size_t off_pyr = 0, off_map = 0, off_raw = 0, off_cnt = 0, off_cand = 0, off_sel = 0, off_stage = 0;
+    // OnePassSIR extras (cfg.onepass != 0): dense affine-shape maps (4, h_o, w_o) per octave, the dense net's scratch, a second
+    // candidate list and the per-(octave, level) top-k table
+    size_t off_affmap = 0, off_dense = 0, off_cand2 = 0, off_lvltab = 0;
+    size_t aff_stride = 0;             // floats between the affine maps of consecutive images
+    size_t aff_off[AFFNET_MAX_OCTAVES] = {0};   // float offset of octave o's (4, h, w) map inside one image's block
+    size_t dense_stride = 0;           // floats of dense-net scratch per image
+    float* affmap = nullptr; float* dense = nullptr;
+    float* cand2_resp = nullptr; float* cand2_syx = nullptr; int32_t* cand2_ids = nullptr;
+    int32_t* lvltab = nullptr;
     size_t ws_bytes = 0;
     size_t pyr_floats = 0, map_bytes = 0, raw_total = 0, cand_cap = 0;
     int cap_pre = 0, cap_final = 0;

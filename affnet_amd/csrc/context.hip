@@ -113,6 +113,26 @@ extern "C" int affnet_ctx_create(affnet_ctx** out, int device, const affnet_conf
         const size_t hard = F * (8192 + 4 * 128), aff = P * 144;
         off += aff_align((hard > aff ? hard : aff) * sizeof(float));
     }
+    if (c.onepass) {
+        // OnePassSIR: dense affine-shape maps of every octave, the dense net's scratch (octave 0 is the largest), a second
+        // candidate list (7 floats per row like the first) and the per-(octave, level) top-k table
+        if (c.num_prefilter != c.num_features) { *out = ctx; return aff_fail(ctx, AFFNET_ERR_INVALID, "onepass: num_prefilter must equal num_features"); }
+        size_t aff = 0;
+        for (int o = 0; o < c.n_octaves; ++o) {
+            if (c.oct_h[o] < 34 || c.oct_w[o] < 34) {
+                *out = ctx;
+                return aff_fail(ctx, AFFNET_ERR_INVALID, "onepass: octave %d is %dx%d, LocalNorm2d(33) needs >= 34 px (the reference raises too: use "
+                                "border >= 15 like its scripts, so that the pyramid stops earlier)", o, c.oct_w[o], c.oct_h[o]);
+            }
+            ctx->aff_off[o] = aff; aff += aff_align((size_t)4 * c.oct_h[o] * c.oct_w[o] * sizeof(float)) / sizeof(float);
+        }
+        ctx->aff_stride = aff;
+        ctx->dense_stride = affnet_fullconv_scratch_bytes(c.oct_h[0], c.oct_w[0]) / sizeof(float);
+        ctx->off_affmap = off; off += aff_align(B * aff * sizeof(float));
+        ctx->off_dense = off; off += aff_align(B * ctx->dense_stride * sizeof(float));
+        ctx->off_cand2 = off; off += aff_align(B * ctx->cand_cap * 7 * sizeof(float));
+        ctx->off_lvltab = off; off += aff_align(B * (size_t)AFFNET_MAX_OCTAVES * AFFNET_MAX_LEVELS * 4 * sizeof(int32_t));
+    }
     ctx->ws_bytes = off;
     *out = ctx;
     return AFFNET_OK;
@@ -132,6 +152,12 @@ extern "C" int64_t affnet_pyramid_level_offset(const affnet_ctx* ctx, int octave
 }
 
 extern "C" int64_t affnet_pyramid_image_stride(const affnet_ctx* ctx) { return ctx ? (int64_t)ctx->pyr_stride : 0; }
+
+extern "C" int64_t affnet_affmap_offset(const affnet_ctx* ctx, int octave) {
+    if (!ctx || !ctx->cfg.onepass || octave < 0 || octave >= ctx->cfg.n_octaves) return -1;
+    return (int64_t)(ctx->off_affmap / sizeof(float)) + (int64_t)ctx->aff_off[octave];
+}
+extern "C" int64_t affnet_affmap_image_stride(const affnet_ctx* ctx) { return (ctx && ctx->cfg.onepass) ? (int64_t)ctx->aff_stride : 0; }
 extern "C" int affnet_batch(const affnet_ctx* ctx) { return ctx ? ctx->B : 0; }
 
 extern "C" int affnet_bind_workspace(affnet_ctx* ctx, void* d_workspace, size_t bytes) {
@@ -173,6 +199,13 @@ extern "C" int affnet_bind_workspace(affnet_ctx* ctx, void* d_workspace, size_t 
     ctx->st_R = (float*)s; s += aff_align(F * 4 * sizeof(float));
     ctx->st_lafs_norm = (float*)s; ctx->st_lvl_ids = (int32_t*)((float*)s + 6 * F); s += aff_align(F * 9 * sizeof(float));
     ctx->st_hard_scratch = (float*)s;
+    if (ctx->cfg.onepass) {
+        ctx->affmap = (float*)(b + ctx->off_affmap);
+        ctx->dense = (float*)(b + ctx->off_dense);
+        float* c2 = (float*)(b + ctx->off_cand2);
+        ctx->cand2_resp = c2; ctx->cand2_syx = c2 + CC; ctx->cand2_ids = (int32_t*)(c2 + 4 * CC);
+        ctx->lvltab = (int32_t*)(b + ctx->off_lvltab);
+    }
     return AFFNET_OK;
 }
 

@@ -500,22 +500,159 @@ __global__ __launch_bounds__(256) void select_emit_kernel(const float* __restric
     out_ids[3 * r] = sel_ids[3 * i]; out_ids[3 * r + 1] = sel_ids[3 * i + 1]; out_ids[3 * r + 2] = sel_ids[3 * i + 2];
 }
 
+// ---- OnePassSIR: per-level top-k + frame boundary test on the candidate list, LAFs composed with the dense affine map ------------
+// (HandCraftedModules.py:292-363 NMS3dAndComposeAAff, OnePassSIR.py:87-93, LAF.py:442-449 sc_y_x_and_A2LAFs)
+struct AffMaps {
+    const float* map[AFFNET_MAX_OCTAVES];   // octave o: planar (4, h, w) = (a11, a12, a21, a22) per pixel, image 0
+    int hw[AFFNET_MAX_OCTAVES];
+    size_t img_stride;
+};
+
+// One workgroup per (octave, detection level, image).  The reference takes the top `num_features` responses of a LEVEL when the
+// level has more positive maxima than that (HandCraftedModules.py:323-327) - before OnePassSIR drops frames that touch the image
+// boundary - so the per-level cut cannot be folded into the global top-k as in the patch-based detector.  MSB-first 8-bit radix
+// select over the level's candidates -> tab[(o * MAX_LEVELS + l - 1) * 4 ..] = {mode, threshold key, ties to take, ties taken}.
+__global__ __launch_bounds__(1024) void onepass_level_select_kernel(const float* __restrict__ resp, const int32_t* __restrict__ ids, const int32_t* cnt,
+                                                                    int cand_cap, int N, int n_detect, int32_t* tab) {
+    __shared__ uint32_t hist[256];
+    __shared__ uint32_t s_prefix, s_mask, s_need;
+    const int o = blockIdx.x / n_detect, l1 = blockIdx.x - o * n_detect;     // l1 = level - 1 (the id stored with a candidate)
+    resp += (size_t)blockIdx.y * cand_cap; ids += (size_t)blockIdx.y * cand_cap * 3;
+    cnt += blockIdx.y * CNT_TOTAL;
+    tab += ((size_t)blockIdx.y * AFFNET_MAX_OCTAVES * AFFNET_MAX_LEVELS + o * AFFNET_MAX_LEVELS + l1) * 4;
+    int n = cnt[CNT_CAND];
+    if (n > cand_cap) n = cand_cap;
+    const int n_pos = cnt[CNT_POS0 + l1 * AFFNET_MAX_OCTAVES + o];
+    if (!(N > 0 && N < n_pos)) {
+        if (threadIdx.x == 0) { tab[0] = 0; tab[1] = 0; tab[2] = 0; tab[3] = 0; }
+        return;
+    }
+    if (threadIdx.x == 0) { s_prefix = 0; s_mask = 0; s_need = (uint32_t)N; }
+    __syncthreads();
+    for (int shift = 24; shift >= 0; shift -= 8) {
+        for (int i = threadIdx.x; i < 256; i += 1024) hist[i] = 0;
+        __syncthreads();
+        const uint32_t prefix = s_prefix, mask = s_mask;
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            if (ids[3 * i] != o || ids[3 * i + 1] != l1) continue;
+            const uint32_t k = order_key(resp[i]);
+            if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t need = s_need;
+            int d = 255;
+            for (; d > 0; --d) {
+                if (hist[d] >= need) break;
+                need -= hist[d];
+            }
+            s_need = need;
+            s_prefix = prefix | ((uint32_t)d << shift);
+            s_mask = mask | (255u << shift);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { tab[0] = 1; tab[1] = (int32_t)s_prefix; tab[2] = (int32_t)s_need; tab[3] = 0; }
+}
+
+__global__ __launch_bounds__(256) void onepass_filter_kernel(const float* __restrict__ resp, const float* __restrict__ syx, const int32_t* __restrict__ ids,
+                                                             int32_t* cnt, int cand_cap, int32_t* tab, AffMaps am, float* out_resp, float* out_syx,
+                                                             int32_t* out_ids) {
+    {
+        const size_t img = blockIdx.y;
+        resp += img * cand_cap; syx += img * cand_cap * 3; ids += img * cand_cap * 3; cnt += img * CNT_TOTAL;
+        tab += img * AFFNET_MAX_OCTAVES * AFFNET_MAX_LEVELS * 4;
+        out_resp += img * cand_cap; out_syx += img * cand_cap * 3; out_ids += img * cand_cap * 3;
+    }
+    int n = cnt[CNT_CAND];
+    if (n > cand_cap) n = cand_cap;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    bool keep = i < n;
+    int o = 0, l1 = 0, pix = 0;
+    float s = 0.f, y = 0.f, x = 0.f, r = 0.f;
+    if (keep) {
+        o = ids[3 * i]; l1 = ids[3 * i + 1]; pix = ids[3 * i + 2];
+        r = resp[i];
+        int32_t* t = tab + (o * AFFNET_MAX_LEVELS + l1) * 4;
+        if (t[0] == 1) {                                       // this level keeps only its top num_features responses
+            const uint32_t k = order_key(r), T = (uint32_t)t[1];
+            keep = k > T;
+            if (k == T) keep = atomicAdd(&t[3], 1) < t[2];
+        }
+    }
+    if (keep) {
+        s = syx[3 * i]; y = syx[3 * i + 1]; x = syx[3 * i + 2];
+        const float* m = am.map[o] + blockIdx.y * am.img_stride;
+        const int hw = am.hw[o];
+        // LAF = [s * A | (x, y)] (LAF.py:442-449); OnePassSIR.py:91 tests the frame with its 2x2 part times 3.0 (hard-coded)
+        const float b00 = (s * m[pix]) * 3.0f, b01 = (s * m[hw + pix]) * 3.0f, b10 = (s * m[2 * hw + pix]) * 3.0f, b11 = (s * m[3 * hw + pix]) * 3.0f;
+        const float px[4] = {-1.f, -1.f, 1.f, 1.f}, py[4] = {-1.f, 1.f, -1.f, 1.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {                          // checkTouchBoundary (LAF.py:98-104), bmm order like shape_filter_kernel
+            const float ox = fmaf(x, 1.0f, fmaf(b01, py[k], b00 * px[k]));
+            const float oy = fmaf(y, 1.0f, fmaf(b11, py[k], b10 * px[k]));
+            if (ox > 1.0f || ox < 0.0f || oy > 1.0f || oy < 0.0f) keep = false;
+        }
+    }
+    const unsigned long long bal = __ballot(keep);
+    int wbase = 0;
+    if (bal) {
+        if (lane == 0) wbase = atomicAdd(&cnt[CNT_CAND2], __popcll(bal));
+        wbase = __shfl(wbase, 0, 64);
+    }
+    if (keep) {
+        const int slot = wbase + __popcll(bal & ((1ull << lane) - 1ull));     // slot < cand_cap: cand2 has the capacity of the first list
+        out_resp[slot] = r;
+        out_syx[3 * slot] = s; out_syx[3 * slot + 1] = y; out_syx[3 * slot + 2] = x;
+        out_ids[3 * slot] = o; out_ids[3 * slot + 1] = l1; out_ids[3 * slot + 2] = pix;
+    }
+}
+
+__global__ void onepass_adopt_count_kernel(int32_t* cnt) {    // the global selection below runs on the filtered list
+    cnt += blockIdx.x * CNT_TOTAL;
+    cnt[CNT_CAND] = cnt[CNT_CAND2];
+}
+
+// select_emit_kernel with the OnePassSIR LAF composition: A = s * A_map[pixel] (LAF.py:444), then x mrSize (OnePassSIR.py:146).
+__global__ __launch_bounds__(256) void select_emit_onepass_kernel(const float* __restrict__ sel_resp, const float* __restrict__ sel_syx,
+                                                                  const int32_t* __restrict__ sel_ids, int32_t* cnt, int sel_cap,
+                                                                  const int32_t* __restrict__ rank, float mr, AffMaps am, float* out_resp,
+                                                                  float* out_lafs, int32_t* out_ids, int32_t* out_count) {
+    {
+        const size_t img = blockIdx.y;
+        sel_resp += img * sel_cap; sel_syx += img * sel_cap * 3; sel_ids += img * sel_cap * 3; cnt += img * CNT_TOTAL;
+        rank += img * sel_cap; out_resp += img * sel_cap; out_lafs += img * sel_cap * 6; out_ids += img * sel_cap * 3;
+        if (out_count) out_count += img;
+    }
+    int n = cnt[CNT_SEL];
+    if (n > sel_cap) n = sel_cap;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i == 0) { cnt[CNT_DET] = n; if (out_count) *out_count = n; }
+    if (i >= n) return;
+    const int r = rank[i];
+    out_resp[r] = sel_resp[i];
+    const float s = sel_syx[3 * i], y = sel_syx[3 * i + 1], x = sel_syx[3 * i + 2];
+    const int o = sel_ids[3 * i], pix = sel_ids[3 * i + 2];
+    const float* m = am.map[o] + blockIdx.y * am.img_stride;
+    const int hw = am.hw[o];
+    float* L = out_lafs + 6 * (size_t)r;
+    L[0] = mr * (s * m[pix]); L[1] = mr * (s * m[hw + pix]); L[2] = x;
+    L[3] = mr * (s * m[2 * hw + pix]); L[4] = mr * (s * m[3 * hw + pix]); L[5] = y;
+    out_ids[3 * r] = o; out_ids[3 * r + 1] = sel_ids[3 * i + 1]; out_ids[3 * r + 2] = pix;
+}
+
+// Stage 1 + 2 of the detector (shared by the patch-based and the OnePassSIR path): raw 3-D maxima per octave, then the
+// sequential-in-level octaveMap replay -> candidate list (ctx->cand_*, CNT_CAND) and per-level positive counts (CNT_POS0).
 // d_responses == NULL: Hessian responses computed from the pyramid in the workspace; otherwise response maps of a custom
 // RespNet slot, laid out like the pyramid (image stride = affnet_pyramid_image_stride, level offsets as the pyramid's).
-int aff_detect_impl(affnet_ctx* ctx, const float* d_responses, float* d_resp, float* d_lafs, int32_t* d_ids, int32_t* d_count, void* stream) {
-    if (!ctx || !ctx->ws || !d_resp || !d_lafs || !d_ids) return aff_fail(ctx, AFFNET_ERR_INVALID, "detect: context not bound or null output");
-    hipStream_t st = (hipStream_t)stream;
+static int detect_candidates(affnet_ctx* ctx, const float* d_responses, hipStream_t st) {
     const affnet_config& c = ctx->cfg;
     const int NLv = c.levels_per_octave;
     if (NLv < 3 || NLv > 8) return aff_fail(ctx, AFFNET_ERR_INVALID, "detect: levels_per_octave = %d (3..8 supported)", NLv);
     const int B = ctx->B;
     AFF_HIP(ctx, hipMemsetAsync(ctx->cnt, 0, (size_t)B * CNT_TOTAL * sizeof(int32_t), st));
     AFF_HIP(ctx, hipMemsetAsync(ctx->omap, 0, (size_t)B * ctx->map_stride, st));
-    const size_t P = (size_t)B * ctx->cap_pre;
-    AFF_HIP(ctx, hipMemsetAsync(d_resp, 0, P * sizeof(float), st));
-    AFF_HIP(ctx, hipMemsetAsync(d_lafs, 0, P * 6 * sizeof(float), st));
-    AFF_HIP(ctx, hipMemsetAsync(d_ids, 0, P * 3 * sizeof(int32_t), st));
-    AFF_HIP(ctx, hipMemsetAsync(ctx->st_rank, 0, P * sizeof(int32_t), st));
     ResolveParams rp;
     memset(&rp, 0, sizeof(rp));
     for (int o = 0; o < c.n_octaves; ++o) {
@@ -556,17 +693,92 @@ int aff_detect_impl(affnet_ctx* ctx, const float* d_responses, float* d_resp, fl
         }
     }
     AFF_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(select_prepare_kernel, dim3(B), dim3(1024), 0, st, ctx->cand_resp, ctx->cnt, (int)ctx->cand_cap, c.num_prefilter,
-                       ctx->cap_pre);
+    return AFFNET_OK;
+}
+
+// Stage 3: global top-C of a candidate list (CNT_CAND rows of resp / syx / ids) -> ranked rows in ctx->sel_* (CNT_SEL, st_rank).
+static int select_top(affnet_ctx* ctx, const float* resp, const float* syx, const int32_t* ids, hipStream_t st) {
+    const affnet_config& c = ctx->cfg;
+    const int B = ctx->B;
+    hipLaunchKernelGGL(select_prepare_kernel, dim3(B), dim3(1024), 0, st, resp, ctx->cnt, (int)ctx->cand_cap, c.num_prefilter, ctx->cap_pre);
     AFF_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(select_compact_kernel, dim3(aff_cdiv((int)ctx->cand_cap, 256), B), dim3(256), 0, st, ctx->cand_resp, ctx->cand_syx,
-                       ctx->cand_ids, ctx->cnt, (int)ctx->cand_cap, ctx->sel_resp, ctx->sel_syx, ctx->sel_ids, ctx->cap_pre);
+    hipLaunchKernelGGL(select_compact_kernel, dim3(aff_cdiv((int)ctx->cand_cap, 256), B), dim3(256), 0, st, resp, syx, ids, ctx->cnt,
+                       (int)ctx->cand_cap, ctx->sel_resp, ctx->sel_syx, ctx->sel_ids, ctx->cap_pre);
     AFF_LAUNCH_CHECK(ctx);
     const int nb = aff_cdiv(ctx->cap_pre, 256);
     hipLaunchKernelGGL(select_rank_kernel, dim3(nb, nb, B), dim3(256), 0, st, ctx->sel_resp, ctx->sel_ids, ctx->cnt, ctx->cap_pre, ctx->st_rank);
     AFF_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(select_emit_kernel, dim3(nb, B), dim3(256), 0, st, ctx->sel_resp, ctx->sel_syx, ctx->sel_ids, ctx->cnt, ctx->cap_pre,
-                       ctx->st_rank, c.mr_size, d_resp, d_lafs, d_ids, d_count);
+    return AFFNET_OK;
+}
+
+static int clear_outputs(affnet_ctx* ctx, float* d_resp, float* d_lafs, int32_t* d_ids, hipStream_t st) {
+    const size_t P = (size_t)ctx->B * ctx->cap_pre;
+    AFF_HIP(ctx, hipMemsetAsync(d_resp, 0, P * sizeof(float), st));
+    AFF_HIP(ctx, hipMemsetAsync(d_lafs, 0, P * 6 * sizeof(float), st));
+    AFF_HIP(ctx, hipMemsetAsync(d_ids, 0, P * 3 * sizeof(int32_t), st));
+    AFF_HIP(ctx, hipMemsetAsync(ctx->st_rank, 0, P * sizeof(int32_t), st));
+    return AFFNET_OK;
+}
+
+int aff_detect_impl(affnet_ctx* ctx, const float* d_responses, float* d_resp, float* d_lafs, int32_t* d_ids, int32_t* d_count, void* stream) {
+    if (!ctx || !ctx->ws || !d_resp || !d_lafs || !d_ids) return aff_fail(ctx, AFFNET_ERR_INVALID, "detect: context not bound or null output");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = clear_outputs(ctx, d_resp, d_lafs, d_ids, st);
+    if (rc) return rc;
+    rc = detect_candidates(ctx, d_responses, st);
+    if (rc) return rc;
+    rc = select_top(ctx, ctx->cand_resp, ctx->cand_syx, ctx->cand_ids, st);
+    if (rc) return rc;
+    const int nb = aff_cdiv(ctx->cap_pre, 256);
+    hipLaunchKernelGGL(select_emit_kernel, dim3(nb, ctx->B), dim3(256), 0, st, ctx->sel_resp, ctx->sel_syx, ctx->sel_ids, ctx->cnt, ctx->cap_pre,
+                       ctx->st_rank, ctx->cfg.mr_size, d_resp, d_lafs, d_ids, d_count);
+    AFF_LAUNCH_CHECK(ctx);
+    return AFFNET_OK;
+}
+
+int aff_fullconv_launch(affnet_ctx* ctx, const float* packed, const float* img, size_t img_stride, int h, int w, float* out, size_t out_stride,
+                        float* scratch, size_t scratch_stride, int B, hipStream_t st);
+
+// OnePassSIR.multiScaleDetectorAff (OnePassSIR.py:53-115) on the pyramid in the workspace.  d_packed_fullconv != NULL: the dense
+// AffNetFastFullConv maps of every octave are computed here (level 0 of each octave, OnePassSIR.py:69); NULL: the caller has written
+// them into the workspace (affnet_affmap_offset) - the slot form for a foreign dense AffNet.  Results go to the context's internal
+// detection list, consumed by affnet_describe_detected (with nets->d_affnet == NULL: no per-patch shape stage).
+int aff_detect_onepass_impl(affnet_ctx* ctx, const float* d_packed_fullconv, hipStream_t st) {
+    if (!ctx || !ctx->ws) return aff_fail(ctx, AFFNET_ERR_INVALID, "detect_onepass: context not bound");
+    if (!ctx->cfg.onepass) return aff_fail(ctx, AFFNET_ERR_INVALID, "detect_onepass: the context was not created with cfg.onepass");
+    const affnet_config& c = ctx->cfg;
+    const int B = ctx->B;
+    AffMaps am;
+    memset(&am, 0, sizeof(am));
+    am.img_stride = ctx->aff_stride;
+    for (int o = 0; o < c.n_octaves; ++o) {
+        const OctaveGeom& g = ctx->oct[o];
+        am.map[o] = ctx->affmap + ctx->aff_off[o];
+        am.hw[o] = g.h * g.w;
+        if (d_packed_fullconv) {
+            int rc = aff_fullconv_launch(ctx, d_packed_fullconv, ctx->pyr + g.pyr_off, ctx->pyr_stride, g.h, g.w, ctx->affmap + ctx->aff_off[o],
+                                         ctx->aff_stride, ctx->dense, ctx->dense_stride, B, st);
+            if (rc) return rc;
+        }
+    }
+    int rc = clear_outputs(ctx, ctx->st_det_resp, ctx->st_det_lafs, ctx->st_det_ids, st);
+    if (rc) return rc;
+    rc = detect_candidates(ctx, nullptr, st);
+    if (rc) return rc;
+    const int n_detect = c.levels_per_octave - 2;
+    hipLaunchKernelGGL(onepass_level_select_kernel, dim3(c.n_octaves * n_detect, B), dim3(1024), 0, st, ctx->cand_resp, ctx->cand_ids, ctx->cnt,
+                       (int)ctx->cand_cap, c.num_features, n_detect, ctx->lvltab);
+    AFF_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(onepass_filter_kernel, dim3(aff_cdiv((int)ctx->cand_cap, 256), B), dim3(256), 0, st, ctx->cand_resp, ctx->cand_syx, ctx->cand_ids,
+                       ctx->cnt, (int)ctx->cand_cap, ctx->lvltab, am, ctx->cand2_resp, ctx->cand2_syx, ctx->cand2_ids);
+    AFF_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(onepass_adopt_count_kernel, dim3(B), dim3(1), 0, st, ctx->cnt);
+    AFF_LAUNCH_CHECK(ctx);
+    rc = select_top(ctx, ctx->cand2_resp, ctx->cand2_syx, ctx->cand2_ids, st);
+    if (rc) return rc;
+    const int nb = aff_cdiv(ctx->cap_pre, 256);
+    hipLaunchKernelGGL(select_emit_onepass_kernel, dim3(nb, B), dim3(256), 0, st, ctx->sel_resp, ctx->sel_syx, ctx->sel_ids, ctx->cnt, ctx->cap_pre,
+                       ctx->st_rank, c.mr_size, am, ctx->st_det_resp, ctx->st_det_lafs, ctx->st_det_ids, ctx->st_det_count);
     AFF_LAUNCH_CHECK(ctx);
     return AFFNET_OK;
 }

@@ -6,9 +6,9 @@
 //   image (h x w, fp32 0..255)
 //     -> local_norm_kernel      : (x - mean33) / (sqrt|E33[x^2] - mean33^2| + 1e-10) clamped to +-6, reflect padding.  The two
 //                                 33 x 33 box sums are accumulated per output pixel sequentially in row-major order in fp32 -
-//                                 exactly what ATen's CPU avg_pool2d does - so this stage is BIT-IDENTICAL to the reference
-//                                 (x^2 up to 65025 against window variances of a few units: E[x^2] - mean^2 cancels
-//                                 catastrophically, any other summation order moves the normalised image by 1e-3);
+//                                 exactly what ATen's CPU avg_pool2d does - so the sums are the reference's bit for bit and the
+//                                 normalised image agrees to 1 ulp (x^2 up to 65025 against window variances of a few units:
+//                                 E[x^2] - mean^2 cancels catastrophically, any other summation order moves it by 1e-3);
 //     -> dense_conv0_kernel     : reflect-pad by 14 (fused into the tile loader), conv 1 -> 16 on the matrix cores (K = 9 -> 12)
 //     -> dense_conv_kernel x 5  : 16->16, 16->32 /2, 32->32, 32->64 /2, 64->64; one workgroup = one 32 / 16 / 8-pixel square
 //                                 input tile (+1 px apron of REAL neighbours) staged in LDS in the trunk's channel-interleaved
@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256) void local_norm_kernel(const float* __restrict
     const int x0 = blockIdx.x * LN_T, y0 = blockIdx.y * LN_T;
     for (int i = threadIdx.x; i < LN_LW * LN_LW; i += 256) {
         const int ty = i / LN_LW, tx = i - ty * LN_LW;
-        const int gy = reflect_idx(min(y0 + ty, h + LN_R - 1) - LN_R, h), gx = reflect_idx(min(x0 + tx, w + LN_R - 1) - LN_R, w);
+        // tile (ty, tx) = source (y0 + ty - 16, x0 + tx - 16); rows / columns past h + 15 / w + 15 are never part of a valid window
+        const int gy = reflect_idx(min(y0 + ty, h + 2 * LN_R - 1) - LN_R, h), gx = reflect_idx(min(x0 + tx, w + 2 * LN_R - 1) - LN_R, w);
         tile[i] = in[(size_t)gy * w + gx];
     }
     __syncthreads();

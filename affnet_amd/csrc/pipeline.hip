@@ -86,6 +86,29 @@ extern "C" int affnet_detect_image(affnet_ctx* ctx, const float* d_img, void* st
     return AFFNET_OK;
 }
 
+int aff_detect_onepass_impl(affnet_ctx* ctx, const float* d_packed_fullconv, hipStream_t st);
+
+// OnePassSIR detector half (OnePassSIR.py:53-115,146): pyramid (when d_img != NULL; NULL = already built with
+// affnet_pyramid_build), dense AffNetFastFullConv map per octave (when d_packed_fullconv != NULL; NULL = the caller wrote the maps
+// of a foreign dense AffNet into the workspace at affnet_affmap_offset), Hessian / NMS / per-level top-k / boundary test / global
+// top-k, LAFs = mrSize * s * A_map[pixel].  Candidates go to the internal list consumed by affnet_describe_detected, which is
+// then called with nets->d_affnet == NULL (no per-patch shape stage): OriNet, denormalisation, level select, HardNet as usual.
+extern "C" int affnet_detect_image_onepass(affnet_ctx* ctx, const float* d_packed_fullconv, const float* d_img, void* stream) {
+    AFF_DEVICE(ctx);
+    if (!ctx || !ctx->ws) return aff_fail(ctx, AFFNET_ERR_INVALID, "detect_image_onepass: context not bound");
+    hipStream_t st = (hipStream_t)stream;
+    aff_prof_mark(ctx, 0, st);
+    if (d_img) {
+        int rc = affnet_pyramid_build(ctx, d_img, stream);
+        if (rc) return rc;
+    }
+    aff_prof_mark(ctx, 1, st);
+    int rc = aff_detect_onepass_impl(ctx, d_packed_fullconv, st);
+    if (rc) return rc;
+    aff_prof_mark(ctx, 9, st);
+    return AFFNET_OK;
+}
+
 extern "C" int affnet_describe_detected(affnet_ctx* ctx, const affnet_nets* nets, int do_ori, float* d_lafs_px, float* d_resp,
                                         int32_t* d_ids, float* d_desc, int32_t* d_count, void* stream) {
     AFF_DEVICE(ctx);

@@ -35,10 +35,12 @@ class Context(object):
     """One extractor instance on one device: config, workspace, pyramid views."""
 
     def __init__(self, height, width, device, n_levels, init_sigma, border, mr_size, threshold,
-                 num_features, num_prefilter, max_keep=16384, batch=1, baum_iters=0, raw_div=4):
+                 num_features, num_prefilter, max_keep=16384, batch=1, baum_iters=0, raw_div=4, onepass=False):
         self.plan = PyramidPlan(height, width, n_levels, init_sigma, border)
         self.batch = int(batch)
-        self.cfg = self.plan.fill_config(mr_size, threshold, num_features, num_prefilter, max_keep, raw_div=raw_div, batch=self.batch, baum_iters=baum_iters)
+        self.onepass = bool(onepass)
+        self.cfg = self.plan.fill_config(mr_size, threshold, num_features, num_prefilter, max_keep, raw_div=raw_div, batch=self.batch, baum_iters=baum_iters,
+                                         onepass=onepass)
         self.device = device
         self.handle = C.c_void_p()
         idx = device.index if device.index is not None else torch.cuda.current_device()
@@ -63,6 +65,15 @@ class Context(object):
                 levels.append(self._ws_f32[off:off + h * w].view(1, 1, h, w))
             pyr.append(levels)
         return pyr
+
+    def affmap_views(self, image=0):
+        """OnePassSIR contexts: the dense affine-shape map of every octave of image `image` as (1,4,h,w) views into the workspace."""
+        base = image * lib.affnet_affmap_image_stride(self.handle)
+        out = []
+        for o, (h, w) in enumerate(self.plan.sizes):
+            off = base + lib.affnet_affmap_offset(self.handle, o)
+            out.append(self._ws_f32[off:off + 4 * h * w].view(1, 4, h, w))
+        return out
 
     def read_counts(self, allow_empty=False):
         """The one host read-back: [rows after detection, rows after the shape filter, overflow flag, raw maxima] summed over

@@ -242,6 +242,9 @@ def main():
     ap.add_argument("--config5", action="store_true",
                     help="BASELINE.json configs[4] instead of the headline configs[2]: 3840x2160 images, 8000 kp each (deep pyramid stress); "
                          "batch / chunk default to 8 / 8")
+    ap.add_argument("--onepass", action="store_true",
+                    help="OnePassSIR path (SURVEY section 8f row 4) instead of the headline path: affine shapes from ONE dense AffNetFastFullConv "
+                         "evaluation per octave (shipped AffNet.pth weights), border = 15 like the reference's scripts; a separately labelled line")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: ranks rendezvous (backend from AFFNET_BENCH_BACKEND, default gloo here), exchange fake records and "
                          "print the JSON skeleton - exercises the launch / world-size / gather bookkeeping on a CPU host")
@@ -367,6 +370,11 @@ def run(args, world):
         return net.to(dev)
 
     A, O, Hn = load("AffNet", affnet_amd.AffNetFast), load("OriNet", affnet_amd.OriNetFast), load("HardNet", affnet_amd.HardNet)
+    ONEPASS = args.onepass
+    if ONEPASS:
+        FC = affnet_amd.AffNetFastFullConv()
+        FC.load_state_dict(torch.load(os.path.join(ROOT, "pretrained", "AffNet.pth"), map_location="cpu", weights_only=False)["state_dict"])
+        FC = FC.to(dev)
     # global image i of a step lives on rank i % world (weak scaling: `batch` images per rank per step)
     seeds = [rank + world * j for j in range(args.batch)]
     CH = max(1, min(args.chunk, args.batch))
@@ -390,6 +398,9 @@ def run(args, world):
     dets = {}
     for ci, c in enumerate(chunks):
         k = (ci % S, c.size(0))
+        if k not in dets and ONEPASS:
+            dets[k] = affnet_amd.OnePassSIR(mrSize=5.192, num_features=NKP, border=15, num_Baum_iters=1, AffNet=FC, OriNet=O).to(dev)
+            dets[k]._context(c)
         if k not in dets:
             dets[k] = affnet_amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=NKP, border=5, num_Baum_iters=1,
                                                                 AffNet=A, OriNet=O).to(dev)
@@ -431,7 +442,10 @@ def run(args, world):
         results = [None] * len(cur_chunks)
         for ci, c in enumerate(cur_chunks):
             with torch.cuda.stream(streams[0] if PIPE else streams[ci % S]):
-                results[ci] = dets[(ci % S, c.size(0))].enqueue(c, do_ori=True, desc=Hn, det_stream=det_stream, input_ready=False)
+                if ONEPASS:
+                    results[ci] = dets[(ci % S, c.size(0))].enqueue(c, do_ori=True, desc=Hn)
+                else:
+                    results[ci] = dets[(ci % S, c.size(0))].enqueue(c, do_ori=True, desc=Hn, det_stream=det_stream, input_ready=False)
         step_no[0] += 1
         if LAZY:
             with torch.cuda.stream(streams[0]):
@@ -523,6 +537,8 @@ def run(args, world):
         metric = "keypoints/sec (detect+AffNet+OriNet+HardNet) per image, %d kp @%dx%d" % (NKP, W, H)
         if H2D:
             metric += " [PCIe-inclusive: images uploaded from pinned host memory every step]"
+        if ONEPASS:
+            metric = "keypoints/sec (OnePassSIR: detect + dense AffNetFastFullConv per octave + OriNet + HardNet) per image, %d kp @%dx%d" % (NKP, W, H)
         out = {
             "metric": metric,
             "value": kps / tmax, "unit": "keypoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -550,9 +566,13 @@ def run(args, world):
                          "affnet_tflops": 1.5 * kp_per_img * FLOP_AFF / (max(stage_ms[2], 1e-9) * 1e-3) / 1e12,
                          "orinet_tflops": kp_per_img * FLOP_ORI / (max(stage_ms[4], 1e-9) * 1e-3) / 1e12},
         }
-        if not args.no_secondary:
+        if ONEPASS:
+            out["stage_ms_per_image"]["detector"] = round(stage_ms[1], 4)
+            out["config"]["workload"] = ("OnePassSIR path (SURVEY section 8f row 4) on the BASELINE configs[2] images: batch of %d synthetic %dx%d images, %d kp, "
+                                         "border 15; the detector stage includes the dense AffNetFastFullConv of every octave" % (args.batch, W, H, NKP))
+        if not args.no_secondary and not ONEPASS:
             out["secondary_rooflines"] = secondary_rooflines(dets, chunks, stage_ms, dev)
-        if world == 1 and not args.no_cpu_baseline and not args.config5:
+        if world == 1 and not args.no_cpu_baseline and not args.config5 and not ONEPASS:
             base, kept = cpu_baseline()
             out["cpu_baseline"] = base
 

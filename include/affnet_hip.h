@@ -85,6 +85,10 @@ typedef struct affnet_config {
      * level_blur like every other octave (the usual case, init_sigma > 0.5). */
     int32_t level_blur0_taps[AFFNET_MAX_LEVELS];
     float level_blur0[AFFNET_MAX_LEVELS][AFFNET_MAX_TAPS * AFFNET_MAX_TAPS];
+    int32_t onepass;                       /* != 0: context for the OnePassSIR path (OnePassSIR.py:14-153): the workspace also holds a
+                                            * dense affine-shape map per octave + the dense net's scratch; num_prefilter must equal
+                                            * num_features (no shape-filter stage) and every octave must be >= 34 px (LocalNorm2d(33)
+                                            * reflect-pads by 16: the reference's scripts use border = 15)                       */
     float mr_size;                         /* mrSize (ctor kwarg, SparseImgRepresenter.py:19)          */
     float threshold;                       /* th; responses are clamp(resp - th, 0) (:77)              */
     int32_t num_features;                  /* N; <= 0: keep everything (th given => num = -1, :33-35)  */
@@ -210,7 +214,8 @@ int affnet_cnn32_forward_pyr(affnet_ctx* ctx, int net_kind, const float* d_packe
 /* ---- fully-convolutional AffNet + 2-D NMS (the OnePassSIR path) ------------------------------- */
 
 /* LocalNorm2d(33): (x - mean33) / (sqrt|E33[x^2] - mean33^2| + 1e-10) clamped to [-6, 6], reflect padding; the 33 x 33 box sums are
- * accumulated in the reference's CPU order, so the result is bit-identical.  Replaces architectures.py:21-31.  h, w >= 17. */
+ * accumulated in the reference's CPU order (bit-identical sums; the normalised value agrees to 1 ulp).  Replaces
+ * architectures.py:21-31.  h, w >= 17. */
 int affnet_local_norm(affnet_ctx* ctx, const float* d_in, float* d_out, int h, int w, void* stream);
 
 /* Bytes of device scratch affnet_fullconv_forward needs for an h x w image (0 if the image is too small: h, w >= 34). */
@@ -339,6 +344,20 @@ int affnet_detect_image(affnet_ctx* ctx, const float* d_img, void* stream);
 int affnet_detect_image_responses(affnet_ctx* ctx, const float* d_responses, void* stream);
 int affnet_describe_detected(affnet_ctx* ctx, const affnet_nets* nets, int do_ori, float* d_lafs_px, float* d_resp,
                              int32_t* d_ids, float* d_desc, int32_t* d_count, void* stream);
+
+/* OnePassSIR detector half (context created with cfg->onepass): replaces OnePassSIR.multiScaleDetectorAff + the x mrSize of
+ * OnePassSIR.forward (OnePassSIR.py:53-115,146), NMS3dAndComposeAAff (HandCraftedModules.py:292-363), sc_y_x_and_A2LAFs
+ * (LAF.py:442-449) and the boundary test of OnePassSIR.py:91.
+ *   d_img != NULL: the pyramid is built first; NULL: it has been built with affnet_pyramid_build;
+ *   d_packed_fullconv != NULL (affnet_cnn32_pack_weights(AFFNET_NET_AFFNET_FULLCONV, ...)): the dense affine-shape map of every
+ *   octave is computed from its level 0 (OnePassSIR.py:69); NULL: the caller has written the maps of a foreign dense AffNet,
+ *   planar (4, h_o, w_o) per octave, at affnet_affmap_offset(ctx, o) (+ affnet_affmap_image_stride per image).
+ * Follow with affnet_describe_detected(nets->d_affnet = NULL, ...): orientation, denormalisation, descriptors. */
+int affnet_detect_image_onepass(affnet_ctx* ctx, const float* d_packed_fullconv, const float* d_img, void* stream);
+/* Float offset (from the workspace base) of the (4, h_o, w_o) affine-shape map of octave o of image 0, and the floats between the
+ * maps of consecutive images; -1 / 0 when the context has no OnePassSIR areas. */
+int64_t affnet_affmap_offset(const affnet_ctx* ctx, int octave);
+int64_t affnet_affmap_image_stride(const affnet_ctx* ctx);
 
 /* Stage timing with HIP events recorded on the caller's stream around the stages of
  * affnet_extract_features (no host synchronisation while enabled; a ring of 256 calls).

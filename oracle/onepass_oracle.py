@@ -142,3 +142,6 @@ class OnePassOracle(object):
             return orc.denormalize_lafs(lafs, x.size(3), x.size(2)), resp
 
     __call__ = forward
+    # descriptor patches exactly as in the patch-based extractor (OnePassSIR.py:130-138 == SparseImgRepresenter.py:181-188)
+    level_for_lafs = orc.OracleExtractor.level_for_lafs
+    extract_patches_from_pyr = orc.OracleExtractor.extract_patches_from_pyr

@@ -1,0 +1,183 @@
+"""GPU parity tests of the OnePassSIR path (run with -m gpu on an MI355X): LocalNorm2d, the dense
+AffNetFastFullConv map, NMS2d and OnePassSIR end to end, against oracle/onepass_oracle.py (pinned bit-for-bit to the reference's
+classes and to OnePassSIR.py executed through a one-statement in-memory shim) and against tests/golden/onepass_synth.npz (the
+reference's own outputs on the authoring host).
+
+Bars: LocalNorm2d reproduces the CPU summation order of avg_pool2d -> within 1 ulp (see the test); the dense convolutions run on fp32 MFMA (other
+summation order than oneDNN) -> map within 5e-5; end to end: keys (octave, level, pixel) matched >= 99.5 %, responses bit-equal,
+LAFs within 1e-3 px, descriptors within 1e-3 (BASELINE north_star tolerance)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import affnet_oracle as orc
+import onepass_oracle as opo
+from conftest import record_parity
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def amd():
+    import affnet_amd
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return affnet_amd
+
+
+@pytest.fixture(scope="module")
+def nets(amd, weights):
+    FC = amd.AffNetFastFullConv(); FC.load_state_dict(weights["AffNet"]); FC = FC.to(DEV)
+    O = amd.OriNetFast(PS=32); O.load_state_dict(weights["OriNet"]); O = O.to(DEV)
+    H = amd.HardNet(); H.load_state_dict(weights["HardNet"]); H = H.to(DEV)
+    return FC, O, H
+
+
+def _keys(ids):
+    ids = np.asarray(ids).astype(np.int64)
+    return ids[:, 0] * (1 << 40) + ids[:, 1] * (1 << 32) + ids[:, 2]
+
+
+def _match(ids_got, keys_want):
+    kg, kw = _keys(ids_got), _keys(keys_want)
+    pos = {k: i for i, k in enumerate(kw)}
+    gi = [i for i, k in enumerate(kg) if k in pos]
+    return np.array(gi, dtype=np.int64), np.array([pos[kg[i]] for i in gi], dtype=np.int64)
+
+
+def test_local_norm_exact(amd, golden_dir):
+    from affnet_amd import engine
+    g = np.load(os.path.join(golden_dir, "onepass_synth.npz"))
+    for (h, w, seed, key) in ((240, 320, 1, "norm_240x320"), (131, 97, 4, "norm_131x97")):
+        x = orc.synthetic_image(h, w, seed)
+        got = engine.local_norm(x.to(DEV)).cpu().numpy()[0, 0]
+        want = opo.local_norm2d(x).numpy()[0, 0]
+        d, dg = np.abs(got - want), np.abs(got - g[key])
+        record_parity("LocalNorm2d(33) %dx%d" % (w, h), max_abs_diff_vs_oracle=float(d.max()), mismatching_vs_oracle=int((d > 0).sum()),
+                      max_abs_diff_vs_golden=float(dg.max()), mismatching_vs_golden=int((dg > 0).sum()), elements=int(d.size))
+        # The two 33 x 33 box sums follow avg_pool2d's CPU order exactly; what remains is the last bit of the closing
+        # (x - mean) / (sqrt|..| + eps): measured 1 ulp (4.8e-7 at |v| <= 6) in 0.7 % of the pixels against the reference on the
+        # authoring host - while the SAME torch build on the GPU box's EPYC differs from that host in 15 % of the pixels.
+        assert dg.max() <= 1e-6 and (dg > 0).mean() < 0.03, "LocalNorm2d vs the reference's output (golden): max %g, %d pixels" % (dg.max(), (dg > 0).sum())
+        assert d.max() <= 1e-6, "LocalNorm2d differs from the oracle on this host by %g" % d.max()
+    with pytest.raises(Exception):
+        engine.local_norm(torch.zeros(1, 1, 12, 40, device=DEV))          # reflect padding of 16 needs >= 17 px
+
+
+def test_dense_affnet_map(amd, nets, weights, golden_dir):
+    FC = nets[0]
+    g = np.load(os.path.join(golden_dir, "onepass_synth.npz"))
+    for (h, w, seed) in ((240, 320, 1), (131, 97, 4), (768, 1024, 2)):
+        x = orc.synthetic_image(h, w, seed)
+        got = FC(x.to(DEV)).cpu().numpy()
+        with torch.no_grad():
+            want = opo.affnet_fullconv_forward(weights["AffNet"], x).numpy()
+        assert got.shape == want.shape == (1, 4, h, w)
+        d = np.abs(got - want)
+        rec = {"max_abs_diff_vs_oracle": float(d.max()), "p99": float(np.percentile(d, 99)), "elements": int(d.size)}
+        if (h, w) == (240, 320):
+            rec["max_abs_diff_vs_golden"] = float(np.abs(got[0, :, ::4, ::4] - g["map_240x320_sub"]).max())
+        if (h, w) == (131, 97):
+            rec["max_abs_diff_vs_golden"] = float(np.abs(got[0] - g["map_131x97"]).max())
+        record_parity("AffNetFastFullConv dense map %dx%d" % (w, h), **rec)
+        assert d.max() < 5e-5, rec
+        assert rec.get("max_abs_diff_vs_golden", 0.0) < 5e-5, rec
+        assert np.all(got[0, 1] == 0.0)                                   # a12 = 0 * det
+    with pytest.raises(ValueError, match="too small"):
+        FC(torch.zeros(1, 1, 30, 64, device=DEV))
+
+
+def test_nms2d(amd):
+    from affnet_amd.HandCraftedModules import NMS2d
+    x = orc.hessian_response(orc.gaussian_blur(orc.synthetic_image(130, 70, 3), 1.6), 1.6)
+    for th in (0.0, 0.5):
+        got = NMS2d(threshold=th)(x.to(DEV)).cpu()
+        want = opo.nms2d(x, th)
+        assert torch.equal(got, want), "NMS2d(threshold=%g) differs" % th
+        assert int((got > 0).sum()) > 10
+
+
+def _check_onepass(amd, nets, weights, x, n, name, do_ori=True, th=None):
+    FC, O, H = nets
+    det = amd.OnePassSIR(mrSize=5.192, num_features=n, border=15, num_Baum_iters=1, th=th, AffNet=FC, OriNet=O).to(DEV)
+    res = det.run(x.to(DEV), do_ori=do_ori, desc=H)
+    ex = opo.OnePassOracle(mrSize=5.192, num_features=n, border=15, th=th, affnet_sd=weights["AffNet"], orinet_sd=weights["OriNet"])
+    Lw, rw = ex(x, do_ori=do_ori)
+    with torch.no_grad():
+        Dw = orc.hardnet_forward(weights["HardNet"], ex.extract_patches_from_pyr(Lw, PS=32))
+    L, r, D = res["LAFs"].cpu().numpy(), res["responses"].cpu().numpy(), res["descriptors"].cpu().numpy()
+    gi, wi = _match(res["ids"].cpu().numpy(), ex.keys.numpy())
+    dl = np.abs(L[gi] - Lw.numpy()[wi]).reshape(len(gi), -1).max(axis=1)
+    dd = np.abs(D[gi] - Dw.numpy()[wi]).max(axis=1)
+    rec = {"rows": int(L.shape[0]), "oracle_rows": int(Lw.shape[0]), "matched": int(len(gi)), "match_rate": len(gi) / float(max(Lw.shape[0], 1)),
+           "same_row_order": bool(len(gi) == Lw.shape[0] and np.array_equal(gi, wi)), "laf_max_px": float(dl.max()), "laf_p99_px": float(np.percentile(dl, 99)),
+           "laf_rows_within_1e-3": float((dl < 1e-3).mean()), "desc_max": float(dd.max()), "desc_rows_within_1e-3": float((dd < 1e-3).mean()),
+           "responses_equal": bool(np.array_equal(r[gi], rw.numpy()[wi]))}
+    record_parity(name, **rec)
+    print(name, rec)
+    assert abs(L.shape[0] - Lw.shape[0]) <= 0.005 * Lw.shape[0] + 1, rec
+    assert rec["match_rate"] >= 0.995 and rec["responses_equal"], rec
+    assert rec["laf_rows_within_1e-3"] >= 0.995 and rec["laf_max_px"] < 1e-2, rec
+    assert rec["desc_rows_within_1e-3"] >= 0.995, rec
+    return det, res, ex
+
+
+def test_onepass_sir_vs_oracle_and_golden(amd, nets, weights, golden_dir):
+    g = np.load(os.path.join(golden_dir, "onepass_synth.npz"))
+    x = orc.synthetic_image(240, 320, 1)
+    det, res, ex = _check_onepass(amd, nets, weights, x, 300, "OnePassSIR 320x240, 300 kp")
+    # the affine maps the detector used are the stand-alone dense maps
+    FC = nets[0]
+    assert len(det.aff_maps) == len(ex.aff_maps) == len(det.scale_pyr)
+    for o in range(len(det.aff_maps)):
+        assert torch.equal(det.aff_maps[o], FC(det.scale_pyr[o][0]))
+        assert float((det.aff_maps[o].cpu() - ex.aff_maps[o]).abs().max()) < 5e-5
+    # golden (the reference's own OnePassSIR output, rows in response order): match through the response bit pattern
+    L, r = res["LAFs"].cpu().numpy(), res["responses"].cpu().numpy()
+    pos = {v: i for i, v in enumerate(g["resp_n300"].view(np.uint32))}
+    gi = np.array([i for i, v in enumerate(r.view(np.uint32)) if v in pos], dtype=np.int64)
+    wi = np.array([pos[r.view(np.uint32)[i]] for i in gi], dtype=np.int64)
+    dl = np.abs(L[gi] - g["LAFs_n300"][wi]).reshape(len(gi), -1).max(axis=1)
+    record_parity("OnePassSIR 320x240, 300 kp vs the reference's golden output", matched=int(len(gi)), laf_max_px=float(dl.max()),
+                  laf_rows_within_1e_3=float((dl < 1e-3).mean()))
+    assert len(gi) >= 0.995 * 300 and (dl < 1e-3).mean() >= 0.995
+    # fewer detections than the budget: every candidate that survives the boundary test, (octave, level, pixel) order
+    FCn, O, H = nets
+    det2 = amd.OnePassSIR(mrSize=5.192, num_features=5000, border=15, num_Baum_iters=1, AffNet=FCn, OriNet=O).to(DEV)
+    L2, r2 = det2(x.to(DEV), do_ori=False)
+    assert abs(L2.shape[0] - g["LAFs_all_noori"].shape[0]) <= 2
+    if L2.shape[0] == g["LAFs_all_noori"].shape[0]:
+        assert np.array_equal(r2.cpu().numpy(), g["resp_all"])
+        assert np.abs(L2.cpu().numpy() - g["LAFs_all_noori"]).max() < 1e-3
+
+
+def test_onepass_sir_metric_size(amd, nets, weights):
+    """1024 x 768, 2000 kp: the per-level top-k really cuts here (octave 0 levels hold more than 2000 positive maxima)."""
+    _check_onepass(amd, nets, weights, orc.synthetic_image(768, 1024, 1), 2000, "OnePassSIR 1024x768, 2000 kp")
+
+
+def test_onepass_foreign_dense_affnet_slot_and_batch(amd, nets, weights):
+    """Any callable image -> (1,4,h,w) works as the AffNet slot (OnePassSIR.py:69); batches give per-image identical rows."""
+    FC, O, H = nets
+    x = orc.synthetic_image(240, 320, 1).to(DEV)
+    native = amd.OnePassSIR(mrSize=5.192, num_features=300, border=15, AffNet=FC, OriNet=O).to(DEV)
+    a = native.run(x, do_ori=True, desc=H)
+
+    class Foreign(torch.nn.Module):
+        def forward(self, img):
+            return FC(img)
+    b = amd.OnePassSIR(mrSize=5.192, num_features=300, border=15, AffNet=Foreign(), OriNet=O).to(DEV).run(x, do_ori=True, desc=H)
+    for k in ("LAFs", "responses", "ids", "descriptors"):
+        assert torch.equal(a[k], b[k]), k
+    xb = torch.cat([x, orc.synthetic_image(240, 320, 2).to(DEV), x], 0)
+    r = amd.OnePassSIR(mrSize=5.192, num_features=300, border=15, AffNet=FC, OriNet=O).to(DEV).enqueue(xb, do_ori=True, desc=H)
+    torch.cuda.synchronize()
+    for i in (0, 2):
+        n = int(r["count"][i])
+        assert n == a["LAFs"].shape[0]
+        for k in ("LAFs", "responses", "ids", "descriptors"):
+            assert torch.equal(r[k][i, :n], a[k]), (i, k)
+    with pytest.raises(Exception, match="34 px"):
+        amd.OnePassSIR(mrSize=5.192, num_features=300, border=5, AffNet=FC, OriNet=O).to(DEV).run(x)

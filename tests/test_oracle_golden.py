@@ -147,3 +147,25 @@ def test_metric_configuration_1024x768_n2000(golden_dir, weights):
     _close(r.numpy(), g["resp"], 1e-2, "responses")
     _close(L.numpy(), g["LAFs"], 1e-3, "LAFs px")
     _close(D.numpy(), g["desc"], 1e-4, "descriptors")
+
+
+def test_onepass_oracle_vs_reference_golden(golden_dir, weights):
+    """oracle/onepass_oracle.py (OnePassSIR path) against the reference's own outputs
+    (tests/golden/make_golden_onepass.py: AffNetFastFullConv / LocalNorm2d classes + OnePassSIR.py through the in-memory shim)."""
+    import onepass_oracle as opo
+    g = np.load(os.path.join(golden_dir, "onepass_synth.npz"))
+    x = orc.synthetic_image(240, 320, 1)
+    xs = orc.synthetic_image(131, 97, 4)
+    _close(opo.local_norm2d(x)[0, 0].numpy(), g["norm_240x320"], 0, "LocalNorm2d 240x320")
+    _close(opo.local_norm2d(xs)[0, 0].numpy(), g["norm_131x97"], 0, "LocalNorm2d 131x97")
+    with torch.no_grad():
+        _close(opo.affnet_fullconv_forward(weights["AffNet"], x)[0, :, ::4, ::4].numpy(), g["map_240x320_sub"], 1e-5, "dense map 240x320")
+        _close(opo.affnet_fullconv_forward(weights["AffNet"], xs)[0].numpy(), g["map_131x97"], 1e-5, "dense map 131x97")
+    ex = opo.OnePassOracle(mrSize=5.192, num_features=300, border=15, affnet_sd=weights["AffNet"], orinet_sd=weights["OriNet"])
+    L, r = ex(x, do_ori=True)
+    _close(r.numpy(), g["resp_n300"], 1e-3, "responses")
+    _close(L.numpy(), g["LAFs_n300"], 1e-3, "LAFs px")
+    ex = opo.OnePassOracle(mrSize=5.192, num_features=5000, border=15, affnet_sd=weights["AffNet"], orinet_sd=weights["OriNet"])
+    L, r = ex(x, do_ori=False)
+    assert L.shape == g["LAFs_all_noori"].shape
+    _close(L.numpy(), g["LAFs_all_noori"], 1e-3, "all LAFs")
