@@ -67,11 +67,14 @@ extern "C" int affnet_cnn32_pack_weights(int kind, const float* const* conv_w, c
         }
     } else if (kind == AFFNET_NET_AFFNET_FULLCONV) {
         if (!head_b) return AFFNET_ERR_INVALID;
-        // dense 8 x 8 head (architectures.py:652): [tap pp = ky * 8 + kx][channel group c / 4][output o][c % 4] - what one thread of
-        // fullconv_head_kernel multiplies with the float4 (4 channels of one pixel) it loads
+        // dense 8 x 8 head (architectures.py:652) as the A operand of fullconv_head_kernel's GEMM: rows n = o * 8 + kx (24 of 32
+        // used, the rest stay zero), K = (ky, c): [ky][c / 16][(c / 4) % 4][n][c % 4]
         for (int o = 0; o < 3; ++o)
             for (int c = 0; c < 64; ++c)
-                for (int pp = 0; pp < 64; ++pp) out[L.head_w + (((size_t)pp * 16 + c / 4) * 3 + o) * 4 + c % 4] = head_w[((size_t)o * 64 + c) * 64 + pp];
+                for (int ky = 0; ky < 8; ++ky)
+                    for (int kx = 0; kx < 8; ++kx)
+                        out[L.head_w + ((((size_t)ky * 4 + c / 16) * 4 + (c / 4) % 4) * 32 + o * 8 + kx) * 4 + c % 4] =
+                            head_w[((size_t)o * 64 + c) * 64 + ky * 8 + kx];
         memcpy(out + L.head_b, head_b, 3 * sizeof(float));
     } else {
         const int no = kind == AFFNET_NET_AFFNET ? 3 : 2;

@@ -85,7 +85,7 @@ static inline NetLayout net_layout(int kind) {
     }
     L.head_w = off;
     if (kind == AFFNET_NET_AFFNET) { off += 3 * 4096; L.head_b = off; off += 4; }
-    else if (kind == AFFNET_NET_AFFNET_FULLCONV) { off += 3 * 4096; L.head_b = off; off += 4; }   // [tap][channel / 4][output][channel % 4]
+    else if (kind == AFFNET_NET_AFFNET_FULLCONV) { off += 8 * 64 * 32; L.head_b = off; off += 4; }   // [ky][c / 16][(c / 4) % 4][n = o * 8 + kx (32)][c % 4]
     else if (kind == AFFNET_NET_ORINET) { off += 2 * 4096; L.head_b = off; off += 4; }
     else { off += (size_t)HEAD_K * 128; L.head_b = off; off += 128; }
     L.total = off;

@@ -14,7 +14,7 @@
 //                                 input tile (+1 px apron of REAL neighbours) staged in LDS in the trunk's channel-interleaved
 //                                 layout and contracted by the SAME conv3x3_mfma instantiations as the per-patch AffNet trunk
 //                                 (cnn_mfma.h); activations travel between layers as [C/4][Y][X] float4 planes in HBM
-//     -> fullconv_head_kernel   : 8 x 8 valid conv 64 -> 3 (+ bias), one thread per output pixel
+//     -> fullconv_head_kernel   : 8 x 8 valid conv 64 -> 3 (+ bias) on MFMA with the taps of a kernel row folded into N
 //     -> fullconv_finish_kernel : bilinear upsampling to h x w (align_corners = False), tanh, [[1+x0, 0],[x1, 1+x2]],
 //                                 up-is-up rectification -> planar (4, h, w) map (a11, 0, a21, a22)
 //
@@ -80,22 +80,23 @@ __global__ __launch_bounds__(256) void local_norm_kernel(const float* __restrict
     if (y0 + ty >= h || x0 + tx >= w) return;
     // 4 x 4 outputs per thread; input rows arrive in ascending order, every window is summed left to right: each accumulator
     // sees its 33 x 33 values in row-major order = the order of ATen's CPU avg_pool2d loop (acc = acc + v, fp32)
-    float s1[4][4], s2[4][4];
+    // (sum, sum of squares) of one output travel as a float2 and grow with one v_pk_add_f32 per window element
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 s12[4][4];
 #pragma unroll
     for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { s1[r][q] = 0.f; s2[r][q] = 0.f; }
+        for (int q = 0; q < 4; ++q) s12[r][q] = (f32x2){0.f, 0.f};
 #pragma unroll 1
     for (int i = 0; i < 4 + LN_K - 1; ++i) {
-        float v[LN_K + 3], v2[LN_K + 3];
+        f32x2 vv[LN_K + 3];
         const float4* row = reinterpret_cast<const float4*>(&tile[(ty + i) * LN_LW + tx]);
 #pragma unroll
         for (int k = 0; k < (LN_K + 3) / 4; ++k) {
             const float4 t = row[k];
-            v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+            vv[4 * k] = (f32x2){t.x, t.x * t.x}; vv[4 * k + 1] = (f32x2){t.y, t.y * t.y};      // x * x rounded to fp32 first, like the
+            vv[4 * k + 2] = (f32x2){t.z, t.z * t.z}; vv[4 * k + 3] = (f32x2){t.w, t.w * t.w};  // reference's `x*x` tensor
         }
-#pragma unroll
-        for (int k = 0; k < LN_K + 3; ++k) v2[k] = v[k] * v[k];       // x * x rounded to fp32 first, like the reference's `x*x` tensor
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int ti = i - r;                                   // window row of output row r (uniform across the workgroup)
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(256) void local_norm_kernel(const float* __restrict
 #pragma unroll
             for (int j = 0; j < LN_K; ++j)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { s1[r][q] = s1[r][q] + v[j + q]; s2[r][q] = s2[r][q] + v2[j + q]; }
+                for (int q = 0; q < 4; ++q) s12[r][q] = s12[r][q] + vv[j + q];
         }
     }
 #pragma unroll
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void local_norm_kernel(const float* __restrict
             const int x = x0 + tx + q;
             if (x >= w) break;
             const float xv = tile[(ty + r + LN_R) * LN_LW + tx + q + LN_R];
-            const float mean = s1[r][q] / 1089.0f, sq = s2[r][q] / 1089.0f;
+            const float mean = s12[r][q].x / 1089.0f, sq = s12[r][q].y / 1089.0f;
             const float mm = mean * mean;
             const float sd = sqrtf(fabsf(sq - mm)) + 1e-10f;
             const float nv = (xv - mean) / sd;
@@ -214,35 +215,69 @@ __global__ __launch_bounds__(512, 4) void dense_conv_kernel(DenseArgs a) {
     store_tiles_dense<HOUT, TM, TN, true>(out, a.Hout, a.Wout, Y0 / STRIDE, X0 / STRIDE, bias, acc, wave, lane);
 }
 
-// 8 x 8 valid head 64 -> 3 (+ bias): thread = output pixel; weights [tap][c/4][o][4] are wave-uniform (scalar loads).
+// 8 x 8 valid head 64 -> 3 (+ bias) on the matrix cores.  A direct GEMM would use 3 of the 16 MFMA rows; instead the taps of one
+// kernel ROW are folded into the N dimension: P[(o, kx)][y][x'] = sum over (ky, c) of W[o][c][ky][kx] * in[c][y + ky][x'] is a
+// GEMM with N = 3 * 8 = 24 (two 16-row tiles, 75 % useful), K = 8 * 64 = 512, and out[o][y][x] = bias + sum over kx of
+// P[(o, kx)][y][x + kx] is eight shifted adds per output.  One wave = one output row segment: 64 consecutive x' (four 16-pixel
+// MFMA tiles) -> 57 outputs; activation fragments are 16-byte loads straight from the [C/4][Y][X] float4 planes (16 consecutive
+// pixels = 256 contiguous bytes per channel quad), weights [ky][c/16][kq][n (32)][4] stream from L1 / L2.
+#define FH_SEG 57
 __global__ __launch_bounds__(256) void fullconv_head_kernel(const float* __restrict__ in, const float* __restrict__ hw, const float* __restrict__ hb,
                                                             float* __restrict__ out, int H4, int W4, int Hf, int Wf, size_t in_stride,
                                                             size_t out_stride) {
+    __shared__ float P[4][32 * 64];
     in += blockIdx.z * in_stride;
     out += blockIdx.z * out_stride;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (y >= Hf) return;
-    const int xc = x < Wf ? x : Wf - 1;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m = lane & 15, kq = lane >> 4;
+    const int y = min((int)blockIdx.y * 4 + wave, Hf - 1);             // tail rows recompute row Hf - 1 (never stored)
+    const int x0 = blockIdx.x * FH_SEG;
     const size_t plane = (size_t)H4 * W4 * 4;
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
-#pragma unroll 1
-    for (int ky = 0; ky < 8; ++ky)
-#pragma unroll 1
-        for (int kx = 0; kx < 8; ++kx) {
-            const float* wp = hw + (size_t)(ky * 8 + kx) * 16 * 12;
-            const float* ip = in + ((size_t)(y + ky) * W4 + xc + kx) * 4;
+    int xo[4];
 #pragma unroll
-            for (int g = 0; g < 16; ++g) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(ip + g * plane);
-                const f32x4 w0 = *reinterpret_cast<const f32x4*>(wp + g * 12), w1 = *reinterpret_cast<const f32x4*>(wp + g * 12 + 4),
-                            w2 = *reinterpret_cast<const f32x4*>(wp + g * 12 + 8);
+    for (int i = 0; i < 4; ++i) xo[i] = min(x0 + i * 16 + m, W4 - 1) * 4;   // columns past the tensor: clamped, their P values are never read
+    f32x4 acc[4][2];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { a0 = fmaf(v[j], w0[j], a0); a1 = fmaf(v[j], w1[j], a1); a2 = fmaf(v[j], w2[j], a2); }
-            }
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int ky = 0; ky < 8; ++ky) {
+        const float* rowp = in + (size_t)(y + ky) * W4 * 4;
+#pragma unroll
+        for (int G = 0; G < 4; ++G) {
+            f32x4 fb[4], fa[2];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const f32x4*>(rowp + (size_t)(G * 4 + kq) * plane + xo[i]);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fa[j] = *reinterpret_cast<const f32x4*>(hw + ((((ky * 4 + G) * 4 + kq) * 32) + j * 16 + m) * 4);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[j][s4], fb[i][s4], acc[i][j], 0, 0, 0);
         }
-    if (x >= Wf) return;
-    const size_t o = (size_t)y * Wf + x, pl = (size_t)Hf * Wf;
-    out[o] = a0 + hb[0]; out[pl + o] = a1 + hb[1]; out[2 * pl + o] = a2 + hb[2];
+    }
+    // acc[i][j][r] = P[n = 16 j + 4 kq + r][pixel 16 i + m]
+    float* Pw = P[wave];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) Pw[(16 * j + 4 * kq + r) * 64 + 16 * i + m] = acc[i][j][r];
+    __syncthreads();
+    const int yy = blockIdx.y * 4 + wave, x = x0 + lane;
+    if (yy >= Hf || lane >= FH_SEG || x >= Wf) return;
+    const size_t o = (size_t)yy * Wf + x, pl = (size_t)Hf * Wf;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int kx = 0; kx < 8; ++kx) sacc += Pw[(c * 8 + kx) * 64 + lane + kx];
+        out[c * pl + o] = sacc + hb[c];
+    }
 }
 
 // Bilinear upsampling (F.upsample / interpolate, align_corners = False: src = scale * (dst + 0.5) - 0.5 clamped at 0), tanh,
@@ -338,7 +373,7 @@ int aff_fullconv_launch(affnet_ctx* ctx, const float* packed, const float* img, 
     layer(5, bufA, bufB, g.H4, g.W4, g.H4, g.W4);
     hipLaunchKernelGGL((dense_conv_kernel<64, 64, 1, LayC4, 2, 1, 2, false>), dim3(aff_cdiv(g.W4, 8), aff_cdiv(g.H4, 8), B), dim3(512), 0, st, a);
     AFF_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(fullconv_head_kernel, dim3(aff_cdiv(g.Wf, 64), aff_cdiv(g.Hf, 4), B), dim3(256), 0, st, bufB, packed + L.head_w, packed + L.head_b,
+    hipLaunchKernelGGL(fullconv_head_kernel, dim3(aff_cdiv(g.Wf, FH_SEG), aff_cdiv(g.Hf, 4), B), dim3(256), 0, st, bufB, packed + L.head_w, packed + L.head_b,
                        bufA, g.H4, g.W4, g.Hf, g.Wf, scratch_stride, scratch_stride);
     AFF_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(fullconv_finish_kernel, dim3(aff_cdiv(w, 64), aff_cdiv(h, 4), B), dim3(256), 0, st, bufA, out, g.Hf, g.Wf, h, w, scratch_stride,

@@ -360,6 +360,8 @@ def run(args, world):
     import affnet_amd
     from affnet_amd import _lib
     from affnet_amd.synthetic import synthetic_image
+    if world > 1:                      # N ranks generate their synthetic images side by side: do not let each of them spin up every core
+        torch.set_num_threads(max(1, min(16, host_threads()[1] // world)))
 
     def load(name, cls):
         net = cls(PS=32) if name != "HardNet" else cls()
@@ -570,7 +572,7 @@ def run(args, world):
             out["stage_ms_per_image"]["detector"] = round(stage_ms[1], 4)
             out["config"]["workload"] = ("OnePassSIR path (SURVEY section 8f row 4) on the BASELINE configs[2] images: batch of %d synthetic %dx%d images, %d kp, "
                                          "border 15; the detector stage includes the dense AffNetFastFullConv of every octave" % (args.batch, W, H, NKP))
-        if not args.no_secondary and not ONEPASS:
+        if not args.no_secondary and not ONEPASS and world == 1:
             out["secondary_rooflines"] = secondary_rooflines(dets, chunks, stage_ms, dev)
         if world == 1 and not args.no_cpu_baseline and not args.config5 and not ONEPASS:
             base, kept = cpu_baseline()

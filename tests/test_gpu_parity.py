@@ -272,7 +272,7 @@ def _check_full(amd, nets, x, n, weights, want=None, min_match=0.995, name=None)
     print("rows within 1e-3 px: %.4f ; worst row %.3g px" % (inside.mean(), row_err.max()))
     _row_stats(name or "full path %dx%d n=%d" % (x.size(3), x.size(2), n), res["ids"].cpu().numpy(), L, D, r, ex.keys.numpy(), Lw.numpy(), Dw.numpy(),
                rw.numpy())
-    assert inside.mean() >= 0.995 and row_err.max() < 1e-2, "LAF error above tolerance"
+    assert inside.mean() >= 0.995 and row_err.max() < 5e-3, "LAF error above tolerance"
     assert dd[inside].max() < 1e-3 and np.percentile(dd, 99.5) < 1e-3, "descriptor error above 1e-3"
     assert np.array_equal(r[gi], rw.numpy()[wi]), "responses of matched keypoints must be bit-identical"
     # patches through the public API (level choice on the device instead of host scipy)
@@ -426,6 +426,8 @@ def test_iterated_affnet_shape(amd, nets, weights, iters):
     dd = np.abs(res["descriptors"].cpu().numpy()[gi] - Dw.numpy()[wi]).max()
     print("iters %d: matched %d / %d, LAF worst %.3g px, rows within 1e-3 px %.4f, descriptor worst %.3g" %
           (iters, len(gi), len(ex.keys), row_err.max(), (row_err < 1e-3).mean(), dd))
+    record_parity("num_Baum_iters = %d (AffNet) 320x240" % iters, keypoints=int(len(ex.keys)), matched=int(len(gi)), laf_max_px=float(row_err.max()),
+                  rows_within_1e_3=float((row_err < 1e-3).mean()), desc_max=float(dd))
     assert len(gi) >= 0.99 * len(ex.keys) and (row_err < 1e-3).mean() >= 0.99 and dd < 1e-3
     # differs from the single-iteration result (the iteration really happened)
     one = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=1, AffNet=A, OriNet=O).to(DEV)
@@ -448,6 +450,7 @@ def test_other_nlevels(amd, nets, weights, nlevels):
     gi, wi = _match(res["ids"].cpu().numpy(), ex.keys.numpy())
     row_err = np.abs(res["LAFs"].cpu().numpy()[gi] - Lw.numpy()[wi]).reshape(len(gi), -1).max(axis=1)
     print("nlevels %d: matched %d / %d, worst row %.3g px" % (nlevels, len(gi), len(ex.keys), row_err.max()))
+    record_parity("nlevels = %d 320x240" % nlevels, keypoints=int(len(ex.keys)), matched=int(len(gi)), laf_max_px=float(row_err.max()))
     assert len(gi) >= 0.99 * len(ex.keys) and (row_err < 1e-3).mean() >= 0.99
     assert np.array_equal(res["responses"].cpu().numpy()[gi], rw.numpy()[wi])
     assert np.abs(res["descriptors"].cpu().numpy()[gi] - Dw.numpy()[wi]).max() < 1e-3
@@ -481,7 +484,9 @@ def test_custom_respnet_slot(amd, nets, weights):
     gi, wi = _match(got["ids"].cpu().numpy(), ex.keys.numpy())
     row_err = np.abs(got["LAFs"].cpu().numpy()[gi] - Lw.numpy()[wi]).reshape(len(gi), -1).max(axis=1)
     print("custom RespNet: matched %d / %d, rows within 1e-3 px %.4f" % (len(gi), len(ex.keys), (row_err < 1e-3).mean()))
-    assert len(gi) >= 0.97 * len(ex.keys) and (row_err < 1e-3).mean() >= 0.99     # conv2d on GPU vs CPU: response ties can flip
+    record_parity("custom RespNet slot (sigma^2 |Laplacian|) 320x240", keypoints=int(len(ex.keys)), matched=int(len(gi)),
+                  rows_within_1e_3=float((row_err < 1e-3).mean()))
+    assert len(gi) >= 0.99 * len(ex.keys) and (row_err < 1e-3).mean() >= 0.99     # conv2d on GPU vs CPU: response ties can flip
     assert not torch.equal(got["ids"], builtin["ids"])
 
 
@@ -494,7 +499,9 @@ def test_handcrafted_default_slots(amd, nets, golden_dir):
     ang = OrientationDetector(patch_size=19)(p).cpu().numpy()
     same = np.abs(ang - g["ori_angles"]) < 1e-6
     print("orientation: %d / %d angles identical" % (same.sum(), len(same)))
-    assert same.mean() >= 0.95                    # argmax over 36 smoothed bins: only near-ties may flip (summation order)
+    record_parity("hand-crafted OrientationDetector(19): golden patches", patches=int(len(same)), identical_angles=int(same.sum()),
+                  flipped=[int(i) for i in np.nonzero(~same)[0]])
+    assert same.all(), "orientation bins flipped for golden patches %s (a flipped 10-degree bin is a wrong frame)" % np.nonzero(~same)[0].tolist()
     R = OrientationDetector(patch_size=19)(p, return_rot_matrix=True).cpu()
     assert np.abs(R.numpy()[same] - orc.angles_to_rotation(torch.from_numpy(g["ori_angles"])).numpy()[same]).max() < 1e-6
     A = AffineShapeEstimator(patch_size=19)(p).cpu().numpy()
@@ -506,19 +513,24 @@ def test_handcrafted_default_slots(amd, nets, golden_dir):
     assert np.array_equal(r.cpu().numpy(), g["default_resp"])
     row_err = np.abs(L.cpu().numpy() - g["default_LAFs"]).reshape(len(L), -1).max(axis=1)
     print("default extractor: rows within 1e-3 px %.4f (a flipped orientation bin rotates the frame)" % (row_err < 1e-3).mean())
-    assert (row_err < 1e-3).mean() >= 0.97
+    record_parity("default-constructed extractor (hand-crafted slots) 320x240", rows=int(len(L)), rows_within_1e_3=float((row_err < 1e-3).mean()),
+                  worst_row_px=float(row_err.max()))
+    assert (row_err < 1e-3).mean() >= 0.99
     # frames that differ must differ by a pure rotation: same centre, same determinant
     assert np.abs(L.cpu().numpy()[:, :, 2] - g["default_LAFs"][:, :, 2]).max() < 1e-3
     # LAFs2ellT (section 8f row 3) on the reference's own LAFs
     ell = amd.LAF.LAFs2ellT(torch.from_numpy(g["default_LAFs"]).to(DEV)).cpu().numpy()
     rel = np.abs(ell - g["default_ellT"]) / (np.abs(g["default_ellT"]) + 1e-6 * np.abs(g["default_ellT"]).max())
     print("LAFs2ellT: worst relative error %.3g" % rel.max())
+    record_parity("LAFs2ellT on the device", worst_relative_error=float(rel.max()))
     assert rel.max() < 2e-4 and np.array_equal(ell[:, :2], g["default_ellT"][:, :2])
     det = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=4).to(DEV)
     L, r = det(x, do_ori=False)
     assert L.shape == g["baum4_LAFs"].shape and np.array_equal(r.cpu().numpy(), g["baum4_resp"])
     row_err = np.abs(L.cpu().numpy() - g["baum4_LAFs"]).reshape(len(L), -1).max(axis=1)
     print("Baumberg x4: worst row %.3g px, rows within 1e-3 px %.4f" % (row_err.max(), (row_err < 1e-3).mean()))
+    record_parity("4 Baumberg iterations 320x240 vs golden", rows=int(len(L)), rows_within_1e_3=float((row_err < 1e-3).mean()), worst_row_px=float(row_err.max()),
+                  note="rows outside are near-singular shapes: the iteration amplifies any ulp")
     assert (row_err < 1e-3).mean() >= 0.99
 
 
@@ -539,6 +551,8 @@ def test_matching_snn_and_homography_check(amd, golden_dir):
     got = set(zip(t1.tolist(), t2.tolist()))
     ref = set(zip(g["tent1"].tolist(), g["tent2"].tolist()))
     print("tentatives: %d (reference %d), common %d" % (len(got), len(ref), len(got & ref)))
+    record_parity("SNN matching graf 1-6, 500 kp", tentatives=len(got), reference_tentatives=len(ref), common=len(got & ref),
+                  min_dist_max_abs_diff=float(np.abs(md.cpu().numpy() - g["min_dist"]).max()))
     assert len(got & ref) >= len(ref) - 1 and abs(len(got) - len(ref)) <= 1
     assert t1.tolist() == sorted(t1.tolist())                          # row order, like boolean-mask indexing
     # homography check on the reference's own tentatives: identical rows

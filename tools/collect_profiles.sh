@@ -9,10 +9,14 @@ grep '^{' gpurun_out/bench_spawn2_onedev.log > profiles/${T}_bench_gpus2_selfspa
 grep '^{' gpurun_out/bench_self_gather.log > profiles/${T}_bench_self_gather_rccl_1rank.json
 tail -n 1 gpurun_out/bench_gpus2_refused.log > profiles/${T}_bench_gpus2_refused_on_1gpu_box.txt
 cp gpurun_out/prof/run_kernel_stats.csv profiles/${T}_kernel_stats.csv
+[ -f gpurun_out/prof_onepass/run_kernel_stats.csv ] && cp gpurun_out/prof_onepass/run_kernel_stats.csv profiles/${T}_onepass_kernel_stats.csv
+grep '^{' gpurun_out/bench_onepass.log > profiles/${T}_bench_onepass.json
+grep '^{' gpurun_out/bench_config5.log > profiles/${T}_bench_config5.json
 cp gpurun_out/fetch_calibration.json profiles/${T}_fetch_calibration.json
 cp gpurun_out/pmc_summary.txt profiles/${T}_pmc_summary.txt
 cp gpurun_out/traffic.json profiles/${T}_traffic.json
 grep -E "passed|failed" gpurun_out/pytest_gpu.log | tail -n 1 > profiles/${T}_pytest_gpu_summary.txt
 grep -E "^(PASSED|FAILED)" gpurun_out/pytest_gpu.log >> profiles/${T}_pytest_gpu_summary.txt
 tail -n 1 gpurun_out/smoke.log >> profiles/${T}_pytest_gpu_summary.txt
+python tools/roofline_table.py profiles/${T} > profiles/${T}_roofline_table.md
 ls -la profiles/${T}_*

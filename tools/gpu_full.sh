@@ -13,10 +13,13 @@ timeout 300 python bench.py --include-h2d --no-cpu-baseline --no-secondary > gpu
 # N > 1 path on one device: self-spawned 2 ranks, RCCL cannot share one GPU between ranks -> gloo for the exchange, real kernels
 AFFNET_BENCH_ONE_DEVICE=1 AFFNET_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 2 --warmup 1 --batch 32 --no-secondary > gpurun_out/bench_spawn2_onedev.log 2>&1; echo "spawn2 exit: $?"; grep '^{' gpurun_out/bench_spawn2_onedev.log | cut -c1-300
 AFFNET_BENCH_SELF_GATHER=1 timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > gpurun_out/bench_self_gather.log 2>&1; echo "self-gather (1-rank RCCL) exit: $?"; grep '^{' gpurun_out/bench_self_gather.log | cut -c1-200
+timeout 300 python bench.py --onepass > gpurun_out/bench_onepass.log 2>&1; echo "onepass exit: $?"; grep '^{' gpurun_out/bench_onepass.log | cut -c1-300
+timeout 600 python bench.py --config5 > gpurun_out/bench_config5.log 2>&1; echo "config5 exit: $?"; grep '^{' gpurun_out/bench_config5.log | cut -c1-300
 timeout 120 python bench.py --gpus 2 --steps 1 --warmup 0 > gpurun_out/bench_gpus2_refused.log 2>&1; echo "gpus2 on a 1-GPU box exit (2 = refused loudly): $?"; tail -n 2 gpurun_out/bench_gpus2_refused.log
 CMD="python bench.py --steps 1 --warmup 1 --batch 64 --chunk 32 --no-cpu-baseline --no-secondary"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o run -- $CMD > gpurun_out/prof.log 2>&1; echo "prof exit: $?"
 f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -n 12 "$f" | cut -c1-200
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_onepass -o run -- python bench.py --onepass --steps 1 --warmup 1 > gpurun_out/prof_onepass.log 2>&1; echo "prof onepass exit: $?"
 if [ "$SKIP_PMC" != "1" ]; then
   timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/calib_f -o run -- python tools/fetch_calib.py run > gpurun_out/calib_f.log 2>&1; echo "calib fetch exit $?"
   timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/calib_w -o run -- python tools/fetch_calib.py run > gpurun_out/calib_w.log 2>&1; echo "calib write exit $?"
