@@ -14,7 +14,7 @@ grep '^{' gpurun_out/bench_onepass.log > profiles/${T}_bench_onepass.json
 grep '^{' gpurun_out/bench_config5.log > profiles/${T}_bench_config5.json
 cp gpurun_out/fetch_calibration.json profiles/${T}_fetch_calibration.json
 cp gpurun_out/pmc_summary.txt profiles/${T}_pmc_summary.txt
-cp gpurun_out/traffic.json profiles/${T}_traffic.json
+sed "s#gpurun_out/fetch_calibration.json#profiles/${T}_fetch_calibration.json#" gpurun_out/traffic.json > profiles/${T}_traffic.json
 grep -E "passed|failed" gpurun_out/pytest_gpu.log | tail -n 1 > profiles/${T}_pytest_gpu_summary.txt
 grep -E "^(PASSED|FAILED)" gpurun_out/pytest_gpu.log >> profiles/${T}_pytest_gpu_summary.txt
 tail -n 1 gpurun_out/smoke.log >> profiles/${T}_pytest_gpu_summary.txt
