@@ -114,18 +114,7 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
         ids = torch.empty(B, F, 3, dtype=torch.int32, device=dev)
         count = torch.zeros(B, dtype=torch.int32, device=dev)
         dsc = torch.empty(B, F, 128, dtype=torch.float32, device=dev) if desc is not None else None
-        nets = _lib.Nets()
-        if self.num_Baum_iters > 0:
-            if isinstance(self.AffNet, _HipHandCrafted):
-                nets.h_baumberg_window = C.cast(self.AffNet.window(), C.c_void_p)
-            else:
-                nets.d_affnet = self.AffNet.packed_weights(dev).data_ptr()
-        if do_ori:
-            if isinstance(self.OriNet, _HipHandCrafted):
-                nets.h_orientation_window = C.cast(self.OriNet.window(), C.c_void_p)
-            else:
-                nets.d_orinet = self.OriNet.packed_weights(dev).data_ptr()
-        nets.d_hardnet = desc.packed_weights(dev).data_ptr() if desc is not None else None
+        nets = self._nets(dev, do_ori, desc)
         if self.RespNet is not None:
             rmaps = self._response_pyramid(ctx, img)
             check(lib.affnet_detect_image_responses(ctx.handle, ptr(rmaps), engine.stream_of(dev)), ctx.handle, "affnet_detect_image_responses")
@@ -157,6 +146,28 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
         if B == 1:      # the reference's shapes
             lafs, resp, ids, dsc = lafs[0], resp[0], ids[0], (None if dsc is None else dsc[0])
         return {"LAFs": lafs, "responses": resp, "ids": ids, "descriptors": dsc, "count": count, "_img": img}
+
+    def _nets(self, dev, do_ori, desc):
+        nets = _lib.Nets()
+        if self.num_Baum_iters > 0:
+            if isinstance(self.AffNet, _HipHandCrafted):
+                nets.h_baumberg_window = C.cast(self.AffNet.window(), C.c_void_p)
+            else:
+                nets.d_affnet = self.AffNet.packed_weights(dev).data_ptr()
+        if do_ori:
+            if isinstance(self.OriNet, _HipHandCrafted):
+                nets.h_orientation_window = C.cast(self.OriNet.window(), C.c_void_p)
+            else:
+                nets.d_orinet = self.OriNet.packed_weights(dev).data_ptr()
+        nets.d_hardnet = desc.packed_weights(dev).data_ptr() if desc is not None else None
+        return nets
+
+    def capture(self, x, do_ori=False, desc=None):
+        """Captures the whole fused path for images of x's shape into ONE HIP graph (affnet_graph_capture_extract) and returns a
+        CapturedPath: `.image` is the static input tensor, `.launch(x)` copies x into it and replays the graph with a single launch
+        on the current stream (returns the same dict as enqueue()), `.run(x)` adds the count read-back and slicing of run().  For
+        callers that process one image at a time (hesaffnet.py:35-60): ~45 kernel launches per image become one."""
+        return CapturedPath(self, x, do_ori, desc)
 
     def run_batch(self, x, do_ori=False, desc=None):
         """(B,1,H,W) -> list of B per-image dicts (LAFs px (n_b,2,3), responses, ids, descriptors): one fused
@@ -281,6 +292,49 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
         check(lib.affnet_pyr_grid_sample(ctx.handle, ptr(norm), ptr(ids), None, n, PS, ptr(out), st), ctx.handle, "affnet_pyr_grid_sample")
         self.last_level_ids = ids
         return out
+
+
+class CapturedPath(object):
+    def __init__(self, det, x, do_ori, desc):
+        if not (det._native(det.AffNet) and det._native(det.OriNet)) or det.RespNet is not None:
+            raise NotImplementedError("graph capture needs the native slots (foreign slots run Python between the stages)")
+        ctx = det._context(x, allow_batch=True)
+        dev = x.device
+        self.det, self.ctx, self.do_ori, self.desc = det, ctx, bool(do_ori), desc
+        B, F = x.size(0), ctx.cap_final
+        self.image = x.contiguous().float().clone()
+        self.out = {"LAFs": torch.empty(B, F, 2, 3, dtype=torch.float32, device=dev), "responses": torch.empty(B, F, dtype=torch.float32, device=dev),
+                    "ids": torch.empty(B, F, 3, dtype=torch.int32, device=dev), "count": torch.zeros(B, dtype=torch.int32, device=dev),
+                    "descriptors": torch.empty(B, F, 128, dtype=torch.float32, device=dev) if desc is not None else None}
+        self._nets = det._nets(dev, do_ori, desc)              # packed weight tensors are owned (and kept alive) by the net modules
+        self._stream = torch.cuda.Stream(device=dev)           # capture needs an explicit stream; nothing executes on it
+        torch.cuda.synchronize(dev)
+        o = self.out
+        check(lib.affnet_graph_capture_extract(ctx.handle, C.byref(self._nets), ptr(self.image), int(self.do_ori), ptr(o["LAFs"]), ptr(o["responses"]),
+                                               ptr(o["ids"]), ptr(o["descriptors"]), ptr(o["count"]), C.c_void_p(self._stream.cuda_stream)),
+              ctx.handle, "affnet_graph_capture_extract")
+
+    def launch(self, x=None):
+        """One graph launch on the current stream; no host synchronisation.  x (same shape as at capture) is copied into `.image` first.
+        (The captured path contains only kernels of this library - its fills and copies are kernels too: hipMemsetAsync nodes of a
+        captured graph share blit state with eager null-stream memsets on ROCm 7.2 and faulted on replay.)"""
+        if x is not None:
+            self.image.copy_(x, non_blocking=True)
+        check(lib.affnet_graph_launch(self.ctx.handle, engine.stream_of(self.image.device)), self.ctx.handle, "affnet_graph_launch")
+        if self.image.size(0) == 1:
+            return {k: (v[0] if (v is not None and k != "count") else v) for k, v in self.out.items()}
+        return self.out
+
+    def run(self, x=None):
+        """launch() + the one count read-back: dict(LAFs px (N,2,3), responses, ids, descriptors) of a single image."""
+        if self.image.size(0) != 1:
+            raise ValueError("run() is for single images; use launch() for batches")
+        r = self.launch(x)
+        self.det._publish_pyramid(self.ctx)
+        self.ctx.read_counts()
+        n = int(r["count"].item())
+        dsc = r["descriptors"]
+        return {"LAFs": r["LAFs"][:n], "responses": r["responses"][:n], "ids": r["ids"][:n], "descriptors": None if dsc is None else dsc[:n]}
 
 
 def get_geometry_and_descriptors(img, det, desc, do_ori=True):

@@ -87,6 +87,8 @@ SYMBOLS = {
     "affnet_affmap_offset": (C.c_int64, [_P, _I]),
     "affnet_affmap_image_stride": (C.c_int64, [_P]),
     "affnet_describe_detected": (_I, [_P, C.POINTER(Nets), _I, _P, _P, _P, _P, _P, _P]),
+    "affnet_graph_capture_extract": (_I, [_P, C.POINTER(Nets), _P, _I, _P, _P, _P, _P, _P, _P]),
+    "affnet_graph_launch": (_I, [_P, _P]),
     "affnet_profile_enable": (_I, [_P, _I]),
     "affnet_profile_read": (_I, [_P, C.POINTER(C.c_double * 8), C.POINTER(C.c_int32)]),
     "affnet_read_counts": (_I, [_P, C.POINTER(C.c_int32 * 4), _P]),

@@ -94,6 +94,14 @@ struct affnet_ctx {
     int prof_calls = 0;
     // tuning aid (include/affnet_hip_debug.h): s_memtime stamp buffer of THIS context's CNN launches, or NULL
     unsigned long long* dbg_time = nullptr;
+    // the whole path captured as one HIP graph (affnet_graph_capture_extract): one launch instead of ~45 for latency-bound callers
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    ~affnet_ctx() {
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        for (auto& e : prof_ev) (void)hipEventDestroy(e);
+    }
 };
 
 // Every entry point that launches work makes the context's device current for the duration of the call and restores
@@ -137,6 +145,14 @@ int aff_fail(affnet_ctx* ctx, int code, const char* fmt, ...);
             return aff_fail(ctx, AFFNET_ERR_HIP, "kernel launch failed: %s (%s:%d)",                \
                             hipGetErrorString(e_), __FILE__, __LINE__);                            \
     } while (0)
+
+// Device-side fills and copies as plain kernels of this library (context.hip) instead of hipMemsetAsync / hipMemcpyAsync: the
+// runtime's blit path shares per-queue state with captured graph nodes (replaying a captured graph after eager null-stream
+// memsets faulted on ROCm 7.2), and a kernel of our own is also what a stream capture records most cheaply.
+int aff_zero_async(affnet_ctx* ctx, void* dst, size_t bytes, hipStream_t st);
+int aff_copy_async(affnet_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t st);
+// rows x width_bytes, row r at dst + r * dpitch / src + r * spitch (all multiples of 4 bytes)
+int aff_copy2d_async(affnet_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes, size_t rows, hipStream_t st);
 
 static inline size_t aff_align(size_t x, size_t a = 256) { return (x + a - 1) / a * a; }
 static inline int aff_cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -13,6 +13,51 @@ int aff_fail(affnet_ctx* ctx, int code, const char* fmt, ...) {
     return code;
 }
 
+// ---- fills / copies ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void aff_zero_kernel(unsigned char* __restrict__ p, size_t bytes) {
+    // 16-byte stores over the aligned body, byte stores for the (rare) unaligned head / tail
+    const size_t head = ((16 - ((size_t)p & 15)) & 15) < bytes ? ((16 - ((size_t)p & 15)) & 15) : bytes;
+    const size_t n16 = (bytes - head) / 16, tail0 = head + n16 * 16;
+    uint4* q = reinterpret_cast<uint4*>(p + head);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) q[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0) {
+        for (size_t i = threadIdx.x; i < head; i += 256) p[i] = 0;
+        for (size_t i = tail0 + threadIdx.x; i < bytes; i += 256) p[i] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void aff_copy2d_kernel(uint32_t* __restrict__ dst, size_t dpitch_w, const uint32_t* __restrict__ src, size_t spitch_w,
+                                                         size_t width_w) {
+    const uint32_t* s = src + (size_t)blockIdx.y * spitch_w;
+    uint32_t* d = dst + (size_t)blockIdx.y * dpitch_w;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < width_w; i += (size_t)gridDim.x * 256) d[i] = s[i];
+}
+
+int aff_zero_async(affnet_ctx* ctx, void* dst, size_t bytes, hipStream_t st) {
+    if (!dst || bytes == 0) return AFFNET_OK;
+    size_t blocks = (bytes / 16 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+    hipLaunchKernelGGL(aff_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (unsigned char*)dst, bytes);
+    AFF_LAUNCH_CHECK(ctx);
+    return AFFNET_OK;
+}
+
+int aff_copy2d_async(affnet_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes, size_t rows, hipStream_t st) {
+    if (rows == 0 || width_bytes == 0) return AFFNET_OK;
+    if (!dst || !src || ((size_t)dst & 3) || ((size_t)src & 3) || (dpitch & 3) || (spitch & 3) || (width_bytes & 3) || rows > 65535)
+        return aff_fail(ctx, AFFNET_ERR_INVALID, "copy2d: pointers, pitches and width must be multiples of 4 bytes, rows <= 65535");
+    size_t bx = (width_bytes / 4 + 255) / 256;
+    bx = bx < 1 ? 1 : (bx > 2048 ? 2048 : bx);
+    hipLaunchKernelGGL(aff_copy2d_kernel, dim3((unsigned)bx, (unsigned)rows), dim3(256), 0, st, (uint32_t*)dst, dpitch / 4, (const uint32_t*)src, spitch / 4,
+                       width_bytes / 4);
+    AFF_LAUNCH_CHECK(ctx);
+    return AFFNET_OK;
+}
+
+int aff_copy_async(affnet_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t st) {
+    return aff_copy2d_async(ctx, dst, bytes, src, bytes, bytes, 1, st);
+}
+
 extern "C" const char* affnet_version(void) { return "affnet_hip 0.2 (gfx950, hipcc, fp32 MFMA 16x16x4)"; }
 
 extern "C" const char* affnet_last_error(const affnet_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }

@@ -651,8 +651,8 @@ static int detect_candidates(affnet_ctx* ctx, const float* d_responses, hipStrea
     const int NLv = c.levels_per_octave;
     if (NLv < 3 || NLv > 8) return aff_fail(ctx, AFFNET_ERR_INVALID, "detect: levels_per_octave = %d (3..8 supported)", NLv);
     const int B = ctx->B;
-    AFF_HIP(ctx, hipMemsetAsync(ctx->cnt, 0, (size_t)B * CNT_TOTAL * sizeof(int32_t), st));
-    AFF_HIP(ctx, hipMemsetAsync(ctx->omap, 0, (size_t)B * ctx->map_stride, st));
+    { int zrc = aff_zero_async(ctx, ctx->cnt, (size_t)B * CNT_TOTAL * sizeof(int32_t), st); if (zrc) return zrc; }
+    { int zrc = aff_zero_async(ctx, ctx->omap, (size_t)B * ctx->map_stride, st); if (zrc) return zrc; }
     ResolveParams rp;
     memset(&rp, 0, sizeof(rp));
     for (int o = 0; o < c.n_octaves; ++o) {
@@ -713,10 +713,10 @@ static int select_top(affnet_ctx* ctx, const float* resp, const float* syx, cons
 
 static int clear_outputs(affnet_ctx* ctx, float* d_resp, float* d_lafs, int32_t* d_ids, hipStream_t st) {
     const size_t P = (size_t)ctx->B * ctx->cap_pre;
-    AFF_HIP(ctx, hipMemsetAsync(d_resp, 0, P * sizeof(float), st));
-    AFF_HIP(ctx, hipMemsetAsync(d_lafs, 0, P * 6 * sizeof(float), st));
-    AFF_HIP(ctx, hipMemsetAsync(d_ids, 0, P * 3 * sizeof(int32_t), st));
-    AFF_HIP(ctx, hipMemsetAsync(ctx->st_rank, 0, P * sizeof(int32_t), st));
+    { int zrc = aff_zero_async(ctx, d_resp, P * sizeof(float), st); if (zrc) return zrc; }
+    { int zrc = aff_zero_async(ctx, d_lafs, P * 6 * sizeof(float), st); if (zrc) return zrc; }
+    { int zrc = aff_zero_async(ctx, d_ids, P * 3 * sizeof(int32_t), st); if (zrc) return zrc; }
+    { int zrc = aff_zero_async(ctx, ctx->st_rank, P * sizeof(int32_t), st); if (zrc) return zrc; }
     return AFFNET_OK;
 }
 

@@ -207,13 +207,13 @@ extern "C" int affnet_shape_filter_select(affnet_ctx* ctx, const float* d_resp_i
         return aff_fail(ctx, AFFNET_ERR_INVALID, "shape_filter_select: bad argument");
     hipStream_t st = (hipStream_t)stream;
     const int P = ctx->cap_pre, F = ctx->cap_final, B = ctx->B;
-    AFF_HIP(ctx, hipMemsetAsync(d_resp_out, 0, (size_t)B * F * sizeof(float), st));
-    AFF_HIP(ctx, hipMemsetAsync(d_lafs_out, 0, (size_t)B * F * 6 * sizeof(float), st));
-    AFF_HIP(ctx, hipMemsetAsync(d_ids_out, 0, (size_t)B * F * 3 * sizeof(int32_t), st));
+    { int zrc = aff_zero_async(ctx, d_resp_out, (size_t)B * F * sizeof(float), st); if (zrc) return zrc; }
+    { int zrc = aff_zero_async(ctx, d_lafs_out, (size_t)B * F * 6 * sizeof(float), st); if (zrc) return zrc; }
+    { int zrc = aff_zero_async(ctx, d_ids_out, (size_t)B * F * 3 * sizeof(int32_t), st); if (zrc) return zrc; }
     hipLaunchKernelGGL(shape_filter_kernel, dim3(aff_cdiv(P, 256), B), dim3(256), 0, st, d_resp_in, d_lafs_in, d_A, d_count_in, P, ctx->st_key,
                        ctx->st_good);
     AFF_LAUNCH_CHECK(ctx);
-    AFF_HIP(ctx, hipMemsetAsync(ctx->st_rank, 0, (size_t)B * P * sizeof(int32_t), st));
+    { int zrc = aff_zero_async(ctx, ctx->st_rank, (size_t)B * P * sizeof(int32_t), st); if (zrc) return zrc; }
     AFF_HIP(ctx, hipMemset2DAsync(ctx->cnt + CNT_SURVIVED, CNT_TOTAL * sizeof(int32_t), 0, sizeof(int32_t), (size_t)B, st));
     const int nb = aff_cdiv(P, 256);
     hipLaunchKernelGGL(shape_count_kernel, dim3(nb, B), dim3(256), 0, st, ctx->st_good, d_count_in, P, ctx->cnt);

@@ -135,13 +135,13 @@ extern "C" int affnet_match_snn(affnet_ctx* ctx, const float* d_desc1, int n1, c
         return aff_fail(ctx, AFFNET_ERR_INVALID, "match_snn: bad argument");
     if (dim != 128) return aff_fail(ctx, AFFNET_ERR_INVALID, "match_snn: descriptor length %d (only 128 is built)", dim);
     hipStream_t st = (hipStream_t)stream;
-    AFF_HIP(ctx, hipMemsetAsync(d_count, 0, sizeof(int32_t), st));
+    { int zrc = aff_zero_async(ctx, d_count, sizeof(int32_t), st); if (zrc) return zrc; }
     if (n1 == 0) return AFFNET_OK;
     float* a_sq = (float*)d_scratch;
     float* b_sq = a_sq + n1;
     uint8_t* used = (uint8_t*)(b_sq + n2);
     int32_t* idx2 = (int32_t*)(used + aff_align((size_t)n2, 16));
-    AFF_HIP(ctx, hipMemsetAsync(used, 0, (size_t)n2, st));
+    { int zrc = aff_zero_async(ctx, used, (size_t)n2, st); if (zrc) return zrc; }
     hipLaunchKernelGGL(sqnorm_kernel, dim3(aff_cdiv(n1, 4)), dim3(256), 0, st, d_desc1, n1, dim, a_sq);
     hipLaunchKernelGGL(sqnorm_kernel, dim3(aff_cdiv(n2, 4)), dim3(256), 0, st, d_desc2, n2, dim, b_sq);
     hipLaunchKernelGGL(rowmin_dist_kernel<128>, dim3(aff_cdiv(n1, 64)), dim3(256), 0, st, d_desc1, n1, d_desc2, n2, a_sq, b_sq,

@@ -154,12 +154,11 @@ extern "C" int affnet_describe_detected(affnet_ctx* ctx, const affnet_nets* nets
         aff_prof_mark(ctx, 3, st);
         // num_Baum_iters == 0: detections pass through unchanged (C == N)
         if (F != P) return aff_fail(ctx, AFFNET_ERR_INVALID, "describe_detected: without AffNet num_prefilter must equal num_features");
-        AFF_HIP(ctx, hipMemcpyAsync(d_resp, ctx->st_det_resp, B * F * sizeof(float), hipMemcpyDeviceToDevice, st));
-        AFF_HIP(ctx, hipMemcpyAsync(ctx->st_lafs_shaped, ctx->st_det_lafs, B * F * 6 * sizeof(float), hipMemcpyDeviceToDevice, st));
-        AFF_HIP(ctx, hipMemcpyAsync(d_ids, ctx->st_det_ids, B * F * 3 * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-        AFF_HIP(ctx, hipMemcpyAsync(d_count, det_count, B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-        AFF_HIP(ctx, hipMemcpy2DAsync(ctx->cnt + CNT_SHAPED, CNT_TOTAL * sizeof(int32_t), det_count, sizeof(int32_t), sizeof(int32_t), B,
-                                      hipMemcpyDeviceToDevice, st));
+        { int crc = aff_copy_async(ctx, d_resp, ctx->st_det_resp, B * F * sizeof(float), st); if (crc) return crc; }
+        { int crc = aff_copy_async(ctx, ctx->st_lafs_shaped, ctx->st_det_lafs, B * F * 6 * sizeof(float), st); if (crc) return crc; }
+        { int crc = aff_copy_async(ctx, d_ids, ctx->st_det_ids, B * F * 3 * sizeof(int32_t), st); if (crc) return crc; }
+        { int crc = aff_copy_async(ctx, d_count, det_count, B * sizeof(int32_t), st); if (crc) return crc; }
+        { int crc = aff_copy2d_async(ctx, ctx->cnt + CNT_SHAPED, CNT_TOTAL * sizeof(int32_t), det_count, sizeof(int32_t), sizeof(int32_t), B, st); if (crc) return crc; }
     }
     aff_prof_mark(ctx, 4, st);
     if (do_ori) {
@@ -179,7 +178,7 @@ extern "C" int affnet_describe_detected(affnet_ctx* ctx, const affnet_nets* nets
     if (d_desc) {
         rc = affnet_level_select(ctx, d_lafs_px, d_count, F, 32, ctx->st_lvl_ids, ctx->st_lafs_norm, stream);
         if (rc) return rc;
-        AFF_HIP(ctx, hipMemsetAsync(d_desc, 0, B * F * 128 * sizeof(float), st));
+        { int zrc = aff_zero_async(ctx, d_desc, B * F * 128 * sizeof(float), st); if (zrc) return zrc; }
         aff_prof_mark(ctx, 6, st);
         rc = aff_hardnet_forward_pyr_marked(ctx, nets->d_hardnet, ctx->st_lafs_norm, ctx->st_lvl_ids, d_count, F, d_desc,
                                             ctx->st_hard_scratch, st);
@@ -199,4 +198,36 @@ extern "C" int affnet_extract_features(affnet_ctx* ctx, const affnet_nets* nets,
     int rc = affnet_detect_image(ctx, d_img, stream);
     if (rc) return rc;
     return affnet_describe_detected(ctx, nets, do_ori, d_lafs_px, d_resp, d_ids, d_desc, d_count, stream);
+}
+
+
+// ---- the whole path as ONE HIP graph ---------------------------------------------------------------------------------
+// affnet_extract_features enqueues ~45 kernels / memsets without ever touching the host, so for a fixed set of buffers it can be
+// stream-captured once and replayed with a single hipGraphLaunch: what a latency-bound caller (one image at a time, BASELINE
+// configs[1]) pays per call drops from ~45 launches to one.  Throughput callers (32 images per call) are GPU bound and gain nothing.
+extern "C" int affnet_graph_capture_extract(affnet_ctx* ctx, const affnet_nets* nets, const float* d_img, int do_ori, float* d_lafs_px, float* d_resp,
+                                            int32_t* d_ids, float* d_desc, int32_t* d_count, void* stream) {
+    AFF_DEVICE(ctx);
+    if (!ctx || !ctx->ws) return aff_fail(ctx, AFFNET_ERR_INVALID, "graph_capture: context not bound");
+    hipStream_t st = (hipStream_t)stream;
+    if (!st) return aff_fail(ctx, AFFNET_ERR_INVALID, "graph_capture: needs an explicit (non-null) stream - the legacy null stream cannot be captured");
+    if (ctx->prof_on) return aff_fail(ctx, AFFNET_ERR_INVALID, "graph_capture: switch stage profiling off first (its events are per call)");
+    if (ctx->graph_exec) { (void)hipGraphExecDestroy(ctx->graph_exec); ctx->graph_exec = nullptr; }
+    if (ctx->graph) { (void)hipGraphDestroy(ctx->graph); ctx->graph = nullptr; }
+    AFF_HIP(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    const int rc = affnet_extract_features(ctx, nets, d_img, do_ori, d_lafs_px, d_resp, d_ids, d_desc, d_count, stream);
+    hipGraph_t g = nullptr;
+    const hipError_t e = hipStreamEndCapture(st, &g);       // always end the capture, also after a failed enqueue
+    if (rc != AFFNET_OK) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess || !g) return aff_fail(ctx, AFFNET_ERR_HIP, "hipStreamEndCapture failed: %s", hipGetErrorString(e));
+    ctx->graph = g;
+    AFF_HIP(ctx, hipGraphInstantiate(&ctx->graph_exec, ctx->graph, nullptr, nullptr, 0));
+    return AFFNET_OK;
+}
+
+extern "C" int affnet_graph_launch(affnet_ctx* ctx, void* stream) {
+    AFF_DEVICE(ctx);
+    if (!ctx || !ctx->graph_exec) return aff_fail(ctx, AFFNET_ERR_INVALID, "graph_launch: nothing captured (affnet_graph_capture_extract first)");
+    AFF_HIP(ctx, hipGraphLaunch(ctx->graph_exec, (hipStream_t)stream));
+    return AFFNET_OK;
 }

@@ -204,8 +204,8 @@ extern "C" int affnet_pyramid_build(affnet_ctx* ctx, const float* d_img, void* s
                                        ctx->pyr_stride);
                 if (rc) return rc;
             } else {
-                AFF_HIP(ctx, hipMemcpy2DAsync(base, ctx->pyr_stride * sizeof(float), d_img, lvl * sizeof(float), lvl * sizeof(float),
-                                              (size_t)ctx->B, hipMemcpyDeviceToDevice, st));
+                int crc = aff_copy2d_async(ctx, base, ctx->pyr_stride * sizeof(float), d_img, lvl * sizeof(float), lvl * sizeof(float), (size_t)ctx->B, st);
+                if (crc) return crc;
             }
         }
         for (int l = 1; l < L; ++l) {

@@ -299,6 +299,22 @@ def config2_latency(args):
         lat.append(time.perf_counter() - t0)
     lat.sort()
     warm = lat[len(lat) // 2]
+    # the same call replayed as ONE HIP graph (affnet_graph_capture_extract): ~45 launches per image become one
+    glat, gerr = [], None
+    try:
+        cap = det.capture(x, do_ori=True, desc=Hn)
+        for i in range(len(lat) + 3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            cap.image.copy_(host, non_blocking=True)           # pinned host -> the captured input buffer
+            r2 = cap.run()
+            torch.cuda.synchronize()
+            if i >= 3:
+                glat.append(time.perf_counter() - t0)
+        same = all(torch.equal(r[k], r2[k]) for k in ("LAFs", "responses", "descriptors"))
+        glat.sort()
+    except Exception as e:                                      # noqa: BLE001  (reported in the line, the eager figures stand)
+        gerr, same = repr(e), False
     out = {"metric": "latency per image (hesaffnet.py test-graf/img1.png, 2000 kp, detect+AffNet+OriNet+HardNet, B=1, H2D included)",
            "value": warm * 1e3, "unit": "ms", "n_gpus": 1, "steps": len(lat), "warmup": 1, "ms_per_step": warm * 1e3,
            "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "tests/golden/graf_img1.png (byte copy of test-graf/img1.png)",
@@ -307,6 +323,10 @@ def config2_latency(args):
                       "keypoints": n},
            "cold_ms": cold * 1e3, "warm_ms_min": lat[0] * 1e3, "warm_ms_p90": lat[int(0.9 * len(lat))] * 1e3,
            "keypoints_per_s_warm": n / warm,
+           "hip_graph": ({"warm_ms": glat[len(glat) // 2] * 1e3, "warm_ms_min": glat[0] * 1e3, "keypoints_per_s_warm": n / glat[len(glat) // 2],
+                          "identical_to_eager": bool(same), "what": "the whole path captured once (affnet_graph_capture_extract) and replayed with a "
+                                                                    "single hipGraphLaunch per image; H2D into the captured input buffer included"}
+                         if glat else {"error": gerr}),
            "note": "cold = weight load + BN folding + packing + upload, context / workspace creation, HIP module load and the first call"}
     print(json.dumps(out), flush=True)
 

@@ -359,6 +359,15 @@ int affnet_detect_image_onepass(affnet_ctx* ctx, const float* d_packed_fullconv,
 int64_t affnet_affmap_offset(const affnet_ctx* ctx, int octave);
 int64_t affnet_affmap_image_stride(const affnet_ctx* ctx);
 
+/* The whole path as ONE HIP graph.  affnet_graph_capture_extract stream-captures affnet_extract_features with exactly these buffers
+ * (same arguments; `stream` must be an explicit, non-null stream; nothing executes during capture) and instantiates the graph;
+ * affnet_graph_launch replays it: one launch instead of ~45 for callers that process one image at a time
+ * (hesaffnet.py:35-60 per image).  The captured buffers (image, outputs, workspace, packed weights) must stay alive and in place;
+ * new image content is copied into the captured d_img before a launch.  A later capture on the same context replaces the graph. */
+int affnet_graph_capture_extract(affnet_ctx* ctx, const affnet_nets* nets, const float* d_img, int do_ori, float* d_lafs_px, float* d_resp,
+                                 int32_t* d_ids, float* d_desc, int32_t* d_count, void* stream);
+int affnet_graph_launch(affnet_ctx* ctx, void* stream);
+
 /* Stage timing with HIP events recorded on the caller's stream around the stages of
  * affnet_extract_features (no host synchronisation while enabled; a ring of 256 calls).
  * Stages: 0 pyramid, 1 detector, 2 AffNet trunk(+sampling), 3 shape filter/select, 4 OriNet(+rotation),

@@ -699,6 +699,35 @@ def test_metric_configuration_batched_b32_vs_oracle(amd, nets, weights, golden_d
     assert len(gi) >= 0.995 * 2000 and (dl < 1e-3).mean() >= 0.995 and (dd < 1e-3).mean() >= 0.995 and dl.max() < 1e-2
 
 
+def test_hip_graph_replay_equals_eager(amd, nets):
+    """affnet_graph_capture_extract / affnet_graph_launch: the whole path as one HIP graph gives bit-identical results to the eager call,
+    for new image content copied into the captured input, on single images and on batches."""
+    A, O, H = nets
+    imgs = [orc.synthetic_image(240, 320, s).to(DEV) for s in (1, 2, 3)]
+    mk = lambda: amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=1, AffNet=A, OriNet=O).to(DEV)
+    ref = [mk().run(x, do_ori=True, desc=H) for x in imgs]
+    det = mk()
+    cap = det.capture(imgs[0], do_ori=True, desc=H)
+    for rep in range(2):
+        for x, want in zip(imgs, ref):
+            got = cap.run(x)
+            for k in ("LAFs", "responses", "descriptors", "ids"):
+                assert torch.equal(got[k], want[k]), (rep, k)
+    # eager calls on the same extractor still work next to the captured graph
+    again = det.run(imgs[1], do_ori=True, desc=H)
+    assert torch.equal(again["LAFs"], ref[1]["LAFs"])
+    # batch of 3 in one graph
+    xb = torch.cat(imgs, 0)
+    capb = mk().capture(xb, do_ori=True, desc=H)
+    r = capb.launch(xb)
+    torch.cuda.synchronize()
+    for b, want in enumerate(ref):
+        n = int(r["count"][b])
+        assert n == want["LAFs"].shape[0]
+        for k in ("LAFs", "responses", "descriptors", "ids"):
+            assert torch.equal(r[k][b, :n], want[k]), (b, k)
+
+
 def test_two_contexts_two_host_threads(amd, nets):
     """include/affnet_hip.h: different contexts may be driven from different host threads / streams concurrently (the library
     keeps no process-global state).  Two threads, each with its own extractor (= context) and stream, alternate over images; every
