@@ -172,6 +172,42 @@ void aff_fill_pyr_table(const affnet_ctx* ctx, PyrTable* t);
 // tests/test_host_mirror.py).
 void aff_base_grid(int ps, float* base);
 
+// LDS-staged footprint of one patch (north_star: "coalesced HBM reads and LDS-staged image tiles"): the affine frame of a PS x PS
+// patch covers an axis-aligned box of the level image; when that box is small its rows are loaded once with coalesced row-segment
+// loads (zeros outside the image = grid_sample's zero padding) and the four bilinear taps of every sample come from LDS.  The
+// arithmetic of a sample is untouched (same weights, same fmaf chain), so staged and direct sampling are bit-identical.
+struct AffTile {
+    int x0, y0, tw, th;      // box origin in level pixels (may be negative), width / height; tw == 0: not staged
+};
+
+// Box that contains every tap of the patch (1-px margin for the fp32 round trip of the coordinates); staged iff it fits `cap` floats
+// and is small enough that loading it costs fewer requests than the 4 * ps * ps gathers it replaces.
+__device__ __forceinline__ AffTile aff_tile_box(float t00, float t01, float t02, float t10, float t11, float t12, int ps, int cap) {
+    const float um = (float)(ps - 1) / (float)ps;
+    const float hx = (fabsf(t00) + fabsf(t01)) * um, hy = (fabsf(t10) + fabsf(t11)) * um;
+    const float cx = t02 - 0.5f, cy = t12 - 0.5f;
+    AffTile t;
+    t.tw = 0; t.th = 0; t.x0 = 0; t.y0 = 0;
+    if (!(hx < 4096.0f && hy < 4096.0f && fabsf(cx) < 1.0e6f && fabsf(cy) < 1.0e6f)) return t;     // also rejects NaN / inf frames
+    const int x0 = (int)floorf(cx - hx) - 1, x1 = (int)floorf(cx + hx) + 2;
+    const int y0 = (int)floorf(cy - hy) - 1, y1 = (int)floorf(cy + hy) + 2;
+    const int tw = x1 - x0 + 1, th = y1 - y0 + 1;
+    if (tw * th > cap || tw * th > 2 * ps * ps) return t;
+    t.x0 = x0; t.y0 = y0; t.tw = tw; t.th = th;
+    return t;
+}
+
+// Cooperative load of the box into LDS (NTHR threads; the caller synchronises afterwards).
+template <int NTHR>
+__device__ __forceinline__ void aff_tile_load(float* tile, const AffTile t, const float* __restrict__ img, int h, int w, int tid) {
+    const int n = t.tw * t.th;
+    for (int i = tid; i < n; i += NTHR) {
+        const int ty = i / t.tw, tx = i - ty * t.tw;
+        const int gy = t.y0 + ty, gx = t.x0 + tx;
+        tile[i] = (gy >= 0 && gy < h && gx >= 0 && gx < w) ? img[(size_t)gy * w + gx] : 0.0f;
+    }
+}
+
 // Device: one bilinear sample.  Follows LAF.py:313-324 + F.affine_grid + F.grid_sample
 // (align_corners=False, zeros padding) operation by operation in fp32:
 //   theta = LAF * [[m,m,w],[m,m,h]];  g = fma(1,t02, fma(v,t01, u*t00));
@@ -199,5 +235,39 @@ __device__ __forceinline__ float aff_sample_bilinear(const float* __restrict__ i
     const float vne = (xin1 & yin0) ? img[(size_t)y0 * w + x1] : 0.0f;
     const float vsw = (xin0 & yin1) ? img[(size_t)y1 * w + x0] : 0.0f;
     const float vse = (xin1 & yin1) ? img[(size_t)y1 * w + x1] : 0.0f;
+    return fmaf(vse, se, fmaf(vsw, sw, fmaf(vne, ne, vnw * nw)));
+}
+
+// Same sample with the four taps taken from a staged box (zeros are already in the tile for pixels outside the image).  A tap
+// outside the box (cannot happen for a box from aff_tile_box; guarded anyway) falls back to the predicated global load.
+__device__ __forceinline__ float aff_sample_bilinear_tile(const float* tile, const AffTile tl, const float* __restrict__ img, int h, int w,
+                                                          float t00, float t01, float t02, float t10, float t11, float t12, float u, float v) {
+    float gx = fmaf(1.0f, t02, fmaf(v, t01, u * t00));
+    float gy = fmaf(1.0f, t12, fmaf(v, t11, u * t10));
+    const float fw = (float)w, fh = (float)h;
+    gx = 2.0f * gx / fw - 1.0f;
+    gy = 2.0f * gy / fh - 1.0f;
+    const float ix = fmaf(gx + 1.0f, fw * 0.5f, -0.5f);
+    const float iy = fmaf(gy + 1.0f, fh * 0.5f, -0.5f);
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float x1f = x0f + 1.0f, y1f = y0f + 1.0f;
+    const float wx1 = ix - x0f, wx0 = x1f - ix, wy1 = iy - y0f, wy0 = y1f - iy;
+    const float nw = wx0 * wy0, ne = wx1 * wy0, sw = wx0 * wy1, se = wx1 * wy1;
+    const float cx0 = fminf(fmaxf(x0f, -2.0f), fw + 1.0f), cy0 = fminf(fmaxf(y0f, -2.0f), fh + 1.0f);
+    const int x0 = (int)cx0, y0 = (int)cy0;
+    const int lx = x0 - tl.x0, ly = y0 - tl.y0;
+    float vnw, vne, vsw, vse;
+    if (lx >= 0 && ly >= 0 && lx + 1 < tl.tw && ly + 1 < tl.th) {
+        const float* p = tile + ly * tl.tw + lx;
+        vnw = p[0]; vne = p[1]; vsw = p[tl.tw]; vse = p[tl.tw + 1];
+    } else {
+        const int x1 = x0 + 1, y1 = y0 + 1;
+        const bool xin0 = (x0 >= 0) & (x0 < w), xin1 = (x1 >= 0) & (x1 < w);
+        const bool yin0 = (y0 >= 0) & (y0 < h), yin1 = (y1 >= 0) & (y1 < h);
+        vnw = (xin0 & yin0) ? img[(size_t)y0 * w + x0] : 0.0f;
+        vne = (xin1 & yin0) ? img[(size_t)y0 * w + x1] : 0.0f;
+        vsw = (xin0 & yin1) ? img[(size_t)y1 * w + x0] : 0.0f;
+        vse = (xin1 & yin1) ? img[(size_t)y1 * w + x1] : 0.0f;
+    }
     return fmaf(vse, se, fmaf(vsw, sw, fmaf(vne, ne, vnw * nw)));
 }

@@ -23,9 +23,11 @@ void aff_fill_pyr_table(const affnet_ctx* ctx, PyrTable* t) {
     }
 }
 
-// One workgroup per patch.  The affine footprint of a patch is a few hundred source pixels that
-// are re-read 4x by neighbouring samples: they stay in the CU's L1 (32 KiB) after first touch, and
-// each wave row of 32..64 samples walks a straight line through the level image.
+// One workgroup per patch.  The affine footprint of a patch is an axis-aligned box of the level image: when it is small (most
+// detector-level patches: <= 2 x ps x ps pixels) its rows are staged in LDS with coalesced row-segment loads and the four taps of
+// every sample come from there (common.h: aff_tile_*); large footprints (a 32 x 32 patch drawn from a 160 x 160 px region of octave 0
+// touches a sixth of it) keep the four predicated gathers per sample.  Both paths are bit-identical.
+#define GS_TILE_CAP 4096
 __global__ __launch_bounds__(256) void grid_sample_kernel(const float* __restrict__ img, int h, int w, PyrTable pt, int use_pyr,
                                                           const float* __restrict__ lafs, const int32_t* __restrict__ ids,
                                                           const int32_t* __restrict__ d_count, int n_max, int ps, BaseGrid bg,
@@ -47,6 +49,17 @@ __global__ __launch_bounds__(256) void grid_sample_kernel(const float* __restric
     const float t00 = L[0] * m, t01 = L[1] * m, t02 = L[2] * (float)w;
     const float t10 = L[3] * m, t11 = L[4] * m, t12 = L[5] * (float)h;
     float* dst = out + (size_t)p * ps * ps;
+    __shared__ float tile[GS_TILE_CAP];
+    const AffTile tl = aff_tile_box(t00, t01, t02, t10, t11, t12, ps, GS_TILE_CAP);     // uniform across the workgroup
+    if (tl.tw > 0) {
+        aff_tile_load<256>(tile, tl, img, h, w, threadIdx.x);
+        __syncthreads();
+        for (int i = threadIdx.x; i < ps * ps; i += 256) {
+            const int r = i / ps, c = i - r * ps;
+            dst[i] = aff_sample_bilinear_tile(tile, tl, img, h, w, t00, t01, t02, t10, t11, t12, bg.v[c], bg.v[r]);
+        }
+        return;
+    }
     for (int i = threadIdx.x; i < ps * ps; i += 256) {
         const int r = i / ps, c = i - r * ps;
         dst[i] = aff_sample_bilinear(img, h, w, t00, t01, t02, t10, t11, t12, bg.v[c], bg.v[r]);
