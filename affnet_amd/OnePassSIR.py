@@ -114,3 +114,23 @@ class OnePassSIR(nn.Module):
         """OnePassSIR.py:139-153: (LAFs in pixels (N,2,3), responses (N,))."""
         r = self.run(x, do_ori=do_ori)
         return r["LAFs"], r["responses"]
+
+    def extract_patches_from_pyr(self, dLAFs, PS=41):
+        """OnePassSIR.py:130-138: pixel LAFs (N,2,3) -> (N,1,PS,PS) from the best pyramid level of the LAST forward()."""
+        if self._ctx is None or self.scale_pyr is None:
+            raise RuntimeError("call forward() first: the pyramid of the last image is reused (stateful like the reference)")
+        ctx = self._ctx
+        if ctx.batch != 1:
+            raise RuntimeError("extract_patches_from_pyr works on the pyramid of a single-image forward()")
+        engine.require_cuda(dLAFs, "dLAFs")
+        dev, st = dLAFs.device, engine.stream_of(dLAFs.device)
+        lafs = dLAFs.contiguous().float()
+        n = lafs.size(0)
+        out = torch.empty(n, 1, PS, PS, dtype=torch.float32, device=dev)
+        if n == 0:
+            return out
+        ids = torch.empty(n, 3, dtype=torch.int32, device=dev)
+        norm = torch.empty(n, 2, 3, dtype=torch.float32, device=dev)
+        check(lib.affnet_level_select(ctx.handle, ptr(lafs), None, n, PS, ptr(ids), ptr(norm), st), ctx.handle, "affnet_level_select")
+        check(lib.affnet_pyr_grid_sample(ctx.handle, ptr(norm), ptr(ids), None, n, PS, ptr(out), st), ctx.handle, "affnet_pyr_grid_sample")
+        return out

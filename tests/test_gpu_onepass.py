@@ -181,3 +181,20 @@ def test_onepass_foreign_dense_affnet_slot_and_batch(amd, nets, weights):
             assert torch.equal(r[k][i, :n], a[k]), (i, k)
     with pytest.raises(Exception, match="34 px"):
         amd.OnePassSIR(mrSize=5.192, num_features=300, border=5, AffNet=FC, OriNet=O).to(DEV).run(x)
+
+
+def test_onepass_cli(amd, golden_dir, tmp_path):
+    """examples/hesaffnet/extract_geom_and_desc_upisup.py: the reference script's flow (default OrientationDetector, HardNet on
+    extract_patches_from_pyr, LAFs2ellT -> Oxford file)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = tmp_path / "img1.txt"
+    subprocess.check_call([sys.executable, os.path.join(root, "examples/hesaffnet/extract_geom_and_desc_upisup.py"),
+                           os.path.join(golden_dir, "graf_img1.png"), str(out), "500"])
+    lines = open(out).read().split("\n")
+    assert lines[0].strip() == "1.0" and int(lines[1]) == 500
+    ell = np.loadtxt(out, skiprows=2)
+    assert ell.shape == (500, 5) and (ell[:, 2] * ell[:, 4] - ell[:, 3] ** 2 > 0).all()
+    d = np.load(str(out) + ".desc.npy")
+    assert d.shape == (500, 128) and np.abs(np.linalg.norm(d, axis=1) - 1.0).max() < 1e-4
