@@ -145,7 +145,9 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
             self._busy.record(cur)
         if B == 1:      # the reference's shapes
             lafs, resp, ids, dsc = lafs[0], resp[0], ids[0], (None if dsc is None else dsc[0])
-        return {"LAFs": lafs, "responses": resp, "ids": ids, "descriptors": dsc, "count": count, "_img": img}
+        # "overflow": (B,) device view of the capacity-overflow flags (non-zero = a fixed-capacity list overflowed and this image's rows are
+        # truncated) - valid once the enqueued work has completed; run() / run_batch() / bench.py check it through affnet_read_counts
+        return {"LAFs": lafs, "responses": resp, "ids": ids, "descriptors": dsc, "count": count, "overflow": ctx.counter_view(0), "_img": img}
 
     def _nets(self, dev, do_ori, desc):
         nets = _lib.Nets()
@@ -177,7 +179,7 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
         ctx.read_counts(allow_empty=True)   # surfaces capacity overflow; images without detections are legal in a batch
         cnt = r["count"].cpu().tolist()
         if x.size(0) == 1:
-            r = {k: (v.unsqueeze(0) if isinstance(v, torch.Tensor) and k not in ("count", "_img") else v) for k, v in r.items()}
+            r = {k: (v.unsqueeze(0) if isinstance(v, torch.Tensor) and k not in ("count", "overflow", "_img") else v) for k, v in r.items()}
         out = []
         for b, n in enumerate(cnt):
             dsc = r["descriptors"]

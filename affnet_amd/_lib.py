@@ -92,6 +92,8 @@ SYMBOLS = {
     "affnet_profile_enable": (_I, [_P, _I]),
     "affnet_profile_read": (_I, [_P, C.POINTER(C.c_double * 8), C.POINTER(C.c_int32)]),
     "affnet_read_counts": (_I, [_P, C.POINTER(C.c_int32 * 4), _P]),
+    "affnet_counter_offset": (C.c_int64, [_P, _I]),
+    "affnet_counter_stride": (C.c_int64, [_P]),
     "affnet_host_base_grid": (_I, [_I, C.POINTER(C.c_float)]),
 }
 

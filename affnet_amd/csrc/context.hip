@@ -198,6 +198,17 @@ extern "C" int64_t affnet_pyramid_level_offset(const affnet_ctx* ctx, int octave
 
 extern "C" int64_t affnet_pyramid_image_stride(const affnet_ctx* ctx) { return ctx ? (int64_t)ctx->pyr_stride : 0; }
 
+// int32 offset (from the workspace base) of a per-image device counter of image 0; consecutive images are affnet_counter_stride()
+// int32 apart.  which: 0 = capacity-overflow flag (non-zero: a fixed-capacity list overflowed, results are truncated),
+// 1 = rows after detection, 2 = rows after the shape filter.  Lets a caller test the flags on the device / read them with its own
+// asynchronous copy instead of the synchronising affnet_read_counts.
+extern "C" int64_t affnet_counter_offset(const affnet_ctx* ctx, int which) {
+    if (!ctx || ctx->ws_bytes == 0 || which < 0 || which > 2) return -1;
+    const int idx = which == 0 ? CNT_OVERFLOW : (which == 1 ? CNT_DET : CNT_SHAPED);
+    return (int64_t)(ctx->off_cnt / sizeof(int32_t)) + idx;
+}
+extern "C" int64_t affnet_counter_stride(const affnet_ctx* ctx) { return ctx ? (int64_t)CNT_TOTAL : 0; }
+
 extern "C" int64_t affnet_affmap_offset(const affnet_ctx* ctx, int octave) {
     if (!ctx || !ctx->cfg.onepass || octave < 0 || octave >= ctx->cfg.n_octaves) return -1;
     return (int64_t)(ctx->off_affmap / sizeof(float)) + (int64_t)ctx->aff_off[octave];

@@ -75,6 +75,12 @@ class Context(object):
             out.append(self._ws_f32[off:off + 4 * h * w].view(1, 4, h, w))
         return out
 
+    def counter_view(self, which=0):
+        """(B,) int32 device view of a per-image counter in the workspace (0 = capacity-overflow flag, 1 = rows after detection, 2 = rows
+        after the shape filter): callers of enqueue() can test it on the device or copy it asynchronously - no host synchronisation."""
+        off, stride = lib.affnet_counter_offset(self.handle, which), lib.affnet_counter_stride(self.handle)
+        return self.workspace.view(torch.int32)[off:off + stride * self.batch:stride]
+
     def read_counts(self, allow_empty=False):
         """The one host read-back: [rows after detection, rows after the shape filter, overflow flag, raw maxima] summed over
         the batch.  Raises AffnetHipError on a capacity overflow (results would be truncated) and AffnetEmptyError when no

@@ -385,6 +385,12 @@ int affnet_profile_read(affnet_ctx* ctx, double sum_ms[AFFNET_PROFILE_STAGES], i
  * error), AFFNET_ERR_EMPTY when no image of the call produced a detection (out[] is still filled), else AFFNET_OK. */
 int affnet_read_counts(affnet_ctx* ctx, int32_t out[4], void* stream);
 
+/* The same counters without a host synchronisation: int32 offset (from the workspace base) of a per-image device counter of image 0
+ * and the int32 stride between images.  which: 0 = capacity-overflow flag, 1 = rows after detection, 2 = rows after the shape filter.
+ * Valid once the enqueued work has completed on the stream; -1 for a context without a workspace layout. */
+int64_t affnet_counter_offset(const affnet_ctx* ctx, int which);
+int64_t affnet_counter_stride(const affnet_ctx* ctx);
+
 /* Host helper (no GPU): out[ps] = affine_grid base coordinates (linspace(-1,1,ps)*(ps-1))/ps with
  * torch's CPU rounding; exported so the CPU test-suite can pin it against torch.linspace. */
 int affnet_host_base_grid(int ps, float* out);

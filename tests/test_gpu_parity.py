@@ -623,7 +623,14 @@ def test_capacity_overflow_is_an_error_not_a_truncation(amd, nets):
     det.raw_div = 1 << 20                      # raw-maxima capacity 256 per octave; octave 0 of this image has ~700 maxima
     with pytest.raises(AffnetHipError, match="overflow"):
         det.run(x, do_ori=True)
+    # the same flag without a host synchronisation: enqueue() hands out a device view of the per-image overflow counters
+    r = det.enqueue(x, do_ori=True)
+    torch.cuda.synchronize()
+    assert int(r["overflow"][0]) != 0
     det.raw_div = 4
+    r = det.enqueue(x, do_ori=True)
+    torch.cuda.synchronize()
+    assert int(r["overflow"][0]) == 0 and int(r["count"][0]) == 300
     assert det.run(x, do_ori=True)["LAFs"].shape[0] == 300
     det = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=1, th=-1, AffNet=A).to(DEV)
     det.max_keep = 64                          # threshold mode keeps every maximum: capacity 64 rows cannot hold ~1700
