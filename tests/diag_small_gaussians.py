@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Box-side diagnosis: for small Gaussians (K = 3, 5, 7) compare (a) the HIP blur, (b) the oracle's conv2d on THIS host's CPU and
+"""TEST INFRASTRUCTURE (uses the CPU oracle; not collected by pytest, run by hand on the GPU box: python tests/diag_small_gaussians.py).
+Box-side diagnosis: for small Gaussians (K = 3, 5, 7) compare (a) the HIP blur, (b) the oracle's conv2d on THIS host's CPU and
 (c) a numpy emulation of the row-major fmaf chain.  Tells whether a mismatch is the GPU kernel's or this CPU's oneDNN kernel choice."""
 import ctypes as C
 import os
@@ -9,7 +10,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))  # repo root (this file lives in tests/)
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import affnet_oracle as orc
 from affnet_amd import engine
