@@ -49,6 +49,8 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
         self.last_ids = None       # (N,3) int32 (octave, level-1, pixel) of the detections returned last
         self.max_keep = 16384      # row capacity in threshold mode (num = -1)
         self.raw_div = 4           # raw-maxima list capacity per octave = h*w / raw_div (overflow -> AffnetHipError, never truncation)
+        self.lazy_shape_rows = -1  # fused path: AffNet first runs on the 1.2 N best candidates, on the rest only if needed (identical rows);
+                                   # 0 = all 1.5 N candidates at once like the reference (affnet_config.lazy_shape_rows)
 
     # ------------------------------------------------------------------------------------------
     def _context(self, x, allow_batch=False):
@@ -58,10 +60,11 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
                              "(HandCraftedModules.py:283-284) - use enqueue()/run_batch() for (B,1,H,W) batches")
         pre = int(1.5 * self.num) if self.num_Baum_iters > 0 else self.num
         key = (x.size(0), x.size(2), x.size(3), x.device, pre, self.num, float(self.th), self.mrSize, self.b, self.init_sigma,
-               self.nlevels, self.max_keep, self.num_Baum_iters, self.raw_div)
+               self.nlevels, self.max_keep, self.num_Baum_iters, self.raw_div, self.lazy_shape_rows)
         if self._ctx is None or self._ctx_key != key:
             self._ctx = engine.Context(x.size(2), x.size(3), x.device, self.nlevels, self.init_sigma, self.b, self.mrSize,
-                                       float(self.th), self.num, pre, self.max_keep, batch=x.size(0), baum_iters=self.num_Baum_iters, raw_div=self.raw_div)
+                                       float(self.th), self.num, pre, self.max_keep, batch=x.size(0), baum_iters=self.num_Baum_iters, raw_div=self.raw_div,
+                                       lazy_shape_rows=self.lazy_shape_rows)
             self._ctx_key = key
         return self._ctx
 

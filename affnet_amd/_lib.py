@@ -27,6 +27,7 @@ class Config(C.Structure):
         ("level_blur", (C.c_float * (MAX_TAPS * MAX_TAPS)) * MAX_LEVELS),
         ("level_blur0_taps", C.c_int32 * MAX_LEVELS),
         ("level_blur0", (C.c_float * (MAX_TAPS * MAX_TAPS)) * MAX_LEVELS),
+        ("lazy_shape_rows", C.c_int32),
         ("onepass", C.c_int32),
         ("mr_size", C.c_float), ("threshold", C.c_float),
         ("num_features", C.c_int32), ("num_prefilter", C.c_int32),

@@ -181,7 +181,19 @@ struct CnnArgs {
     int dbg_layer;         // >= 0: dump activations after this trunk layer of patch 0 and exit
     float* dbg_out;
     unsigned long long* dbg_time;   // != NULL: s_memtime stamps [patch][wave][32] at the phase boundaries (tuning aid)
+    // Row window [row_begin, row_begin + gridDim.x) of every image, and the lazy-evaluation predicate of the fused pipeline: when
+    // skip_cnt != NULL the launch does nothing for an image whose detections are response-sorted (CNT_SEL_MODE == 1) and whose first
+    // pass already produced skip_n survivors of the shape filter (CNT_SURVIVED1) - pipeline.hip, affnet_describe_detected.
+    int row_begin;
+    const int32_t* skip_cnt;
+    int skip_n;
 };
+
+__device__ __forceinline__ bool lazy_skip(const int32_t* skip_cnt, int skip_n, int image) {
+    if (!skip_cnt) return false;
+    const int32_t* c = skip_cnt + (size_t)image * CNT_TOTAL;
+    return c[CNT_SEL_MODE] == 1 && c[CNT_SURVIVED1] >= skip_n;
+}
 
 #define CNN_STAMP(k)                                                                                     \
     do {                                                                                                 \
@@ -236,8 +248,9 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
     float* red = patch + TrunkLds<CB>::PATCH;
     // grid = (n_max, batch): row blockIdx.x of image blockIdx.y; global row = image * n_max + row
     const int n = a.count ? min(a.count[blockIdx.y], a.n_max) : a.n_max;
-    if ((int)blockIdx.x >= n) return;
-    const size_t pidx = (size_t)blockIdx.y * a.n_max + blockIdx.x;
+    const int prow = blockIdx.x + a.row_begin;
+    if (prow >= n || lazy_skip(a.skip_cnt, a.skip_n, blockIdx.y)) return;
+    const size_t pidx = (size_t)blockIdx.y * a.n_max + prow;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // Issue priority (HardNet only, one workgroup per CU): the short latency-bound phases (input, conv0, epilogues) run at
     // priority 3, the MFMA loops at 0: +2% (130 -> 133 TFLOP/s).  For AffNet / OriNet (two workgroups per CU) it is
@@ -427,10 +440,11 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
 //   OriNet : + bias -> tanh -> mean over the 3x3 map -> atan2 -> rotation (architectures.py:56-58,76-82, LAF.py:276-283)
 template <int KIND>
 __global__ __launch_bounds__(256) void cnn16_finish_kernel(const float* __restrict__ part, const float* __restrict__ hb,
-                                                           const int32_t* __restrict__ count, int n_max, float* __restrict__ out) {
-    const int row = blockIdx.x * 256 + threadIdx.x;
-    const int n = count ? min(count[blockIdx.y], n_max) : n_max;
-    if (row >= n) return;
+                                                           const int32_t* __restrict__ count, int n_max, float* __restrict__ out, int row_begin,
+                                                           int row_end, const int32_t* __restrict__ skip_cnt, int skip_n) {
+    const int row = row_begin + blockIdx.x * 256 + threadIdx.x;
+    const int n = min(count ? min(count[blockIdx.y], n_max) : n_max, row_end);
+    if (row >= n || lazy_skip(skip_cnt, skip_n, blockIdx.y)) return;
     const size_t pidx = (size_t)blockIdx.y * n_max + row;
     float* o = out + 4 * pidx;
     if (KIND == AFFNET_NET_AFFNET) {
@@ -588,7 +602,7 @@ void aff_fill_pyr_src(const affnet_ctx* ctx, PyrSrc* t) {
 
 static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const float* patches, const float* lafs, const int32_t* ids,
                       const int32_t* count, int n_max, float* out, float* scratch, int dbg_layer, float* dbg_out, hipStream_t st,
-                      bool mark_head = false) {
+                      bool mark_head = false, int row_begin = 0, int row_count = -1, const int32_t* skip_cnt = nullptr, int skip_n = 0) {
     if (kind < 0 || kind > 2) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: unknown net kind %d", kind);
     if (!packed || !out || n_max < 0 || (!patches && (!lafs || !ids))) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: null argument");
     if (!patches && !ctx->ws) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: sampling from the pyramid needs a bound workspace");
@@ -601,10 +615,14 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
     a.packed = packed; a.off = to_offsets(L); a.patches = patches; a.lafs = lafs; a.ids = ids; a.count = count; a.n_max = n_max;
     a.out = (dbg_layer < 0) ? scratch : out;              // trunk kernels: HardNet conv5 tensor / AffNet, OriNet head partials
     a.dbg_layer = dbg_layer; a.dbg_out = dbg_out; a.dbg_time = ctx->dbg_time;
+    a.row_begin = row_begin; a.skip_cnt = skip_cnt; a.skip_n = skip_n;
+    if (row_count < 0) row_count = n_max - row_begin;
+    if (row_begin < 0 || row_count < 0 || row_begin + row_count > n_max) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: bad row window");
+    if (row_count == 0) return AFFNET_OK;
     PyrSrc ps;
     aff_fill_pyr_src(ctx, &ps);
     const int B = patches ? 1 : ctx->B;                  // patch tensors are single-"image"; pyramid sampling covers the batch
-    const dim3 grid(n_max, B);
+    const dim3 grid(row_count, B);
     // (Tried and removed: two AffNet patches per persistent 16-wave workgroup in anti-phase - correct but 8 % slower, the
     // small-tile loops reach 85-90 % of the pipe rate with two waves per SIMD; 16-wave HardNet workgroups - slower too.)
 #define TRUNK_LAUNCH(K) do { if (a.dbg_time || dbg_layer >= 0) hipLaunchKernelGGL((cnn32_trunk_kernel<K, 8, true>), grid, dim3(512), 0, st, a, ps); \
@@ -615,11 +633,13 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
 #undef TRUNK_LAUNCH
     AFF_LAUNCH_CHECK(ctx);
     if (kind != AFFNET_NET_HARDNET && dbg_layer < 0) {       // combine the per-wave head partials in `scratch`
-        const dim3 hgrid(aff_cdiv(n_max, 256), B);
+        const dim3 hgrid(aff_cdiv(row_count, 256), B);
         if (kind == AFFNET_NET_AFFNET)
-            hipLaunchKernelGGL((cnn16_finish_kernel<AFFNET_NET_AFFNET>), hgrid, dim3(256), 0, st, scratch, packed + L.head_b, count, n_max, out);
+            hipLaunchKernelGGL((cnn16_finish_kernel<AFFNET_NET_AFFNET>), hgrid, dim3(256), 0, st, scratch, packed + L.head_b, count, n_max, out, row_begin,
+                               row_begin + row_count, skip_cnt, skip_n);
         else
-            hipLaunchKernelGGL((cnn16_finish_kernel<AFFNET_NET_ORINET>), hgrid, dim3(256), 0, st, scratch, packed + L.head_b, count, n_max, out);
+            hipLaunchKernelGGL((cnn16_finish_kernel<AFFNET_NET_ORINET>), hgrid, dim3(256), 0, st, scratch, packed + L.head_b, count, n_max, out, row_begin,
+                               row_begin + row_count, skip_cnt, skip_n);
         AFF_LAUNCH_CHECK(ctx);
     }
     if (mark_head) aff_prof_mark(ctx, 7, st);
@@ -646,6 +666,13 @@ extern "C" int affnet_cnn32_forward_pyr(affnet_ctx* ctx, int net_kind, const flo
     AFF_DEVICE(ctx);
     if (!ctx) return AFFNET_ERR_INVALID;
     return cnn_launch(ctx, net_kind, d_packed, nullptr, d_lafs, d_ids, d_count, n_max, d_out, d_scratch, -1, nullptr, (hipStream_t)stream);
+}
+
+// Rows [row_begin, row_begin + row_count) of every image only, optionally under the lazy-evaluation predicate (see CnnArgs).
+int aff_cnn_forward_pyr_rows(affnet_ctx* ctx, int kind, const float* packed, const float* lafs, const int32_t* ids, const int32_t* count, int n_max,
+                             float* out, float* scratch, int row_begin, int row_count, const int32_t* skip_cnt, int skip_n, hipStream_t st) {
+    if (kind == AFFNET_NET_HARDNET) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: row windows are for the AffNet / OriNet trunks");
+    return cnn_launch(ctx, kind, packed, nullptr, lafs, ids, count, n_max, out, scratch, -1, nullptr, st, false, row_begin, row_count, skip_cnt, skip_n);
 }
 
 int aff_hardnet_forward_pyr_marked(affnet_ctx* ctx, const float* packed, const float* lafs, const int32_t* ids, const int32_t* count,

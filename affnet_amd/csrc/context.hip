@@ -200,11 +200,11 @@ extern "C" int64_t affnet_pyramid_image_stride(const affnet_ctx* ctx) { return c
 
 // int32 offset (from the workspace base) of a per-image device counter of image 0; consecutive images are affnet_counter_stride()
 // int32 apart.  which: 0 = capacity-overflow flag (non-zero: a fixed-capacity list overflowed, results are truncated),
-// 1 = rows after detection, 2 = rows after the shape filter.  Lets a caller test the flags on the device / read them with its own
+// 1 = rows after detection, 2 = rows after the shape filter, 3 = candidates the shape CNN was evaluated on (lazy evaluation).  Lets a caller test the flags on the device / read them with its own
 // asynchronous copy instead of the synchronising affnet_read_counts.
 extern "C" int64_t affnet_counter_offset(const affnet_ctx* ctx, int which) {
-    if (!ctx || ctx->ws_bytes == 0 || which < 0 || which > 2) return -1;
-    const int idx = which == 0 ? CNT_OVERFLOW : (which == 1 ? CNT_DET : CNT_SHAPED);
+    if (!ctx || ctx->ws_bytes == 0 || which < 0 || which > 3) return -1;
+    const int idx = which == 0 ? CNT_OVERFLOW : (which == 1 ? CNT_DET : (which == 2 ? CNT_SHAPED : CNT_AFF_EVAL));
     return (int64_t)(ctx->off_cnt / sizeof(int32_t)) + idx;
 }
 extern "C" int64_t affnet_counter_stride(const affnet_ctx* ctx) { return ctx ? (int64_t)CNT_TOTAL : 0; }

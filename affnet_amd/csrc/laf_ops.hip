@@ -96,17 +96,28 @@ extern "C" int affnet_pyr_grid_sample(affnet_ctx* ctx, const float* d_lafs, cons
 }
 
 // ---- shape compose + filter ------------------------------------------------------------------------
+// Rows [row_begin, row_end) of every image; the other rows keep what they hold (the caller zeroes key / good first).  With the
+// lazy-evaluation predicate (skip_cnt != NULL, see cnn32.hip CnnArgs) the pass does nothing for an image that already has its
+// skip_n survivors - its remaining candidates were never run through the shape CNN and stay "not good".  Survivors are counted
+// into CNT_SURVIVED here (one atomic per wave); thread 0 of a second pass records how many candidates were evaluated at all.
 __global__ __launch_bounds__(256) void shape_filter_kernel(const float* __restrict__ resp, const float* __restrict__ lafs,
                                                            const float* __restrict__ A, const int32_t* __restrict__ d_count,
-                                                           int n_max, float* __restrict__ key, int32_t* __restrict__ good) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
+                                                           int n_max, float* __restrict__ key, int32_t* __restrict__ good, int row_begin,
+                                                           int row_end, int32_t* cnt, const int32_t* skip_cnt, int skip_n) {
+    const int i = row_begin + blockIdx.x * 256 + threadIdx.x;
     {
         const size_t bi = blockIdx.y;
         resp += bi * n_max; lafs += bi * n_max * 6; A += bi * n_max * 4; d_count += bi; key += bi * n_max; good += bi * n_max;
+        cnt += bi * CNT_TOTAL;
     }
     const int n = min(*d_count, n_max);
-    if (i >= n_max) return;
-    if (i >= n) { key[i] = 0.f; good[i] = 0; return; }
+    bool skip = false;
+    if (skip_cnt) {
+        const int32_t* c = skip_cnt + (size_t)blockIdx.y * CNT_TOTAL;
+        skip = c[CNT_SEL_MODE] == 1 && c[CNT_SURVIVED1] >= skip_n;      // frozen after the first pass (shape_freeze_kernel)
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) cnt[CNT_AFF_EVAL] = skip ? min(n, row_begin) : min(n, row_end);
+    if (skip || i >= row_end || i >= n) return;
     // base_A = bmm(A, I) = A exactly (SparseImgRepresenter.py:136, one iteration)
     const float a00 = A[4 * i], a01 = A[4 * i + 1], a10 = A[4 * i + 2], a11 = A[4 * i + 3];
     const float* L = lafs + 6 * (size_t)i;
@@ -134,22 +145,13 @@ __global__ __launch_bounds__(256) void shape_filter_kernel(const float* __restri
     }
     good[i] = ok ? 1 : 0;
     key[i] = resp[i] * (ok ? 1.0f : 0.0f);
+    if (ok) atomicAdd(&cnt[CNT_SURVIVED], 1);
 }
 
 // Selection, split over a 2-D grid like the detector's rank sort: block (bx, by) counts for its 256
 // rows how many rows of chunk `by` precede them; partial positions are accumulated with integer atomics.
 //   survivors > N  -> top-N of key (descending; ties by row index) - torch.topk branch (:151-153)
 //   otherwise      -> stable compaction of the good rows            - nonzero branch (:154-156)
-__global__ __launch_bounds__(256) void shape_count_kernel(const int32_t* __restrict__ good, const int32_t* __restrict__ d_count, int n_max,
-                                                          int32_t* cnt) {
-    good += (size_t)blockIdx.y * n_max; d_count += blockIdx.y; cnt += blockIdx.y * CNT_TOTAL;
-    const int n = min(*d_count, n_max);
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int g = (i < n) ? good[i] : 0;
-    const unsigned long long bal = __ballot(g != 0);
-    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&cnt[CNT_SURVIVED], __popcll(bal));
-}
-
 __global__ __launch_bounds__(256) void shape_rank_kernel(const float* __restrict__ key, const int32_t* __restrict__ good,
                                                          const int32_t* __restrict__ d_count, int n_max, int N,
                                                          const int32_t* __restrict__ cnt, int32_t* __restrict__ pos) {
@@ -211,6 +213,61 @@ __global__ __launch_bounds__(256) void shape_emit_kernel(const float* __restrict
     out_ids[3 * p] = ids[3 * i]; out_ids[3 * p + 1] = ids[3 * i + 1]; out_ids[3 * p + 2] = ids[3 * i + 2];
 }
 
+__global__ void shape_freeze_kernel(int32_t* cnt) {        // survivors of the first pass, read by the second pass's predicates
+    cnt += blockIdx.x * CNT_TOTAL;
+    cnt[CNT_SURVIVED1] = cnt[CNT_SURVIVED];
+}
+
+__global__ void shape_begin_kernel(int32_t* cnt) {
+    cnt += blockIdx.x * CNT_TOTAL;
+    cnt[CNT_SURVIVED] = 0; cnt[CNT_SURVIVED1] = 0; cnt[CNT_AFF_EVAL] = 0;
+}
+
+// The shape stage in three steps, so that the fused pipeline can evaluate the shape CNN lazily (pipeline.hip):
+//   begin  : key / good of every row = 0 ("not evaluated, not good"), survivor counters = 0
+//   rows   : filter rows [row_begin, row_end) of every image (optionally under the lazy predicate), counting survivors;
+//            freeze = true publishes the survivor count for the predicates of a following pass
+//   select : top-N / compaction of the good rows -> outputs
+int aff_shape_filter_begin(affnet_ctx* ctx, hipStream_t st) {
+    const size_t P = (size_t)ctx->B * ctx->cap_pre;
+    int rc = aff_zero_async(ctx, ctx->st_key, P * 2 * sizeof(float), st);        // st_key and st_good are adjacent (context.hip)
+    if (rc) return rc;
+    hipLaunchKernelGGL(shape_begin_kernel, dim3(ctx->B), dim3(1), 0, st, ctx->cnt);
+    AFF_LAUNCH_CHECK(ctx);
+    return AFFNET_OK;
+}
+
+int aff_shape_filter_rows(affnet_ctx* ctx, const float* resp, const float* lafs, const float* A, const int32_t* count, int row_begin, int row_end,
+                          bool lazy, hipStream_t st, bool freeze = false) {
+    if (row_end > row_begin) {
+        hipLaunchKernelGGL(shape_filter_kernel, dim3(aff_cdiv(row_end - row_begin, 256), ctx->B), dim3(256), 0, st, resp, lafs, A, count, ctx->cap_pre,
+                           ctx->st_key, ctx->st_good, row_begin, row_end, ctx->cnt, lazy ? ctx->cnt : nullptr, ctx->cfg.num_features);
+        AFF_LAUNCH_CHECK(ctx);
+    }
+    if (freeze) {
+        hipLaunchKernelGGL(shape_freeze_kernel, dim3(ctx->B), dim3(1), 0, st, ctx->cnt);
+        AFF_LAUNCH_CHECK(ctx);
+    }
+    return AFFNET_OK;
+}
+
+int aff_shape_select(affnet_ctx* ctx, const float* d_resp_in, const float* d_lafs_in, const int32_t* d_ids_in, const float* d_A,
+                     const int32_t* d_count_in, float* d_resp_out, float* d_lafs_out, int32_t* d_ids_out, int32_t* d_count_out, hipStream_t st) {
+    const int P = ctx->cap_pre, F = ctx->cap_final, B = ctx->B;
+    { int zrc = aff_zero_async(ctx, d_resp_out, (size_t)B * F * sizeof(float), st); if (zrc) return zrc; }
+    { int zrc = aff_zero_async(ctx, d_lafs_out, (size_t)B * F * 6 * sizeof(float), st); if (zrc) return zrc; }
+    { int zrc = aff_zero_async(ctx, d_ids_out, (size_t)B * F * 3 * sizeof(int32_t), st); if (zrc) return zrc; }
+    { int zrc = aff_zero_async(ctx, ctx->st_rank, (size_t)B * P * sizeof(int32_t), st); if (zrc) return zrc; }
+    const int nb = aff_cdiv(P, 256);
+    hipLaunchKernelGGL(shape_rank_kernel, dim3(nb, nb, B), dim3(256), 0, st, ctx->st_key, ctx->st_good, d_count_in, P, ctx->cfg.num_features,
+                       ctx->cnt, ctx->st_rank);
+    AFF_LAUNCH_CHECK(ctx);
+    hipLaunchKernelGGL(shape_emit_kernel, dim3(nb, B), dim3(256), 0, st, d_resp_in, d_lafs_in, d_ids_in, d_A, ctx->st_key, ctx->st_good,
+                       ctx->st_rank, d_count_in, P, ctx->cfg.num_features, F, d_resp_out, d_lafs_out, d_ids_out, d_count_out, ctx->cnt);
+    AFF_LAUNCH_CHECK(ctx);
+    return AFFNET_OK;
+}
+
 extern "C" int affnet_shape_filter_select(affnet_ctx* ctx, const float* d_resp_in, const float* d_lafs_in, const int32_t* d_ids_in,
                                           const float* d_A, const int32_t* d_count_in, float* d_resp_out, float* d_lafs_out,
                                           int32_t* d_ids_out, int32_t* d_count_out, void* stream) {
@@ -219,25 +276,11 @@ extern "C" int affnet_shape_filter_select(affnet_ctx* ctx, const float* d_resp_i
         !d_count_out)
         return aff_fail(ctx, AFFNET_ERR_INVALID, "shape_filter_select: bad argument");
     hipStream_t st = (hipStream_t)stream;
-    const int P = ctx->cap_pre, F = ctx->cap_final, B = ctx->B;
-    { int zrc = aff_zero_async(ctx, d_resp_out, (size_t)B * F * sizeof(float), st); if (zrc) return zrc; }
-    { int zrc = aff_zero_async(ctx, d_lafs_out, (size_t)B * F * 6 * sizeof(float), st); if (zrc) return zrc; }
-    { int zrc = aff_zero_async(ctx, d_ids_out, (size_t)B * F * 3 * sizeof(int32_t), st); if (zrc) return zrc; }
-    hipLaunchKernelGGL(shape_filter_kernel, dim3(aff_cdiv(P, 256), B), dim3(256), 0, st, d_resp_in, d_lafs_in, d_A, d_count_in, P, ctx->st_key,
-                       ctx->st_good);
-    AFF_LAUNCH_CHECK(ctx);
-    { int zrc = aff_zero_async(ctx, ctx->st_rank, (size_t)B * P * sizeof(int32_t), st); if (zrc) return zrc; }
-    AFF_HIP(ctx, hipMemset2DAsync(ctx->cnt + CNT_SURVIVED, CNT_TOTAL * sizeof(int32_t), 0, sizeof(int32_t), (size_t)B, st));
-    const int nb = aff_cdiv(P, 256);
-    hipLaunchKernelGGL(shape_count_kernel, dim3(nb, B), dim3(256), 0, st, ctx->st_good, d_count_in, P, ctx->cnt);
-    AFF_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(shape_rank_kernel, dim3(nb, nb, B), dim3(256), 0, st, ctx->st_key, ctx->st_good, d_count_in, P, ctx->cfg.num_features,
-                       ctx->cnt, ctx->st_rank);
-    AFF_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(shape_emit_kernel, dim3(nb, B), dim3(256), 0, st, d_resp_in, d_lafs_in, d_ids_in, d_A, ctx->st_key, ctx->st_good,
-                       ctx->st_rank, d_count_in, P, ctx->cfg.num_features, F, d_resp_out, d_lafs_out, d_ids_out, d_count_out, ctx->cnt);
-    AFF_LAUNCH_CHECK(ctx);
-    return AFFNET_OK;
+    int rc = aff_shape_filter_begin(ctx, st);
+    if (rc) return rc;
+    rc = aff_shape_filter_rows(ctx, d_resp_in, d_lafs_in, d_A, d_count_in, 0, ctx->cap_pre, false, st);
+    if (rc) return rc;
+    return aff_shape_select(ctx, d_resp_in, d_lafs_in, d_ids_in, d_A, d_count_in, d_resp_out, d_lafs_out, d_ids_out, d_count_out, st);
 }
 
 // ---- AffNet iterations (num_Baum_iters > 1, SparseImgRepresenter.py:127-146) ------------------------------------

@@ -35,12 +35,12 @@ class Context(object):
     """One extractor instance on one device: config, workspace, pyramid views."""
 
     def __init__(self, height, width, device, n_levels, init_sigma, border, mr_size, threshold,
-                 num_features, num_prefilter, max_keep=16384, batch=1, baum_iters=0, raw_div=4, onepass=False):
+                 num_features, num_prefilter, max_keep=16384, batch=1, baum_iters=0, raw_div=4, onepass=False, lazy_shape_rows=-1):
         self.plan = PyramidPlan(height, width, n_levels, init_sigma, border)
         self.batch = int(batch)
         self.onepass = bool(onepass)
         self.cfg = self.plan.fill_config(mr_size, threshold, num_features, num_prefilter, max_keep, raw_div=raw_div, batch=self.batch, baum_iters=baum_iters,
-                                         onepass=onepass)
+                                         onepass=onepass, lazy_shape_rows=lazy_shape_rows)
         self.device = device
         self.handle = C.c_void_p()
         idx = device.index if device.index is not None else torch.cuda.current_device()

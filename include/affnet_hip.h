@@ -85,6 +85,10 @@ typedef struct affnet_config {
      * level_blur like every other octave (the usual case, init_sigma > 0.5). */
     int32_t level_blur0_taps[AFFNET_MAX_LEVELS];
     float level_blur0[AFFNET_MAX_LEVELS][AFFNET_MAX_TAPS * AFFNET_MAX_TAPS];
+    int32_t lazy_shape_rows;               /* fused path, AffNetFast, one shape iteration: AffNet first runs on this many of the response-sorted
+                                            * candidates and on the rest only if fewer than N of them survive the shape filter (device-side
+                                            * decision, identical output rows).  0 = evaluate all C candidates at once like the reference,
+                                            * < 0 = default (1.2 N)                                                              */
     int32_t onepass;                       /* != 0: context for the OnePassSIR path (OnePassSIR.py:14-153): the workspace also holds a
                                             * dense affine-shape map per octave + the dense net's scratch; num_prefilter must equal
                                             * num_features (no shape-filter stage) and every octave must be >= 34 px (LocalNorm2d(33)
@@ -386,7 +390,8 @@ int affnet_profile_read(affnet_ctx* ctx, double sum_ms[AFFNET_PROFILE_STAGES], i
 int affnet_read_counts(affnet_ctx* ctx, int32_t out[4], void* stream);
 
 /* The same counters without a host synchronisation: int32 offset (from the workspace base) of a per-image device counter of image 0
- * and the int32 stride between images.  which: 0 = capacity-overflow flag, 1 = rows after detection, 2 = rows after the shape filter.
+ * and the int32 stride between images.  which: 0 = capacity-overflow flag, 1 = rows after detection, 2 = rows after the shape filter,
+ * 3 = candidates the shape CNN was actually evaluated on (cfg->lazy_shape_rows).
  * Valid once the enqueued work has completed on the stream; -1 for a context without a workspace layout. */
 int64_t affnet_counter_offset(const affnet_ctx* ctx, int which);
 int64_t affnet_counter_stride(const affnet_ctx* ctx);

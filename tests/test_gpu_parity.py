@@ -706,6 +706,53 @@ def test_metric_configuration_batched_b32_vs_oracle(amd, nets, weights, golden_d
     assert len(gi) >= 0.995 * 2000 and (dl < 1e-3).mean() >= 0.995 and (dd < 1e-3).mean() >= 0.995 and dl.max() < 1e-2
 
 
+def test_lazy_shape_evaluation_gives_identical_rows(amd, nets, weights):
+    """affnet_config.lazy_shape_rows: AffNet first runs on the 1.2 N best of the 1.5 N response-sorted candidates and on the rest only
+    for images that do not reach N survivors of the shape filter (device-side decision).  Every setting must give bit-identical
+    rows: all-at-once (0), the default, a window so small that the second pass is needed, and the unsorted case (fewer than C
+    candidates: the detections come in (octave, level, pixel) order and the second pass must always run)."""
+    A, O, H = nets
+    x = orc.synthetic_image(240, 320, 1).to(DEV)
+
+    def run(n, lazy):
+        det = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=n, border=5, num_Baum_iters=1, AffNet=A, OriNet=O).to(DEV)
+        det.lazy_shape_rows = lazy
+        r = det.run(x, do_ori=True, desc=H)
+        return r, int(det._ctx.counter_view(3)[0]), int(det._ctx.read_counts()[0])
+
+    ref, ev0, n_det = run(300, 0)
+    assert n_det == 450 and ev0 == 450                                   # all C candidates through AffNet, like the reference
+    for lazy, want_eval in ((-1, None), (360, None), (301, 450), (449, None), (450, 450), (10 ** 6, 450)):
+        got, ev, _ = run(300, lazy)
+        for k in ("LAFs", "responses", "descriptors", "ids"):
+            assert torch.equal(got[k], ref[k]), (lazy, k)
+        assert ev in ((360 if lazy in (-1, 360) else lazy), 450), (lazy, ev)
+        if want_eval is not None:
+            assert ev == want_eval, (lazy, ev)
+    _, ev_default, _ = run(300, -1)
+    record_parity("lazy shape evaluation 320x240, N = 300", candidates=450, evaluated_default_window=ev_default, evaluated_all_at_once=ev0)
+    # unsorted detections: total candidates n with 1.2 N < n <= 1.5 N
+    big = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=100000, border=5, num_Baum_iters=0).to(DEV)
+    big.max_keep = 1 << 17
+    small = orc.synthetic_image(120, 160, 3)
+    n_total = big(small.to(DEV))[0].shape[0]
+    N = int(np.ceil(n_total / 1.4))
+    assert 1.2 * N < n_total <= int(1.5 * N), (n_total, N)
+    outs = []
+    for lazy in (0, -1):
+        det = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=N, border=5, num_Baum_iters=1, AffNet=A, OriNet=O).to(DEV)
+        det.lazy_shape_rows = lazy
+        outs.append(det.run(small.to(DEV), do_ori=True, desc=H))
+        assert int(det._ctx.counter_view(3)[0]) == n_total               # not response-sorted: everything is evaluated
+    for k in ("LAFs", "responses", "descriptors", "ids"):
+        assert torch.equal(outs[0][k], outs[1][k]), k
+    ex = orc.OracleExtractor(mrSize=5.192, num_features=N, border=5, num_Baum_iters=1, affnet_sd=weights["AffNet"], orinet_sd=weights["OriNet"])
+    Lw, rw = ex(small, do_ori=True)
+    gi, wi = _match(outs[1]["ids"].cpu().numpy(), ex.keys.numpy())
+    assert len(gi) >= 0.99 * Lw.shape[0] and abs(outs[1]["LAFs"].shape[0] - Lw.shape[0]) <= 2
+    assert np.abs(outs[1]["LAFs"].cpu().numpy()[gi] - Lw.numpy()[wi]).max() < 1e-3
+
+
 def test_hip_graph_replay_equals_eager(amd, nets):
     """affnet_graph_capture_extract / affnet_graph_launch: the whole path as one HIP graph gives bit-identical results to the eager call,
     for new image content copied into the captured input, on single images and on batches."""
