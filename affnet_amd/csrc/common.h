@@ -29,6 +29,7 @@ enum {
     CNT_CAND2,                               // OnePassSIR: candidates that passed the per-level top-k and the boundary test
     CNT_AFF_EVAL,                            // candidates the shape CNN was actually evaluated on (lazy second pass, pipeline.hip)
     CNT_SURVIVED1,                           // survivors of the first (lazy) shape pass, frozen before the second pass starts
+    CNT_SEL_EQ_TOTAL,                        // candidates whose response equals the top-k threshold (ties: taken in key order)
     CNT_POS0 = AFFNET_MAX_OCTAVES + 16,      // CNT_POS0 + (level-1)*AFFNET_MAX_OCTAVES + o : positive maxima of (octave, level)
     CNT_TOTAL = AFFNET_MAX_OCTAVES + 16 + (AFFNET_MAX_LEVELS - 2) * AFFNET_MAX_OCTAVES
 };

@@ -357,6 +357,10 @@ __device__ __forceinline__ uint32_t order_key(float f) {   // larger float -> la
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+__device__ __forceinline__ unsigned long long ord_key(const int32_t* ids) {  // (octave, level, pixel) lexicographic
+    return ((unsigned long long)(uint32_t)ids[0] << 40) | ((unsigned long long)(uint32_t)ids[1] << 32) | (uint32_t)ids[2];
+}
+
 // One workgroup.  Decides the selection mode and, for top-k, the threshold key by an MSB-first
 // 8-bit radix select over all candidates.
 __global__ __launch_bounds__(1024) void select_prepare_kernel(const float* __restrict__ resp, int32_t* cnt, int cand_cap, int C,
@@ -405,6 +409,7 @@ __global__ __launch_bounds__(1024) void select_prepare_kernel(const float* __res
         cnt[CNT_SEL_MODE] = 1;
         cnt[CNT_SEL_THRESH] = (int32_t)s_prefix;        // key of the C-th largest response
         cnt[CNT_SEL_NEED_EQ] = (int32_t)s_need;         // how many elements equal to it are inside the top C
+        cnt[CNT_SEL_EQ_TOTAL] = (int32_t)hist[s_prefix & 255u];   // how many elements equal it at all (last pass: bucket = full key)
     }
 }
 
@@ -425,7 +430,18 @@ __global__ __launch_bounds__(256) void select_compact_kernel(const float* __rest
     if (cnt[CNT_SEL_MODE] == 1) {
         const uint32_t k = order_key(resp[i]), T = (uint32_t)cnt[CNT_SEL_THRESH];
         take = k > T;
-        if (k == T) take = atomicAdd(&cnt[CNT_EQ_TAKEN], 1) < cnt[CNT_SEL_NEED_EQ];
+        if (k == T) {
+            // Ties at the threshold (torch.topk's choice among equal values is unspecified): deterministic - the first NEED_EQ of them
+            // in (octave, level, pixel) order.  Almost always every tied element is needed and nothing has to be ranked.
+            const int need = cnt[CNT_SEL_NEED_EQ];
+            take = true;
+            if (cnt[CNT_SEL_EQ_TOTAL] != need) {
+                const unsigned long long mine = ord_key(ids + 3 * i);
+                int before = 0;
+                for (int j = 0; j < n; ++j) before += (order_key(resp[j]) == T && ord_key(ids + 3 * j) < mine) ? 1 : 0;
+                take = before < need;
+            }
+        }
     }
     if (!take) return;
     const int slot = atomicAdd(&cnt[CNT_SEL], 1);
@@ -433,10 +449,6 @@ __global__ __launch_bounds__(256) void select_compact_kernel(const float* __rest
     sel_resp[slot] = resp[i];
     sel_syx[3 * slot] = syx[3 * i]; sel_syx[3 * slot + 1] = syx[3 * i + 1]; sel_syx[3 * slot + 2] = syx[3 * i + 2];
     sel_ids[3 * slot] = ids[3 * i]; sel_ids[3 * slot + 1] = ids[3 * i + 1]; sel_ids[3 * slot + 2] = ids[3 * i + 2];
-}
-
-__device__ __forceinline__ unsigned long long ord_key(const int32_t* ids) {  // (octave, level, pixel) lexicographic
-    return ((unsigned long long)(uint32_t)ids[0] << 40) | ((unsigned long long)(uint32_t)ids[1] << 32) | (uint32_t)ids[2];
 }
 
 // Rank sort, split over a 2-D grid: block (bx, by) counts, for its 256 rows i, how many of the 256 rows j
@@ -511,7 +523,7 @@ struct AffMaps {
 // One workgroup per (octave, detection level, image).  The reference takes the top `num_features` responses of a LEVEL when the
 // level has more positive maxima than that (HandCraftedModules.py:323-327) - before OnePassSIR drops frames that touch the image
 // boundary - so the per-level cut cannot be folded into the global top-k as in the patch-based detector.  MSB-first 8-bit radix
-// select over the level's candidates -> tab[(o * MAX_LEVELS + l - 1) * 4 ..] = {mode, threshold key, ties to take, ties taken}.
+// select over the level's candidates -> tab[(o * MAX_LEVELS + l - 1) * 4 ..] = {mode, threshold key, ties to take, ties in total}.
 __global__ __launch_bounds__(1024) void onepass_level_select_kernel(const float* __restrict__ resp, const int32_t* __restrict__ ids, const int32_t* cnt,
                                                                     int cand_cap, int N, int n_detect, int32_t* tab) {
     __shared__ uint32_t hist[256];
@@ -552,11 +564,11 @@ __global__ __launch_bounds__(1024) void onepass_level_select_kernel(const float*
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { tab[0] = 1; tab[1] = (int32_t)s_prefix; tab[2] = (int32_t)s_need; tab[3] = 0; }
+    if (threadIdx.x == 0) { tab[0] = 1; tab[1] = (int32_t)s_prefix; tab[2] = (int32_t)s_need; tab[3] = (int32_t)hist[s_prefix & 255u]; }
 }
 
 __global__ __launch_bounds__(256) void onepass_filter_kernel(const float* __restrict__ resp, const float* __restrict__ syx, const int32_t* __restrict__ ids,
-                                                             int32_t* cnt, int cand_cap, int32_t* tab, AffMaps am, float* out_resp, float* out_syx,
+                                                             int32_t* cnt, int cand_cap, const int32_t* tab, AffMaps am, float* out_resp, float* out_syx,
                                                              int32_t* out_ids) {
     {
         const size_t img = blockIdx.y;
@@ -574,11 +586,17 @@ __global__ __launch_bounds__(256) void onepass_filter_kernel(const float* __rest
     if (keep) {
         o = ids[3 * i]; l1 = ids[3 * i + 1]; pix = ids[3 * i + 2];
         r = resp[i];
-        int32_t* t = tab + (o * AFFNET_MAX_LEVELS + l1) * 4;
+        const int32_t* t = tab + (o * AFFNET_MAX_LEVELS + l1) * 4;
         if (t[0] == 1) {                                       // this level keeps only its top num_features responses
             const uint32_t k = order_key(r), T = (uint32_t)t[1];
             keep = k > T;
-            if (k == T) keep = atomicAdd(&t[3], 1) < t[2];
+            if (k == T && t[3] != t[2]) {                      // more ties than needed: the first ones in pixel order (deterministic)
+                int before = 0;
+                for (int j = 0; j < n; ++j) before += (ids[3 * j] == o && ids[3 * j + 1] == l1 && order_key(resp[j]) == T && ids[3 * j + 2] < pix) ? 1 : 0;
+                keep = before < t[2];
+            } else if (k == T) {
+                keep = true;
+            }
         }
     }
     if (keep) {

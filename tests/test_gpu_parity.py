@@ -706,6 +706,40 @@ def test_metric_configuration_batched_b32_vs_oracle(amd, nets, weights, golden_d
     assert len(gi) >= 0.995 * 2000 and (dl < 1e-3).mean() >= 0.995 and (dd < 1e-3).mean() >= 0.995 and dl.max() < 1e-2
 
 
+def test_exact_response_ties_are_resolved_deterministically(amd, nets):
+    """A periodic image has many keypoints with bit-identical responses, so the top-k cuts fall inside groups of ties.  torch.topk's
+    choice among equal values is unspecified; here ties are taken in (octave, level, pixel) order: the selected RESPONSES equal the
+    oracle's as a multiset, and repeated runs give identical rows (no atomics decide who is in)."""
+    g = torch.Generator().manual_seed(3)
+    blk = torch.rand(1, 1, 48, 64, generator=g) * 255.0
+    x = blk.repeat(1, 1, 5, 5).contiguous()                              # 240 x 320, period (48, 64)
+    A, O, H = nets
+    for n in (100, 300):
+        runs = []
+        for _ in range(3):
+            det = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=n, border=5, num_Baum_iters=0).to(DEV)
+            L, r = det(x.to(DEV))
+            runs.append((L.clone(), r.clone(), det.last_ids.clone()))
+        for L, r, ids in runs[1:]:
+            assert torch.equal(L, runs[0][0]) and torch.equal(r, runs[0][1]) and torch.equal(ids, runs[0][2])
+        ex = orc.OracleExtractor(mrSize=5.192, num_features=n, border=5, num_Baum_iters=0)
+        Lw, rw = ex(x)
+        got, want = np.sort(runs[0][1].cpu().numpy()), np.sort(rw.numpy())
+        assert got.shape == want.shape and np.array_equal(got, want), "selected responses differ from the oracle's as a multiset"
+        u, c = np.unique(want, return_counts=True)
+        assert c.max() >= 4, "the image was meant to produce exact ties"
+        # within the tie group at the cut, the taken keypoints are the first ones in key order
+        keys = _keys(runs[0][2].cpu().numpy())
+        last = runs[0][1].cpu().numpy() == runs[0][1].cpu().numpy().min()
+        assert np.all(np.diff(keys[last]) > 0) or last.sum() == 1
+    # full path with ties: deterministic too
+    det = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=200, border=5, num_Baum_iters=1, AffNet=A, OriNet=O).to(DEV)
+    a = det.run(x.to(DEV), do_ori=True, desc=H)
+    b = det.run(x.to(DEV), do_ori=True, desc=H)
+    for k in ("LAFs", "responses", "descriptors", "ids"):
+        assert torch.equal(a[k], b[k]), k
+
+
 def test_lazy_shape_evaluation_gives_identical_rows(amd, nets, weights):
     """affnet_config.lazy_shape_rows: AffNet first runs on the 1.2 N best of the 1.5 N response-sorted candidates and on the rest only
     for images that do not reach N survivors of the shape filter (device-side decision).  Every setting must give bit-identical
