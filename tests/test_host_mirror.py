@@ -192,3 +192,15 @@ def test_exact_arithmetic_spec_of_the_blur():
         for j in range(k):
             acc = (xp[i:i + 40, j:j + 56].astype(np.float64) * np.float64(ker[i, j]) + acc.astype(np.float64)).astype(np.float32)
     assert np.array_equal(acc, ref)
+
+
+def test_headers_are_plain_c():
+    """The drop-in boundary is a C ABI: both headers must compile as C99 (no C++ constructs, no torch / HIP types)."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    for h in ("affnet_hip.h", "affnet_hip_debug.h"):
+        subprocess.check_call(["gcc", "-std=c99", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", h)])
+        src = open(os.path.join(ROOT, "include", h)).read()
+        assert "hip/" not in src and "torch" not in re.sub(r"/\*.*?\*/", "", src, flags=re.S), h
