@@ -593,8 +593,9 @@ def run(args, world):
                        "streams_per_gpu": "1 CNN stream + 1 detector stream (2 contexts alternate)" if PIPE else S,
                        "h2d": "every step uploads its images from pinned host memory on a copy stream (double-buffered)" if H2D
                               else "images resident in HBM before the timed region",
-                       "parallelism": ("image-per-GPU x%d, %s of padded {int32 count, LAFs, responses, descriptors} records over RCCL"
-                                       % (world, "all_gather" if gather_dst is None else "gather to rank 0")) if world > 1 else "1 GPU"},
+                       "parallelism": ("image-per-GPU x%d, %s of padded {int32 count, LAFs, responses, descriptors} records over %s"
+                                       % (world, "all_gather" if gather_dst is None else "gather to rank 0",
+                                          "RCCL" if backend == "nccl" else backend + " (dry run of the N-rank path)")) if world > 1 else "1 GPU"},
             "ms_per_image": tmax / (args.steps * args.batch) * 1e3,
             "stage_ms_per_image": dict(zip(names, [round(v, 4) for v in stage_ms])),
             "roofline": {"kernel": "cnn32_trunk_kernel<HardNet> (fp32 MFMA 16x16x4, fused sampler+norm+6 convs)", "bound": "mfma",
