@@ -153,6 +153,27 @@ def test_onepass_sir_vs_oracle_and_golden(amd, nets, weights, golden_dir):
         assert np.abs(L2.cpu().numpy() - g["LAFs_all_noori"]).max() < 1e-3
 
 
+@pytest.mark.parametrize("th", [-1, 28.41])
+def test_onepass_sir_threshold_mode(amd, nets, weights, th):
+    """The reference's OnePassSIR scripts run in threshold mode (extract_geomOriTh.py:74: th = 28.41, num_features = -1): every
+    scale-space maximum above the threshold whose frame stays inside the image is kept, (octave, level, pixel) order."""
+    FC, O, H = nets
+    x = orc.synthetic_image(240, 320, 1)
+    det = amd.OnePassSIR(mrSize=5.192, num_features=-1, th=th, border=15, num_Baum_iters=1, AffNet=FC, OriNet=O).to(DEV)
+    res = det.run(x.to(DEV), do_ori=True, desc=H)
+    ex = opo.OnePassOracle(mrSize=5.192, num_features=-1, th=th, border=15, affnet_sd=weights["AffNet"], orinet_sd=weights["OriNet"])
+    Lw, rw = ex(x, do_ori=True)
+    L, r = res["LAFs"].cpu().numpy(), res["responses"].cpu().numpy()
+    gi, wi = _match(res["ids"].cpu().numpy(), ex.keys.numpy())
+    dl = np.abs(L[gi] - Lw.numpy()[wi]).reshape(len(gi), -1).max(axis=1)
+    record_parity("OnePassSIR threshold mode th = %g, 320x240" % th, rows=int(L.shape[0]), oracle_rows=int(Lw.shape[0]), matched=int(len(gi)),
+                  laf_max_px=float(dl.max()), laf_rows_within_1e_3=float((dl < 1e-3).mean()), same_row_order=bool(len(gi) == Lw.shape[0] and np.array_equal(gi, wi)))
+    assert abs(L.shape[0] - Lw.shape[0]) <= 0.005 * Lw.shape[0] + 1              # the x3.0 boundary test compares floats against 0 / 1
+    assert len(gi) >= 0.995 * Lw.shape[0] and np.array_equal(r[gi], rw.numpy()[wi])
+    assert (dl < 1e-3).mean() >= 0.995 and dl.max() < 1e-2
+    assert np.all(np.diff(_keys(res["ids"].cpu().numpy())) > 0), "threshold mode emits (octave, level, pixel) order"
+
+
 def test_onepass_sir_metric_size(amd, nets, weights):
     """1024 x 768, 2000 kp: the per-level top-k really cuts here (octave 0 levels hold more than 2000 positive maxima)."""
     _check_onepass(amd, nets, weights, orc.synthetic_image(768, 1024, 1), 2000, "OnePassSIR 1024x768, 2000 kp")
