@@ -19,4 +19,22 @@ grep -E "passed|failed" gpurun_out/pytest_gpu.log | tail -n 1 > profiles/${T}_py
 grep -E "^(PASSED|FAILED)" gpurun_out/pytest_gpu.log >> profiles/${T}_pytest_gpu_summary.txt
 tail -n 1 gpurun_out/smoke.log >> profiles/${T}_pytest_gpu_summary.txt
 python tools/roofline_table.py profiles/${T} > profiles/${T}_roofline_table.md
+if [ -f gpurun_out/traffic_sampler.json ]; then
+  python - "$T" <<'PY'
+import csv, json, sys
+t = sys.argv[1]
+tr = json.load(open("gpurun_out/traffic_sampler.json"))["kernels"]
+rows = {r["Name"].split("(")[0]: r for r in csv.DictReader(open("gpurun_out/prof_sampler/run_kernel_stats.csv"))}
+out = {"what": "stand-alone grid_sample_kernel (bench.py secondary_rooflines section: 3000 + 2 x 2000 patches per image, 32 images per launch): "
+               "rocprofv3 mean duration and calibrated FETCH_SIZE / WRITE_SIZE per launch", "launches": []}
+for k, v in tr.items():
+    if "grid_sample_kernel" in k and k in rows:
+        ns = float(rows[k]["AverageNs"])
+        out["launches"].append({"kernel": k, "calls": int(rows[k]["Calls"]), "mean_us": ns / 1e3, "hbm_bytes_per_launch": v["hbm_bytes"],
+                                "fetch_bytes": v["fetch_bytes"], "write_bytes": v["write_bytes"], "calibration": v["calibration"],
+                                "pmc_GBs": v["hbm_bytes"] / ns, "frac_of_8TBs": v["hbm_bytes"] / ns / 8000.0})
+json.dump(out, open("profiles/%s_sampler_traffic.json" % t, "w"), indent=1)
+print(json.dumps(out["launches"], indent=1)[:600])
+PY
+fi
 ls -la profiles/${T}_*

@@ -35,4 +35,11 @@ if [ "$SKIP_PMC" != "1" ]; then
   python tools/pmc_summary.py $(P 1) $(P 2) $(P 3) $(P 4) > gpurun_out/pmc_summary.txt 2>&1
   python tools/pmc_traffic.py $(P 3) $(P 4) 32 gpurun_out/fetch_calibration.json > gpurun_out/traffic.json 2> gpurun_out/traffic.log
   head -16 gpurun_out/pmc_summary.txt
+  # the stand-alone sampler (secondary_rooflines section of bench.py): kernel stats + FETCH / WRITE passes of a run that includes it
+  CMD2="python bench.py --steps 1 --warmup 1 --batch 32 --chunk 32 --no-cpu-baseline"
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_sampler -o run -- $CMD2 > gpurun_out/prof_sampler.log 2>&1; echo "prof sampler exit $?"
+  timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_sampler_f -o run -- $CMD2 > gpurun_out/pmc_sampler_f.log 2>&1; echo "pmc sampler fetch exit $?"
+  timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_sampler_w -o run -- $CMD2 > gpurun_out/pmc_sampler_w.log 2>&1; echo "pmc sampler write exit $?"
+  python tools/pmc_traffic.py gpurun_out/pmc_sampler_f gpurun_out/pmc_sampler_w 32 gpurun_out/fetch_calibration.json > gpurun_out/traffic_sampler.json 2>> gpurun_out/traffic.log
+  grep -A8 "grid_sample_kernel" gpurun_out/traffic_sampler.json | head -12; grep "grid_sample_kernel" gpurun_out/prof_sampler/run_kernel_stats.csv | cut -c1-200
 fi
