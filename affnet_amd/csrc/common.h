@@ -34,6 +34,8 @@ enum {
     CNT_TOTAL = AFFNET_MAX_OCTAVES + 16 + (AFFNET_MAX_LEVELS - 2) * AFFNET_MAX_OCTAVES
 };
 
+#define SEL_HIST_BINS 2048      // first digit (11 bits) of the global top-k's radix select, histogrammed by many workgroups
+
 struct RawMax {            // one 3-D local maximum found by hessian_nms_kernel
     int32_t pix;           // flat pixel index y*w+x in the octave
     int32_t lvl;           // detection level 1..nLevels
@@ -61,7 +63,7 @@ struct affnet_ctx {
     std::string err;
     OctaveGeom oct[AFFNET_MAX_OCTAVES];
     // workspace layout (byte offsets from the workspace base)
-    size_t off_pyr = 0, off_map = 0, off_raw = 0, off_cnt = 0, off_cand = 0, off_sel = 0, off_stage = 0;
+    size_t off_pyr = 0, off_map = 0, off_raw = 0, off_cnt = 0, off_hist = 0, off_cand = 0, off_sel = 0, off_stage = 0;
     // OnePassSIR extras (cfg.onepass != 0): dense affine-shape maps (4, h_o, w_o) per octave, the dense net's scratch, a second
     // candidate list and the per-(octave, level) top-k table
     size_t off_affmap = 0, off_dense = 0, off_cand2 = 0, off_lvltab = 0;
@@ -80,6 +82,7 @@ struct affnet_ctx {
     uint8_t* omap = nullptr;
     RawMax* raw = nullptr;
     int32_t* cnt = nullptr;
+    uint32_t* sel_hist = nullptr;        // B x SEL_HIST_BINS: histogram of the top 11 key bits of the candidate responses
     float* cand_resp = nullptr; float* cand_syx = nullptr; int32_t* cand_ids = nullptr;
     float* sel_resp = nullptr; float* sel_syx = nullptr; int32_t* sel_ids = nullptr;
     // pipeline stage buffers
@@ -153,6 +156,14 @@ int aff_fail(affnet_ctx* ctx, int code, const char* fmt, ...);
 // runtime's blit path shares per-queue state with captured graph nodes (replaying a captured graph after eager null-stream
 // memsets faulted on ROCm 7.2), and a kernel of our own is also what a stream capture records most cheaply.
 int aff_zero_async(affnet_ctx* ctx, void* dst, size_t bytes, hipStream_t st);
+// up to 8 fills in one launch
+struct AffZeroSegs {
+    unsigned char* p[8];
+    size_t bytes[8];
+    int n = 0;
+    void add(void* ptr, size_t nbytes) { if (ptr && nbytes && n < 8) { p[n] = (unsigned char*)ptr; bytes[n] = nbytes; ++n; } }
+};
+int aff_zero_multi_async(affnet_ctx* ctx, const AffZeroSegs& z, hipStream_t st);
 int aff_copy_async(affnet_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t st);
 // rows x width_bytes, row r at dst + r * dpitch / src + r * spitch (all multiples of 4 bytes)
 int aff_copy2d_async(affnet_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes, size_t rows, hipStream_t st);

@@ -26,6 +26,34 @@ __global__ __launch_bounds__(256) void aff_zero_kernel(unsigned char* __restrict
     }
 }
 
+// Several fills in ONE launch (blockIdx.y = segment): at one image per call every launch costs ~5 us whatever it does, and the
+// detector alone cleared six areas.
+__global__ __launch_bounds__(256) void aff_zero_multi_kernel(AffZeroSegs z) {
+    unsigned char* p = z.p[blockIdx.y];
+    const size_t bytes = z.bytes[blockIdx.y];
+    const size_t head = ((16 - ((size_t)p & 15)) & 15) < bytes ? ((16 - ((size_t)p & 15)) & 15) : bytes;
+    const size_t n16 = (bytes - head) / 16, tail0 = head + n16 * 16;
+    uint4* q = reinterpret_cast<uint4*>(p + head);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) q[i] = make_uint4(0u, 0u, 0u, 0u);
+    if (blockIdx.x == 0) {
+        for (size_t i = threadIdx.x; i < head; i += 256) p[i] = 0;
+        for (size_t i = tail0 + threadIdx.x; i < bytes; i += 256) p[i] = 0;
+    }
+}
+
+int aff_zero_multi_async(affnet_ctx* ctx, const AffZeroSegs& z, hipStream_t st) {
+    if (z.n <= 0) return AFFNET_OK;
+    size_t blocks = 1;
+    for (int i = 0; i < z.n; ++i) {
+        const size_t b = (z.bytes[i] / 16 + 255) / 256;
+        blocks = b > blocks ? b : blocks;
+    }
+    blocks = blocks > 2048 ? 2048 : blocks;
+    hipLaunchKernelGGL(aff_zero_multi_kernel, dim3((unsigned)blocks, (unsigned)z.n), dim3(256), 0, st, z);
+    AFF_LAUNCH_CHECK(ctx);
+    return AFFNET_OK;
+}
+
 __global__ __launch_bounds__(256) void aff_copy2d_kernel(uint32_t* __restrict__ dst, size_t dpitch_w, const uint32_t* __restrict__ src, size_t spitch_w,
                                                          size_t width_w) {
     const uint32_t* s = src + (size_t)blockIdx.y * spitch_w;
@@ -141,6 +169,7 @@ extern "C" int affnet_ctx_create(affnet_ctx** out, int device, const affnet_conf
     ctx->off_map = off; off += B * ctx->map_stride;
     ctx->off_raw = off; off += aff_align(B * raw * sizeof(RawMax));
     ctx->off_cnt = off; off += aff_align(B * CNT_TOTAL * sizeof(int32_t));
+    ctx->off_hist = off; off += aff_align(B * SEL_HIST_BINS * sizeof(uint32_t));   // top-digit histogram of the global top-k (detect.hip)
     ctx->off_cand = off; off += aff_align(B * ctx->cand_cap * 7 * sizeof(float));   // resp + syx[3] + ids[3]
     ctx->off_sel = off; off += aff_align(B * (size_t)ctx->cap_pre * 7 * sizeof(float));
     ctx->off_stage = off;
@@ -236,6 +265,7 @@ extern "C" int affnet_bind_workspace(affnet_ctx* ctx, void* d_workspace, size_t 
     ctx->omap = (uint8_t*)(b + ctx->off_map);
     ctx->raw = (RawMax*)(b + ctx->off_raw);
     ctx->cnt = (int32_t*)(b + ctx->off_cnt);
+    ctx->sel_hist = (uint32_t*)(b + ctx->off_hist);
     const size_t B = (size_t)ctx->B;
     float* cand = (float*)(b + ctx->off_cand);
     const size_t CC = B * ctx->cand_cap;

@@ -36,16 +36,24 @@
 #define HR_S (HR_W + 1)   // padded row stride
 #define HN_CAP 320        // per-workgroup staging capacity (1024 px x 3 levels; ~2% are maxima)
 
-struct HessParams {
+struct HessOct {           // one octave of the launch
     const float* levels;   // 5 blurred levels of this octave, contiguous
-    int h, w, n_levels;    // n_levels = levels_per_octave (5)
+    RawMax* raw;
+    int32_t* raw_cnt;
+    int h, w, raw_cap;
+    int tiles_x, tile_begin;   // tiles per row; first flat tile index (blockIdx.x) of this octave
     float sigma[AFFNET_MAX_LEVELS];
     float sigma4[AFFNET_MAX_LEVELS];
+};
+
+// ONE launch covers every octave (blockIdx.x = flat tile index over all octaves, largest octave first; blockIdx.z = image): six
+// launches per image were 85 us at one image per call, the small octaves (<= 40 tiles) each as long as the first (latency of one
+// workgroup), and in batched calls their tails no longer idle the chip.
+struct HessParams {
+    HessOct oct[AFFNET_MAX_OCTAVES];
+    int n_oct, n_levels;   // n_levels = levels_per_octave (5)
     float th;
     int border;            // int(mrSize)
-    RawMax* raw;
-    int raw_cap;
-    int32_t* raw_cnt;
     int32_t* overflow;
     // batch (blockIdx.z = image): per-image strides of the pyramid (floats), the raw lists (entries), the counters
     size_t levels_stride, raw_stride;
@@ -68,7 +76,7 @@ __device__ __forceinline__ float hessian_at(const float* __restrict__ X, int ty,
 
 // NL = levels per octave = nLevels + 2 (5 for the reference's default nlevels = 3; 3..8 are instantiated)
 template <int NL>
-__global__ __launch_bounds__(256) void hessian_nms_kernel(HessParams p) {
+__global__ __launch_bounds__(256) void hessian_nms_kernel(HessParams hp) {
     // LDS: NL blurred tiles (20x68) + NL response tiles (18x67)
     __shared__ __attribute__((aligned(16))) float X[NL][HX_H * HX_W];
     __shared__ float Rr[NL][HR_H * HR_S];
@@ -79,13 +87,25 @@ __global__ __launch_bounds__(256) void hessian_nms_kernel(HessParams p) {
     static_assert(sizeof(RawMax) * HN_CAP <= sizeof(float) * NL * HX_H * HX_W, "staging list must fit in the tile area");
     __shared__ int s_n, s_base;
     if (threadIdx.x == 0) s_n = 0;
+    int oi = 0;
+    while (oi + 1 < hp.n_oct && (int)blockIdx.x >= hp.oct[oi + 1].tile_begin) ++oi;      // uniform: scalar loads from the kernel arguments
+    struct {                                       // this tile's octave + the launch-wide fields, under the names the body uses
+        const float* levels; RawMax* raw; int32_t* raw_cnt; int32_t* overflow;
+        int h, w, raw_cap, border, precomputed;
+        float th;
+        float sigma[NL], sigma4[NL];
+    } p;
+    p.h = hp.oct[oi].h; p.w = hp.oct[oi].w; p.raw_cap = hp.oct[oi].raw_cap; p.border = hp.border; p.precomputed = hp.precomputed; p.th = hp.th;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) { p.sigma[l] = hp.oct[oi].sigma[l]; p.sigma4[l] = hp.oct[oi].sigma4[l]; }
     const int h = p.h, w = p.w;
-    const int x0 = blockIdx.x * HT_X, y0 = blockIdx.y * HT_Y;
+    const int tile = (int)blockIdx.x - hp.oct[oi].tile_begin, tiles_x = hp.oct[oi].tiles_x;
+    const int x0 = (tile % tiles_x) * HT_X, y0 = (tile / tiles_x) * HT_Y;
     const size_t lvl_stride = (size_t)h * w;
-    p.levels += blockIdx.z * p.levels_stride;
-    p.raw += blockIdx.z * p.raw_stride;
-    p.raw_cnt += blockIdx.z * CNT_TOTAL;
-    p.overflow += blockIdx.z * CNT_TOTAL;
+    p.levels = hp.oct[oi].levels + blockIdx.z * hp.levels_stride;
+    p.raw = hp.oct[oi].raw + blockIdx.z * hp.raw_stride;
+    p.raw_cnt = hp.oct[oi].raw_cnt + blockIdx.z * CNT_TOTAL;
+    p.overflow = hp.overflow + blockIdx.z * CNT_TOTAL;
     if (!p.precomputed) {
         // All NL x 6 loads of a thread are issued before the first one is consumed (the element -> pixel mapping is the same
         // for every level).  Written as load-then-store per element the compiler put s_waitcnt vmcnt(0) behind each load:
@@ -361,14 +381,73 @@ __device__ __forceinline__ unsigned long long ord_key(const int32_t* ids) {  // 
     return ((unsigned long long)(uint32_t)ids[0] << 40) | ((unsigned long long)(uint32_t)ids[1] << 32) | (uint32_t)ids[2];
 }
 
-// One workgroup.  Decides the selection mode and, for top-k, the threshold key by an MSB-first
-// 8-bit radix select over all candidates.
+// Radix select of the C-th largest response, digits of 11 / 11 / 10 bits.
+//   select_hist_kernel    many workgroups per image: LDS histogram of the FIRST digit of every candidate, non-empty bins added to
+//                         the image's global histogram (sel_hist, zeroed with the counters);
+//   select_prepare_kernel one workgroup per image: picks the first digit from that histogram without touching the candidates,
+//                         then ONE pass over them collects the keys of that bucket in LDS (when they fit) and the second and third
+//                         digit are decided from there.
+// (The former single-workgroup select made four passes over the candidates with an LDS atomic per key and let thread 0 walk the
+// 256 bins after each: 35 us for 10^4 candidates, 250 us for the 8 x 2.5 * 10^5 of a 4K batch - on 8 of 256 CUs.)
+__global__ __launch_bounds__(256) void select_hist_kernel(const float* __restrict__ resp, const int32_t* __restrict__ cnt, int cand_cap, int C,
+                                                          uint32_t* __restrict__ ghist) {
+    __shared__ uint32_t hist[SEL_HIST_BINS];
+    resp += (size_t)blockIdx.y * cand_cap;
+    cnt += blockIdx.y * CNT_TOTAL;
+    ghist += (size_t)blockIdx.y * SEL_HIST_BINS;
+    int n = cnt[CNT_CAND];
+    if (n > cand_cap) n = cand_cap;
+    if (!(C > 0 && n > C) || (int)blockIdx.x * 1024 >= n) return;          // keep-all mode needs no threshold; no work for this workgroup
+    for (int i = threadIdx.x; i < SEL_HIST_BINS; i += 256) hist[i] = 0;
+    __syncthreads();
+    for (int i0 = blockIdx.x * 1024; i0 < n; i0 += gridDim.x * 1024) {
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int i = i0 + u * 256 + threadIdx.x; v[u] = i < n ? resp[i] : 0.0f; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (i0 + u * 256 + (int)threadIdx.x < n) atomicAdd(&hist[order_key(v[u]) >> 21], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < SEL_HIST_BINS; i += 256)
+        if (hist[i]) atomicAdd(&ghist[i], hist[i]);
+}
+
+// Descending walk over hist[nbins] (nbins = 1024 or 2048, in LDS) by the whole 1024-thread workgroup: finds the bin d with
+// sum(hist[d+1 ..]) < need <= sum(hist[d ..]) and writes out[0] = d, out[1] = need - sum(hist[d+1 ..]) (1-based rank inside bin d).
+// The caller guarantees sum(hist) >= need >= 1.  Ends with a barrier.
+__device__ __forceinline__ void radix_pick(const uint32_t* hist, int nbins, uint32_t need, uint32_t* s_wsum, uint32_t* out) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int per = nbins >> 10;
+    const int b0 = nbins - 1 - t * per;
+    const uint32_t c0 = hist[b0], c1 = per == 2 ? hist[b0 - 1] : 0u;
+    const uint32_t mine = c0 + c1;
+    uint32_t inc = mine;
+#pragma unroll
+    for (int ofs = 1; ofs < 64; ofs <<= 1) {
+        const uint32_t v = __shfl_up(inc, ofs, 64);
+        if (lane >= ofs) inc += v;
+    }
+    if (lane == 63) s_wsum[wave] = inc;
+    __syncthreads();
+    uint32_t before = inc - mine;
+    for (int w = 0; w < wave; ++w) before += s_wsum[w];
+    if (before < need && need <= before + mine) {                          // exactly one thread
+        if (need <= before + c0) { out[0] = (uint32_t)b0; out[1] = need - before; }
+        else { out[0] = (uint32_t)(b0 - 1); out[1] = need - before - c0; }
+    }
+    __syncthreads();
+}
+
+#define SEL_LIST_CAP 8192       // keys of the first digit's bucket kept in LDS (32 KB); larger buckets are re-read from global memory
 __global__ __launch_bounds__(1024) void select_prepare_kernel(const float* __restrict__ resp, int32_t* cnt, int cand_cap, int C,
-                                                              int sel_cap) {
-    __shared__ uint32_t hist[256];
-    __shared__ uint32_t s_prefix, s_mask, s_need;
+                                                              int sel_cap, const uint32_t* __restrict__ ghist) {
+    __shared__ uint32_t hist[SEL_HIST_BINS];
+    __shared__ uint32_t list[SEL_LIST_CAP];
+    __shared__ uint32_t s_wsum[16], s_pick[2], s_ln;
     resp += (size_t)blockIdx.x * cand_cap;           // blockIdx.x = image
     cnt += blockIdx.x * CNT_TOTAL;
+    ghist += (size_t)blockIdx.x * SEL_HIST_BINS;
     int n = cnt[CNT_CAND];
     if (n > cand_cap) n = cand_cap;
     if (threadIdx.x == 0) {
@@ -381,35 +460,66 @@ __global__ __launch_bounds__(1024) void select_prepare_kernel(const float* __res
         }
         return;
     }
-    if (threadIdx.x == 0) { s_prefix = 0; s_mask = 0; s_need = (uint32_t)C; }
+    // digit 1 (key bits 31..21): the histogram is already there
+    for (int i = threadIdx.x; i < SEL_HIST_BINS; i += 1024) hist[i] = ghist[i];
+    if (threadIdx.x == 0) s_ln = 0;
     __syncthreads();
-    for (int shift = 24; shift >= 0; shift -= 8) {
-        for (int i = threadIdx.x; i < 256; i += 1024) hist[i] = 0;
-        __syncthreads();
-        const uint32_t prefix = s_prefix, mask = s_mask;
-        for (int i = threadIdx.x; i < n; i += 1024) {
-            const uint32_t k = order_key(resp[i]);
-            if ((k & mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint32_t need = s_need;
-            int d = 255;
-            for (; d > 0; --d) {
-                if (hist[d] >= need) break;
-                need -= hist[d];
+    radix_pick(hist, SEL_HIST_BINS, (uint32_t)C, s_wsum, s_pick);
+    const uint32_t d1 = s_pick[0];
+    uint32_t need = s_pick[1];
+    const bool in_lds = hist[d1] <= SEL_LIST_CAP;     // uniform
+    __syncthreads();
+    // digit 2 (bits 20..10) over the keys of bucket d1; they are copied to LDS on the way when they fit
+    for (int i = threadIdx.x; i < SEL_HIST_BINS; i += 1024) hist[i] = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n; i0 += 8 * 1024) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int i = i0 + u * 1024 + threadIdx.x; v[u] = i < n ? resp[i] : 0.0f; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint32_t k = order_key(v[u]);
+            if (i0 + u * 1024 + (int)threadIdx.x < n && (k >> 21) == d1) {
+                atomicAdd(&hist[(k >> 10) & 2047u], 1u);
+                if (in_lds) list[atomicAdd(&s_ln, 1u)] = k;
             }
-            s_need = need;                              // rank inside bucket d (1-based), hist[d] >= need
-            s_prefix = prefix | ((uint32_t)d << shift);
-            s_mask = mask | (255u << shift);
         }
-        __syncthreads();
     }
+    __syncthreads();
+    radix_pick(hist, 2048, need, s_wsum, s_pick);
+    const uint32_t d2 = s_pick[0];
+    need = s_pick[1];
+    const uint32_t pre = (d1 << 11) | d2;             // key >> 10 of the threshold
+    __syncthreads();
+    // digit 3 (bits 9..0)
+    for (int i = threadIdx.x; i < 1024; i += 1024) hist[i] = 0;
+    __syncthreads();
+    if (in_lds) {
+        const int ln = (int)s_ln;
+        for (int i = threadIdx.x; i < ln; i += 1024) {
+            const uint32_t k = list[i];
+            if ((k >> 10) == pre) atomicAdd(&hist[k & 1023u], 1u);
+        }
+    } else {
+        for (int i0 = 0; i0 < n; i0 += 8 * 1024) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * 1024 + threadIdx.x; v[u] = i < n ? resp[i] : 0.0f; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t k = order_key(v[u]);
+                if (i0 + u * 1024 + (int)threadIdx.x < n && (k >> 10) == pre) atomicAdd(&hist[k & 1023u], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    radix_pick(hist, 1024, need, s_wsum, s_pick);
     if (threadIdx.x == 0) {
+        const uint32_t T = (pre << 10) | s_pick[0];
         cnt[CNT_SEL_MODE] = 1;
-        cnt[CNT_SEL_THRESH] = (int32_t)s_prefix;        // key of the C-th largest response
-        cnt[CNT_SEL_NEED_EQ] = (int32_t)s_need;         // how many elements equal to it are inside the top C
-        cnt[CNT_SEL_EQ_TOTAL] = (int32_t)hist[s_prefix & 255u];   // how many elements equal it at all (last pass: bucket = full key)
+        cnt[CNT_SEL_THRESH] = (int32_t)T;               // key of the C-th largest response
+        cnt[CNT_SEL_NEED_EQ] = (int32_t)s_pick[1];      // how many elements equal to it are inside the top C
+        cnt[CNT_SEL_EQ_TOTAL] = (int32_t)hist[s_pick[0]];   // how many elements equal it at all (last digit: bin = full key)
     }
 }
 
@@ -457,8 +567,8 @@ __global__ __launch_bounds__(256) void select_compact_kernel(const float* __rest
 // ascending = the reference's concatenation order.
 __global__ __launch_bounds__(256) void select_rank_kernel(const float* __restrict__ sel_resp, const int32_t* __restrict__ sel_ids,
                                                           const int32_t* __restrict__ cnt, int sel_cap, int32_t* __restrict__ rank) {
-    __shared__ float t_resp[256];
-    __shared__ unsigned long long t_ord[256];
+    __shared__ __attribute__((aligned(16))) float t_resp[256];
+    __shared__ __attribute__((aligned(16))) unsigned long long t_ord[256];
     {
         const size_t img = blockIdx.z;
         sel_resp += img * sel_cap; sel_ids += img * sel_cap * 3; cnt += img * CNT_TOTAL; rank += img * sel_cap;
@@ -469,20 +579,36 @@ __global__ __launch_bounds__(256) void select_rank_kernel(const float* __restric
     const int i = blockIdx.x * 256 + threadIdx.x, base = blockIdx.y * 256;
     if (blockIdx.x * 256 >= n || base >= n) return;
     const int j = base + threadIdx.x;
-    if (j < n) { t_resp[threadIdx.x] = sel_resp[j]; t_ord[threadIdx.x] = ord_key(sel_ids + 3 * j); }
+    // rows past the end of the list: -inf never precedes a (finite) response, the all-ones key never precedes a key
+    t_resp[threadIdx.x] = j < n ? sel_resp[j] : -INFINITY;
+    t_ord[threadIdx.x] = j < n ? ord_key(sel_ids + 3 * j) : ~0ull;
+    const float ri = i < n ? sel_resp[i] : 0.0f;
+    const unsigned long long oi = i < n ? ord_key(sel_ids + 3 * i) : 0ull;
     __syncthreads();
     if (i >= n) return;
-    const float ri = sel_resp[i];
-    const unsigned long long oi = ord_key(sel_ids + 3 * i);
-    const int m = (n - base) < 256 ? (n - base) : 256;
     int r = 0;
     if (mode == 1) {
-        for (int t = 0; t < m; ++t) {
-            const float rj = t_resp[t];
-            r += (rj > ri) || (rj == ri && t_ord[t] < oi);
+        // 16-byte broadcast reads, 4 comparisons each (one LDS read + wait per element made this loop 20 us for 3000 rows);
+        // equal responses (practically only the row itself) are resolved by key order in a second, rarely taken loop
+        const float4* tr = reinterpret_cast<const float4*>(t_resp);
+        int eq = 0;
+#pragma unroll 8
+        for (int t = 0; t < 64; ++t) {
+            const float4 q = tr[t];
+            r += (q.x > ri) + (q.y > ri) + (q.z > ri) + (q.w > ri);
+            eq += (q.x == ri) + (q.y == ri) + (q.z == ri) + (q.w == ri);
+        }
+        const bool self_here = (i >= base) && (i < base + 256);
+        if (eq > (self_here ? 1 : 0)) {
+            for (int t = 0; t < 256; ++t) r += (t_resp[t] == ri && t_ord[t] < oi);
         }
     } else {
-        for (int t = 0; t < m; ++t) r += t_ord[t] < oi;
+        const ulonglong2* to = reinterpret_cast<const ulonglong2*>(t_ord);
+#pragma unroll 8
+        for (int t = 0; t < 128; ++t) {
+            const ulonglong2 q = to[t];
+            r += (q.x < oi) + (q.y < oi);
+        }
     }
     if (r) atomicAdd(&rank[i], r);
 }
@@ -664,28 +790,40 @@ __global__ __launch_bounds__(256) void select_emit_onepass_kernel(const float* _
 // sequential-in-level octaveMap replay -> candidate list (ctx->cand_*, CNT_CAND) and per-level positive counts (CNT_POS0).
 // d_responses == NULL: Hessian responses computed from the pyramid in the workspace; otherwise response maps of a custom
 // RespNet slot, laid out like the pyramid (image stride = affnet_pyramid_image_stride, level offsets as the pyramid's).
-static int detect_candidates(affnet_ctx* ctx, const float* d_responses, hipStream_t st) {
+static int detect_candidates(affnet_ctx* ctx, const float* d_responses, AffZeroSegs z, hipStream_t st) {
     const affnet_config& c = ctx->cfg;
     const int NLv = c.levels_per_octave;
     if (NLv < 3 || NLv > 8) return aff_fail(ctx, AFFNET_ERR_INVALID, "detect: levels_per_octave = %d (3..8 supported)", NLv);
     const int B = ctx->B;
-    { int zrc = aff_zero_async(ctx, ctx->cnt, (size_t)B * CNT_TOTAL * sizeof(int32_t), st); if (zrc) return zrc; }
-    { int zrc = aff_zero_async(ctx, ctx->omap, (size_t)B * ctx->map_stride, st); if (zrc) return zrc; }
+    z.add(ctx->cnt, (size_t)B * CNT_TOTAL * sizeof(int32_t));
+    z.add(ctx->omap, (size_t)B * ctx->map_stride);
+    z.add(ctx->sel_hist, (size_t)B * SEL_HIST_BINS * sizeof(uint32_t));
+    { int zrc = aff_zero_multi_async(ctx, z, st); if (zrc) return zrc; }          // counters, octaveMap, histogram + the caller's areas: one launch
     ResolveParams rp;
     memset(&rp, 0, sizeof(rp));
+    HessParams hp;
+    memset(&hp, 0, sizeof(hp));
+    hp.n_oct = c.n_octaves; hp.n_levels = NLv;
+    hp.th = c.threshold;
+    hp.border = (int)c.mr_size;
+    hp.overflow = ctx->cnt + CNT_OVERFLOW;
+    hp.levels_stride = ctx->pyr_stride; hp.raw_stride = ctx->raw_stride;
+    hp.precomputed = d_responses ? 1 : 0;
+    int n_tiles = 0;
     for (int o = 0; o < c.n_octaves; ++o) {
         const OctaveGeom& g = ctx->oct[o];
-        HessParams hp;
-        hp.levels = (d_responses ? d_responses : ctx->pyr) + g.pyr_off;
-        hp.precomputed = d_responses ? 1 : 0;
-        hp.h = g.h; hp.w = g.w; hp.n_levels = NLv;
-        for (int l = 0; l < NLv; ++l) { hp.sigma[l] = c.level_sigma[o][l]; hp.sigma4[l] = c.level_sigma4[o][l]; }
-        hp.th = c.threshold;
-        hp.border = (int)c.mr_size;
-        hp.raw = ctx->raw + g.raw_off; hp.raw_cap = g.raw_cap;
-        hp.raw_cnt = ctx->cnt + CNT_RAW0 + o; hp.overflow = ctx->cnt + CNT_OVERFLOW;
-        hp.levels_stride = ctx->pyr_stride; hp.raw_stride = ctx->raw_stride;
-        const dim3 hgrid(aff_cdiv(g.w, HT_X), aff_cdiv(g.h, HT_Y), B);
+        HessOct& ho = hp.oct[o];
+        ho.levels = (d_responses ? d_responses : ctx->pyr) + g.pyr_off;
+        ho.h = g.h; ho.w = g.w;
+        for (int l = 0; l < NLv; ++l) { ho.sigma[l] = c.level_sigma[o][l]; ho.sigma4[l] = c.level_sigma4[o][l]; }
+        ho.raw = ctx->raw + g.raw_off; ho.raw_cap = g.raw_cap;
+        ho.raw_cnt = ctx->cnt + CNT_RAW0 + o;
+        ho.tiles_x = aff_cdiv(g.w, HT_X); ho.tile_begin = n_tiles;
+        n_tiles += ho.tiles_x * aff_cdiv(g.h, HT_Y);
+        rp.raw[o] = ho.raw; rp.omap[o] = ctx->omap + g.map_off; rp.raw_cap[o] = g.raw_cap;
+    }
+    {
+        const dim3 hgrid(n_tiles, 1, B);
         switch (NLv) {
             case 3: hipLaunchKernelGGL(hessian_nms_kernel<3>, hgrid, dim3(256), 0, st, hp); break;
             case 4: hipLaunchKernelGGL(hessian_nms_kernel<4>, hgrid, dim3(256), 0, st, hp); break;
@@ -695,7 +833,6 @@ static int detect_candidates(affnet_ctx* ctx, const float* d_responses, hipStrea
             default: hipLaunchKernelGGL(hessian_nms_kernel<8>, hgrid, dim3(256), 0, st, hp); break;
         }
         AFF_LAUNCH_CHECK(ctx);
-        rp.raw[o] = hp.raw; rp.omap[o] = ctx->omap + g.map_off; rp.raw_cap[o] = g.raw_cap;
     }
     rp.n_detect_levels = NLv - 2; rp.cnt = ctx->cnt;
     rp.cand_resp = ctx->cand_resp; rp.cand_syx = ctx->cand_syx; rp.cand_ids = ctx->cand_ids; rp.cand_cap = (int)ctx->cand_cap;
@@ -718,7 +855,14 @@ static int detect_candidates(affnet_ctx* ctx, const float* d_responses, hipStrea
 static int select_top(affnet_ctx* ctx, const float* resp, const float* syx, const int32_t* ids, hipStream_t st) {
     const affnet_config& c = ctx->cfg;
     const int B = ctx->B;
-    hipLaunchKernelGGL(select_prepare_kernel, dim3(B), dim3(1024), 0, st, resp, ctx->cnt, (int)ctx->cand_cap, c.num_prefilter, ctx->cap_pre);
+    {
+        int hb = aff_cdiv((int)ctx->cand_cap, 1024);
+        hb = hb < 1 ? 1 : (hb > 128 ? 128 : hb);
+        hipLaunchKernelGGL(select_hist_kernel, dim3(hb, B), dim3(256), 0, st, resp, ctx->cnt, (int)ctx->cand_cap, c.num_prefilter, ctx->sel_hist);
+        AFF_LAUNCH_CHECK(ctx);
+    }
+    hipLaunchKernelGGL(select_prepare_kernel, dim3(B), dim3(1024), 0, st, resp, ctx->cnt, (int)ctx->cand_cap, c.num_prefilter, ctx->cap_pre,
+                       ctx->sel_hist);
     AFF_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(select_compact_kernel, dim3(aff_cdiv((int)ctx->cand_cap, 256), B), dim3(256), 0, st, resp, syx, ids, ctx->cnt,
                        (int)ctx->cand_cap, ctx->sel_resp, ctx->sel_syx, ctx->sel_ids, ctx->cap_pre);
@@ -729,21 +873,23 @@ static int select_top(affnet_ctx* ctx, const float* resp, const float* syx, cons
     return AFFNET_OK;
 }
 
-static int clear_outputs(affnet_ctx* ctx, float* d_resp, float* d_lafs, int32_t* d_ids, hipStream_t st) {
+// Output rows past the row count and the rank accumulator are cleared together with the detector's own areas (detect_candidates).
+static AffZeroSegs clear_outputs(affnet_ctx* ctx, float* d_resp, float* d_lafs, int32_t* d_ids) {
     const size_t P = (size_t)ctx->B * ctx->cap_pre;
-    { int zrc = aff_zero_async(ctx, d_resp, P * sizeof(float), st); if (zrc) return zrc; }
-    { int zrc = aff_zero_async(ctx, d_lafs, P * 6 * sizeof(float), st); if (zrc) return zrc; }
-    { int zrc = aff_zero_async(ctx, d_ids, P * 3 * sizeof(int32_t), st); if (zrc) return zrc; }
-    { int zrc = aff_zero_async(ctx, ctx->st_rank, P * sizeof(int32_t), st); if (zrc) return zrc; }
-    return AFFNET_OK;
+    AffZeroSegs z;
+    if ((char*)d_lafs == (char*)d_resp + P * sizeof(float) && (char*)d_ids == (char*)d_lafs + P * 6 * sizeof(float)) {
+        z.add(d_resp, P * 10 * sizeof(float));        // the context's own detection list is one contiguous area
+    } else {
+        z.add(d_resp, P * sizeof(float)); z.add(d_lafs, P * 6 * sizeof(float)); z.add(d_ids, P * 3 * sizeof(int32_t));
+    }
+    z.add(ctx->st_rank, P * sizeof(int32_t));
+    return z;
 }
 
 int aff_detect_impl(affnet_ctx* ctx, const float* d_responses, float* d_resp, float* d_lafs, int32_t* d_ids, int32_t* d_count, void* stream) {
     if (!ctx || !ctx->ws || !d_resp || !d_lafs || !d_ids) return aff_fail(ctx, AFFNET_ERR_INVALID, "detect: context not bound or null output");
     hipStream_t st = (hipStream_t)stream;
-    int rc = clear_outputs(ctx, d_resp, d_lafs, d_ids, st);
-    if (rc) return rc;
-    rc = detect_candidates(ctx, d_responses, st);
+    int rc = detect_candidates(ctx, d_responses, clear_outputs(ctx, d_resp, d_lafs, d_ids), st);
     if (rc) return rc;
     rc = select_top(ctx, ctx->cand_resp, ctx->cand_syx, ctx->cand_ids, st);
     if (rc) return rc;
@@ -779,9 +925,7 @@ int aff_detect_onepass_impl(affnet_ctx* ctx, const float* d_packed_fullconv, hip
             if (rc) return rc;
         }
     }
-    int rc = clear_outputs(ctx, ctx->st_det_resp, ctx->st_det_lafs, ctx->st_det_ids, st);
-    if (rc) return rc;
-    rc = detect_candidates(ctx, nullptr, st);
+    int rc = detect_candidates(ctx, nullptr, clear_outputs(ctx, ctx->st_det_resp, ctx->st_det_lafs, ctx->st_det_ids), st);
     if (rc) return rc;
     const int n_detect = c.levels_per_octave - 2;
     hipLaunchKernelGGL(onepass_level_select_kernel, dim3(c.n_octaves * n_detect, B), dim3(1024), 0, st, ctx->cand_resp, ctx->cand_ids, ctx->cnt,

@@ -19,17 +19,21 @@
 #include "common.h"
 
 #define BT_X 64
-#define BT_Y 64
-#define BT_R 4          // output rows per thread
+// BT_R = output rows per thread (tile height BT_Y = 16 * BT_R).  4 is the throughput shape (one (K+3)-wide register window per input
+// row feeds 4 output rows); 1 is the latency shape for small grids: a 64 x 16 tile is a quarter of the serial work per workgroup and
+// four times as many workgroups - at one 800 x 640 image per call the 64 x 64 tiling put 130 workgroups on 256 CUs and every one
+// of the 25 dependent blur launches took 9-17 us whatever the octave (profiles/r03_s0_config2_gap_table.md).  The per-pixel fmaf
+// chain is the same in both shapes.
 
 template <int K>
 struct Taps { float w[K * K]; };
 
-template <int K>
+template <int K, int BT_R>
 __global__ __launch_bounds__(256) void blur2d_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                      float* __restrict__ dec_out, int h, int w, int w2, size_t in_stride,
                                                      size_t out_stride, Taps<K> taps) {
     constexpr int R = K / 2;
+    constexpr int BT_Y = 16 * BT_R;
     constexpr int LW = BT_X + 2 * R;               // tile width incl. halo
     constexpr int LS = (LW + 15) & ~15;            // row stride: multiple of 16 floats (16-B aligned rows, conflict-free b128)
     constexpr int LH = BT_Y + 2 * R;
@@ -144,8 +148,14 @@ static void launch_blur(const float* in, float* out, float* dec, int h, int w, i
                         const float* taps, hipStream_t st) {
     Taps<K> t;
     memcpy(t.w, taps, sizeof(float) * K * K);
-    dim3 grid(aff_cdiv(w, BT_X), aff_cdiv(h, BT_Y), batch);
-    hipLaunchKernelGGL(blur2d_kernel<K>, grid, dim3(256), 0, st, in, out, dec, h, w, (w - 1) / 2 + 1, in_stride, out_stride, t);
+    const int tiles64 = aff_cdiv(w, BT_X) * aff_cdiv(h, 64) * batch;
+    if (tiles64 >= 1024) {       // >= 4 workgroups per CU with the tall tile: throughput shape
+        dim3 grid(aff_cdiv(w, BT_X), aff_cdiv(h, 64), batch);
+        hipLaunchKernelGGL((blur2d_kernel<K, 4>), grid, dim3(256), 0, st, in, out, dec, h, w, (w - 1) / 2 + 1, in_stride, out_stride, t);
+    } else {
+        dim3 grid(aff_cdiv(w, BT_X), aff_cdiv(h, 16), batch);
+        hipLaunchKernelGGL((blur2d_kernel<K, 1>), grid, dim3(256), 0, st, in, out, dec, h, w, (w - 1) / 2 + 1, in_stride, out_stride, t);
+    }
 }
 
 // batch images per launch: image b reads in + b*in_stride and writes out / dec + b*out_stride (floats)
