@@ -26,6 +26,7 @@
 #include "common.h"
 
 #include "cnn_mfma.h"
+#include "shape_filter.h"
 
 extern "C" size_t affnet_cnn32_packed_floats(int net_kind) {
     if (net_kind < 0 || net_kind > AFFNET_NET_AFFNET_FULLCONV) return 0;
@@ -187,12 +188,18 @@ struct CnnArgs {
     int row_begin;
     const int32_t* skip_cnt;
     int skip_n;
+    // Shape-stage bookkeeping done by thread 0 of workgroup (0, image) of the AffNet trunk launches (each was a 5 us launch of its
+    // own): shape_op 1 = first pass: survivor / evaluation counters = 0; 2 = second (lazy) pass: freeze the first pass's survivor
+    // count (CNT_SURVIVED1) for the predicate of the finish + filter kernel that follows this launch.  The trunk workgroups
+    // themselves test CNT_SURVIVED, which nothing changes while a trunk launch runs.
+    int32_t* shape_cnt;
+    int shape_op;
 };
 
-__device__ __forceinline__ bool lazy_skip(const int32_t* skip_cnt, int skip_n, int image) {
+__device__ __forceinline__ bool lazy_skip(const int32_t* skip_cnt, int skip_n, int image, int which = CNT_SURVIVED1) {
     if (!skip_cnt) return false;
     const int32_t* c = skip_cnt + (size_t)image * CNT_TOTAL;
-    return c[CNT_SEL_MODE] == 1 && c[CNT_SURVIVED1] >= skip_n;
+    return c[CNT_SEL_MODE] == 1 && c[which] >= skip_n;
 }
 
 #define CNN_STAMP(k)                                                                                     \
@@ -249,7 +256,12 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
     // grid = (n_max, batch): row blockIdx.x of image blockIdx.y; global row = image * n_max + row
     const int n = a.count ? min(a.count[blockIdx.y], a.n_max) : a.n_max;
     const int prow = blockIdx.x + a.row_begin;
-    if (prow >= n || lazy_skip(a.skip_cnt, a.skip_n, blockIdx.y)) return;
+    if (KIND == AFFNET_NET_AFFNET && a.shape_cnt && blockIdx.x == 0 && threadIdx.x == 0) {
+        int32_t* c = a.shape_cnt + (size_t)blockIdx.y * CNT_TOTAL;
+        if (a.shape_op == 1) { c[CNT_SURVIVED] = 0; c[CNT_SURVIVED1] = 0; c[CNT_AFF_EVAL] = 0; }
+        else if (a.shape_op == 2) c[CNT_SURVIVED1] = c[CNT_SURVIVED];
+    }
+    if (prow >= n || lazy_skip(a.skip_cnt, a.skip_n, blockIdx.y, CNT_SURVIVED)) return;
     const size_t pidx = (size_t)blockIdx.y * a.n_max + prow;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // Issue priority (HardNet only, one workgroup per CU): the short latency-bound phases (input, conv0, epilogues) run at
@@ -434,45 +446,83 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
     if (STAMPS && a.dbg_layer == 5) { dump_planes<4 * CB, LayC5, NTHR>(act, a.dbg_out); return; }
 }
 
-// ---- AffNet / OriNet heads, second half: combine the eight per-wave partials of a patch, one thread per patch -------
+// ---- AffNet / OriNet heads, second half: combine the eight per-wave partials of a patch ---------------------------------
 //   AffNet : + bias -> tanh -> [[1+x0, 0],[x1, 1+x2]] -> rectifyAffineTransformationUpIsUp
-//            (architectures.py:227-229,246-252, LAF.py:285-291)
-//   OriNet : + bias -> tanh -> mean over the 3x3 map -> atan2 -> rotation (architectures.py:56-58,76-82, LAF.py:276-283)
-template <int KIND>
-__global__ __launch_bounds__(256) void cnn16_finish_kernel(const float* __restrict__ part, const float* __restrict__ hb,
-                                                           const int32_t* __restrict__ count, int n_max, float* __restrict__ out, int row_begin,
-                                                           int row_end, const int32_t* __restrict__ skip_cnt, int skip_n) {
+//            (architectures.py:227-229,246-252, LAF.py:285-291); one thread per patch; optionally the shape filter of the row
+//            (laf_ops.hip: aff_shape_filter_row) in the same kernel - the fused pipeline's finish + filter
+//   OriNet : + bias -> tanh -> mean over the 3x3 map -> atan2 -> rotation (architectures.py:56-58,76-82, LAF.py:276-283); one
+//            WAVEFRONT per patch: lane q < 18 adds the eight partials of tap q (18 consecutive floats per wave partial: coalesced;
+//            one thread per patch read 144 floats at a 576-byte stride, 5.8x overfetch, 18 us for 2000 patches), the nine tanh
+//            values of each output are added in tap order as before; optionally LAF <- LAF * R in the same kernel
+//            (SparseImgRepresenter.py:173-177).
+struct ShapeFuse {           // finish + shape filter in one kernel (pointers of image 0; strides like shape_filter_kernel)
+    const float* resp; const float* lafs; float* key; int32_t* good; int32_t* cnt;
+};
+__global__ __launch_bounds__(256) void affnet_finish_kernel(const float* __restrict__ part, const float* __restrict__ hb,
+                                                            const int32_t* __restrict__ count, int n_max, float* __restrict__ out, int row_begin,
+                                                            int row_end, const int32_t* __restrict__ skip_cnt, int skip_n, ShapeFuse sf) {
     const int row = row_begin + blockIdx.x * 256 + threadIdx.x;
-    const int n = min(count ? min(count[blockIdx.y], n_max) : n_max, row_end);
-    if (row >= n || lazy_skip(skip_cnt, skip_n, blockIdx.y)) return;
+    const int n_img = count ? min(count[blockIdx.y], n_max) : n_max;
+    const int n = min(n_img, row_end);
+    const bool skip = lazy_skip(skip_cnt, skip_n, blockIdx.y);
     const size_t pidx = (size_t)blockIdx.y * n_max + row;
+    if (sf.key) {
+        if (blockIdx.x == 0 && threadIdx.x == 0)
+            sf.cnt[(size_t)blockIdx.y * CNT_TOTAL + CNT_AFF_EVAL] = skip ? min(n_img, row_begin) : min(n_img, row_end);
+        if (skip && row < n) { sf.key[pidx] = 0.0f; sf.good[pidx] = 0; }      // never evaluated: "not good" (no separate clearing pass)
+    }
+    if (row >= n || skip) return;
     float* o = out + 4 * pidx;
-    if (KIND == AFFNET_NET_AFFNET) {
-        const f32x4* pp = reinterpret_cast<const f32x4*>(part + pidx * HEAD_PART_AFF);
-        f32x4 r[8];
+    const f32x4* pp = reinterpret_cast<const f32x4*>(part + pidx * HEAD_PART_AFF);
+    f32x4 r[8];
 #pragma unroll
-        for (int w = 0; w < 8; ++w) r[w] = pp[w];
-        const f32x4 s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-        const float x0 = tanhf(s.x + hb[0]), x1 = tanhf(s.y + hb[1]), x2 = tanhf(s.z + hb[2]);
-        const float a00 = 1.0f + x0, a01 = 0.0f * x0, a10 = x1, a11 = 1.0f + x2;
-        const float det = sqrtf(fabsf(a00 * a11 - a10 * a01 + 1e-10f));
-        const float b2a2 = sqrtf(a01 * a01 + a00 * a00);
-        o[0] = b2a2 / det; o[1] = 0.0f * det;
-        o[2] = (a11 * a01 + a10 * a00) / (b2a2 * det); o[3] = det / b2a2;
-    } else {
-        const float* pp = part + pidx * HEAD_PART_ORI;
-        float t0 = 0.f, t1 = 0.f;
+    for (int w = 0; w < 8; ++w) r[w] = pp[w];
+    const f32x4 s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    const float x0 = tanhf(s.x + hb[0]), x1 = tanhf(s.y + hb[1]), x2 = tanhf(s.z + hb[2]);
+    const float a00 = 1.0f + x0, a01 = 0.0f * x0, a10 = x1, a11 = 1.0f + x2;
+    const float det = sqrtf(fabsf(a00 * a11 - a10 * a01 + 1e-10f));
+    const float b2a2 = sqrtf(a01 * a01 + a00 * a00);
+    const float o0 = b2a2 / det, o1 = 0.0f * det, o2 = (a11 * a01 + a10 * a00) / (b2a2 * det), o3 = det / b2a2;
+    o[0] = o0; o[1] = o1; o[2] = o2; o[3] = o3;
+    if (sf.key) {
+        const size_t bi = blockIdx.y;
+        aff_shape_filter_row(sf.resp + bi * n_max, sf.lafs + bi * n_max * 6, o0, o1, o2, o3, row, sf.key + bi * n_max, sf.good + bi * n_max,
+                             sf.cnt + bi * CNT_TOTAL);
+    }
+}
+
+__global__ __launch_bounds__(256) void orinet_finish_kernel(const float* __restrict__ part, const float* __restrict__ hb,
+                                                            const int32_t* __restrict__ count, int n_max, float* __restrict__ out, int row_begin,
+                                                            int row_end, float* __restrict__ rot_lafs) {
+    const int row = row_begin + blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int n = min(count ? min(count[blockIdx.y], n_max) : n_max, row_end);
+    if (row >= n) return;
+    const size_t pidx = (size_t)blockIdx.y * n_max + row;
+    const float* pp = part + pidx * HEAD_PART_ORI;
+    float th = 0.f;
+    if (lane < 18) {
+        float p[8];
 #pragma unroll
-        for (int q = 0; q < 9; ++q) {
-            float r0 = 0.f, r1 = 0.f;
+        for (int w = 0; w < 8; ++w) p[w] = pp[w * 18 + lane];
+        float r = 0.f;
 #pragma unroll
-            for (int w = 0; w < 8; w += 2) { r0 += pp[w * 18 + q] + pp[(w + 1) * 18 + q]; r1 += pp[w * 18 + 9 + q] + pp[(w + 1) * 18 + 9 + q]; }
-            t0 += tanhf(r0 + hb[0]); t1 += tanhf(r1 + hb[1]);
-        }
-        const float yv = t0 / 9.0f, xv = t1 / 9.0f;                       // AdaptiveAvgPool2d(1)
-        const float ang = atan2f(yv + 1e-8f, xv + 1e-8f);                 // architectures.py:78
-        const float sn = sinf(ang), cs = cosf(ang);
-        o[0] = cs; o[1] = sn; o[2] = -sn; o[3] = cs;
+        for (int w = 0; w < 8; w += 2) r += p[w] + p[w + 1];
+        th = tanhf(r + hb[lane >= 9 ? 1 : 0]);
+    }
+    float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { t0 += __shfl(th, q, 64); t1 += __shfl(th, 9 + q, 64); }
+    if (lane != 0) return;
+    const float yv = t0 / 9.0f, xv = t1 / 9.0f;                       // AdaptiveAvgPool2d(1)
+    const float ang = atan2f(yv + 1e-8f, xv + 1e-8f);                 // architectures.py:78
+    const float sn = sinf(ang), cs = cosf(ang);
+    float* o = out + 4 * pidx;
+    o[0] = cs; o[1] = sn; o[2] = -sn; o[3] = cs;
+    if (rot_lafs) {                                                   // apply_rotation_kernel (laf_ops.hip), same fmaf order
+        float* L = rot_lafs + 6 * pidx;
+        const float l00 = L[0], l01 = L[1], l10 = L[3], l11 = L[4];
+        L[0] = fmaf(l01, -sn, l00 * cs); L[1] = fmaf(l01, cs, l00 * sn);
+        L[3] = fmaf(l11, -sn, l10 * cs); L[4] = fmaf(l11, cs, l10 * sn);
     }
 }
 
@@ -484,15 +534,20 @@ __global__ __launch_bounds__(256) void cnn16_finish_kernel(const float* __restri
 // MFMAs.  The A slab (64 x 128) is fetched one iteration ahead into registers (buffer loads: rows >= n read as zero)
 // and written to LDS with 16-byte stores.  Partial sums go to a scratch [4][n][128] with plain stores (no float atomics:
 // bit-reproducible); hardnet_finish_kernel adds them in fixed order, adds the bias and L2-normalises.
-#define HEAD_MP 64
 #define HEAD_KSPLIT 4
 #define HEAD_KC 128
 #define HEAD_AS (HEAD_KC + 4)    // row stride: 16-byte aligned rows
+// MP = patches per workgroup: 64 (4 M-tiles per wave) is the throughput shape; 32 / 16 give small calls 2x / 4x as many workgroups
+// (one image with 2000 keypoints is 32 x 4 workgroups of the 64-patch shape on 256 CUs: 85 us at 49 TFLOP/s).  The K order of every
+// output's sum is the same for all three, so results do not depend on the shape.
+template <int MP>
 __global__ __launch_bounds__(256, 2) void hardnet_head_kernel(const float* __restrict__ trunk, const float* __restrict__ Bw,
                                                               const int32_t* __restrict__ count, int n_max, float* __restrict__ partial) {
-    __shared__ __attribute__((aligned(16))) float As[HEAD_MP * HEAD_AS];
+    constexpr int MI = MP / 16;                  // M-tiles per wave
+    constexpr int NA = MP * HEAD_KC / 4 / 256;   // float4 of the A slab per thread
+    __shared__ __attribute__((aligned(16))) float As[MP * HEAD_AS];
     const int n = count ? min(count[blockIdx.z], n_max) : n_max;      // blockIdx.z = image of the batch
-    const int p0 = blockIdx.x * HEAD_MP;
+    const int p0 = blockIdx.x * MP;
     if (p0 >= n) return;
     const size_t rows_total = (size_t)gridDim.z * n_max;
     const int kbeg = blockIdx.y * (HEAD_K / HEAD_KSPLIT);
@@ -500,37 +555,37 @@ __global__ __launch_bounds__(256, 2) void hardnet_head_kernel(const float* __res
     const int m = lane & 15, kq = lane >> 4;
     const __amdgpu_buffer_rsrc_t rA = weight_rsrc(trunk + (size_t)blockIdx.z * n_max * HEAD_K, n * HEAD_K);   // rows >= n -> 0
     const __amdgpu_buffer_rsrc_t rB = weight_rsrc(Bw, HEAD_K * 128);
-    int offA[8];
+    int offA[NA];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < NA; ++r) {
         const int f = tid + 256 * r, row = f >> 5, c4 = f & 31;       // 32 consecutive float4 = one 512-byte row segment
         offA[r] = ((p0 + row) * HEAD_K + 4 * c4) * 4;
     }
     const int offB = ((kq * 128) + wave * 32 + m) * 16;
     const unsigned a_addr = lds_byte_addr(As) + (m * HEAD_AS + 4 * kq) * 4;
-    f32x4 acc[4][2], stage[8];
+    f32x4 acc[MI][2], stage[NA];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 8; ++r) stage[r] = buf_read4(rA, offA[r], kbeg * 4);
+    for (int r = 0; r < NA; ++r) stage[r] = buf_read4(rA, offA[r], kbeg * 4);
 #pragma unroll 1
     for (int k0 = kbeg; k0 < kbeg + HEAD_K / HEAD_KSPLIT; k0 += HEAD_KC) {
         __syncthreads();                                              // the previous slab has been consumed
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
+        for (int r = 0; r < NA; ++r) {
             const int f = tid + 256 * r, row = f >> 5, c4 = f & 31;
             *reinterpret_cast<f32x4*>(&As[row * HEAD_AS + 4 * c4]) = stage[r];
         }
         __syncthreads();
         if (k0 + HEAD_KC < kbeg + HEAD_K / HEAD_KSPLIT) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) stage[r] = buf_read4(rA, offA[r], (k0 + HEAD_KC) * 4);
+            for (int r = 0; r < NA; ++r) stage[r] = buf_read4(rA, offA[r], (k0 + HEAD_KC) * 4);
         }
-        f32x4 fa[2][4], fb[2][2];
+        f32x4 fa[2][MI], fb[2][2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[0][i] = lds_read4(a_addr + i * 16 * HEAD_AS * 4);
+        for (int i = 0; i < MI; ++i) fa[0][i] = lds_read4(a_addr + i * 16 * HEAD_AS * 4);
 #pragma unroll
         for (int j = 0; j < 2; ++j) fb[0][j] = buf_read4(rB, offB + j * 256, k0 * 512);
 #pragma unroll
@@ -538,14 +593,14 @@ __global__ __launch_bounds__(256, 2) void hardnet_head_kernel(const float* __res
             const int cur = g & 1, nxt = cur ^ 1;
             if (g + 1 < HEAD_KC / 16) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) fa[nxt][i] = lds_read4(a_addr + i * 16 * HEAD_AS * 4 + (g + 1) * 64);
+                for (int i = 0; i < MI; ++i) fa[nxt][i] = lds_read4(a_addr + i * 16 * HEAD_AS * 4 + (g + 1) * 64);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) fb[nxt][j] = buf_read4(rB, offB + j * 256, (k0 + 16 * (g + 1)) * 512);
             }
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[cur][i][s4], fb[cur][j][s4], acc[i][j], 0, 0, 0);
@@ -555,7 +610,7 @@ __global__ __launch_bounds__(256, 2) void hardnet_head_kernel(const float* __res
     const int g = lane >> 4;
     float* dst = partial + ((size_t)blockIdx.y * rows_total + (size_t)blockIdx.z * n_max) * 128;
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = p0 + 16 * i + 4 * g + r;
@@ -565,13 +620,15 @@ __global__ __launch_bounds__(256, 2) void hardnet_head_kernel(const float* __res
         }
 }
 
-// One wavefront per patch: sum the K-split partials in fixed order, + BN bias, L2 normalise (eps 1e-8).
+// One wavefront per patch: sum the K-split partials in fixed order, + BN bias, L2 normalise (eps 1e-8).  Rows past the image's row
+// count are cleared here (the caller's descriptor buffer needs no separate fill).
 __global__ __launch_bounds__(256) void hardnet_finish_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
                                                              const int32_t* __restrict__ count, int n_max, float* __restrict__ out) {
     const int n = count ? min(count[blockIdx.y], n_max) : n_max;      // blockIdx.y = image of the batch
     const int lrow = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (lrow >= n) return;
+    if (lrow >= n_max) return;
     const size_t rows_total = (size_t)gridDim.y * n_max, row = (size_t)blockIdx.y * n_max + lrow;
+    if (lrow >= n) { out[row * 128 + lane] = 0.0f; out[row * 128 + 64 + lane] = 0.0f; return; }
     float v0 = 0.f, v1 = 0.f;
 #pragma unroll
     for (int s = 0; s < HEAD_KSPLIT; ++s) {
@@ -602,7 +659,8 @@ void aff_fill_pyr_src(const affnet_ctx* ctx, PyrSrc* t) {
 
 static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const float* patches, const float* lafs, const int32_t* ids,
                       const int32_t* count, int n_max, float* out, float* scratch, int dbg_layer, float* dbg_out, hipStream_t st,
-                      bool mark_head = false, int row_begin = 0, int row_count = -1, const int32_t* skip_cnt = nullptr, int skip_n = 0) {
+                      bool mark_head = false, int row_begin = 0, int row_count = -1, const int32_t* skip_cnt = nullptr, int skip_n = 0,
+                      const ShapeFuse* fuse = nullptr, int shape_op = 0, float* rot_lafs = nullptr) {
     if (kind < 0 || kind > 2) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: unknown net kind %d", kind);
     if (!packed || !out || n_max < 0 || (!patches && (!lafs || !ids))) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: null argument");
     if (!patches && !ctx->ws) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: sampling from the pyramid needs a bound workspace");
@@ -616,6 +674,7 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
     a.out = (dbg_layer < 0) ? scratch : out;              // trunk kernels: HardNet conv5 tensor / AffNet, OriNet head partials
     a.dbg_layer = dbg_layer; a.dbg_out = dbg_out; a.dbg_time = ctx->dbg_time;
     a.row_begin = row_begin; a.skip_cnt = skip_cnt; a.skip_n = skip_n;
+    a.shape_cnt = (fuse && shape_op) ? fuse->cnt : nullptr; a.shape_op = shape_op;
     if (row_count < 0) row_count = n_max - row_begin;
     if (row_begin < 0 || row_count < 0 || row_begin + row_count > n_max) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: bad row window");
     if (row_count == 0) return AFFNET_OK;
@@ -633,20 +692,30 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
 #undef TRUNK_LAUNCH
     AFF_LAUNCH_CHECK(ctx);
     if (kind != AFFNET_NET_HARDNET && dbg_layer < 0) {       // combine the per-wave head partials in `scratch`
-        const dim3 hgrid(aff_cdiv(row_count, 256), B);
-        if (kind == AFFNET_NET_AFFNET)
-            hipLaunchKernelGGL((cnn16_finish_kernel<AFFNET_NET_AFFNET>), hgrid, dim3(256), 0, st, scratch, packed + L.head_b, count, n_max, out, row_begin,
-                               row_begin + row_count, skip_cnt, skip_n);
-        else
-            hipLaunchKernelGGL((cnn16_finish_kernel<AFFNET_NET_ORINET>), hgrid, dim3(256), 0, st, scratch, packed + L.head_b, count, n_max, out, row_begin,
-                               row_begin + row_count, skip_cnt, skip_n);
+        if (kind == AFFNET_NET_AFFNET) {
+            ShapeFuse sf;
+            memset(&sf, 0, sizeof(sf));
+            if (fuse) sf = *fuse;
+            hipLaunchKernelGGL(affnet_finish_kernel, dim3(aff_cdiv(row_count, 256), B), dim3(256), 0, st, scratch, packed + L.head_b, count, n_max, out,
+                               row_begin, row_begin + row_count, skip_cnt, skip_n, sf);
+        } else {
+            hipLaunchKernelGGL(orinet_finish_kernel, dim3(aff_cdiv(row_count, 4), B), dim3(256), 0, st, scratch, packed + L.head_b, count, n_max, out,
+                               row_begin, row_begin + row_count, rot_lafs);
+        }
         AFF_LAUNCH_CHECK(ctx);
     }
     if (mark_head) aff_prof_mark(ctx, 7, st);
     if (kind == AFFNET_NET_HARDNET && dbg_layer < 0) {
         float* partial = scratch + (size_t)B * n_max * HEAD_K;   // [HEAD_KSPLIT][B * n_max][128] behind the trunk output
-        hipLaunchKernelGGL(hardnet_head_kernel, dim3(aff_cdiv(n_max, HEAD_MP), HEAD_KSPLIT, B), dim3(256), 0, st, scratch, packed + L.head_w,
-                           count, n_max, partial);
+        // patches per workgroup: the 64-patch shape once it gives every CU a workgroup, else 32 / 16 (same sums, more workgroups)
+        int mp = (aff_cdiv(n_max, 64) * HEAD_KSPLIT * B >= 256) ? 64 : ((aff_cdiv(n_max, 32) * HEAD_KSPLIT * B >= 256) ? 32 : 16);
+        if (const char* e = getenv("AFFNET_HEAD_MP")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) mp = v; }   // tuning aid
+        if (mp == 64)
+            hipLaunchKernelGGL(hardnet_head_kernel<64>, dim3(aff_cdiv(n_max, 64), HEAD_KSPLIT, B), dim3(256), 0, st, scratch, packed + L.head_w, count, n_max, partial);
+        else if (mp == 32)
+            hipLaunchKernelGGL(hardnet_head_kernel<32>, dim3(aff_cdiv(n_max, 32), HEAD_KSPLIT, B), dim3(256), 0, st, scratch, packed + L.head_w, count, n_max, partial);
+        else
+            hipLaunchKernelGGL(hardnet_head_kernel<16>, dim3(aff_cdiv(n_max, 16), HEAD_KSPLIT, B), dim3(256), 0, st, scratch, packed + L.head_w, count, n_max, partial);
         AFF_LAUNCH_CHECK(ctx);
         hipLaunchKernelGGL(hardnet_finish_kernel, dim3(aff_cdiv(n_max, 4), B), dim3(256), 0, st, partial, packed + L.head_b, count, n_max, out);
         AFF_LAUNCH_CHECK(ctx);
@@ -673,6 +742,23 @@ int aff_cnn_forward_pyr_rows(affnet_ctx* ctx, int kind, const float* packed, con
                              float* out, float* scratch, int row_begin, int row_count, const int32_t* skip_cnt, int skip_n, hipStream_t st) {
     if (kind == AFFNET_NET_HARDNET) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: row windows are for the AffNet / OriNet trunks");
     return cnn_launch(ctx, kind, packed, nullptr, lafs, ids, count, n_max, out, scratch, -1, nullptr, st, false, row_begin, row_count, skip_cnt, skip_n);
+}
+
+// AffNet on a row window with the shape filter of every evaluated row fused into the finish kernel (key / good / survivor count in
+// the context's stage buffers) and the shape-stage counter bookkeeping done by the trunk launch (shape_op: see CnnArgs).
+int aff_affnet_filter_rows(affnet_ctx* ctx, const float* packed, const float* resp, const float* lafs, const int32_t* ids, const int32_t* count,
+                           float* out, float* scratch, int row_begin, int row_count, bool lazy, int shape_op, hipStream_t st) {
+    ShapeFuse sf;
+    sf.resp = resp; sf.lafs = lafs; sf.key = ctx->st_key; sf.good = ctx->st_good; sf.cnt = ctx->cnt;
+    return cnn_launch(ctx, AFFNET_NET_AFFNET, packed, nullptr, lafs, ids, count, ctx->cap_pre, out, scratch, -1, nullptr, st, false, row_begin, row_count,
+                      lazy ? ctx->cnt : nullptr, ctx->cfg.num_features, &sf, shape_op);
+}
+
+// OriNet with LAF <- LAF * R applied by the finish kernel (d_lafs rotated in place).
+int aff_orinet_rotate(affnet_ctx* ctx, const float* packed, float* lafs, const int32_t* ids, const int32_t* count, int n_max, float* out, float* scratch,
+                      hipStream_t st) {
+    return cnn_launch(ctx, AFFNET_NET_ORINET, packed, nullptr, lafs, ids, count, n_max, out, scratch, -1, nullptr, st, false, 0, -1, nullptr, 0, nullptr, 0,
+                      lafs);
 }
 
 int aff_hardnet_forward_pyr_marked(affnet_ctx* ctx, const float* packed, const float* lafs, const int32_t* ids, const int32_t* count,

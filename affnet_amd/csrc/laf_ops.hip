@@ -7,6 +7,7 @@
 #include <math.h>
 
 #include "common.h"
+#include "shape_filter.h"
 
 #define MAX_PS 64
 
@@ -118,99 +119,98 @@ __global__ __launch_bounds__(256) void shape_filter_kernel(const float* __restri
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) cnt[CNT_AFF_EVAL] = skip ? min(n, row_begin) : min(n, row_end);
     if (skip || i >= row_end || i >= n) return;
-    // base_A = bmm(A, I) = A exactly (SparseImgRepresenter.py:136, one iteration)
-    const float a00 = A[4 * i], a01 = A[4 * i + 1], a10 = A[4 * i + 2], a11 = A[4 * i + 3];
-    const float* L = lafs + 6 * (size_t)i;
-    // new_LAF = [base_A * LAF_2x2 | centre]: bmm row-by-column, k ascending, fused accumulate
-    const float n00 = fmaf(a01, L[3], a00 * L[0]), n01 = fmaf(a01, L[4], a00 * L[1]);
-    const float n10 = fmaf(a11, L[3], a10 * L[0]), n11 = fmaf(a11, L[4], a10 * L[1]);
-    const float cx = L[2], cy = L[5];
-    // batch_eig2x2 (Utils.py:168-175), op by op
-    const float tr = a00 + a11;
-    const float p1 = a00 * a11, p2 = a10 * a01;
-    const float d1 = tr * tr - 4.0f * (p1 - p2);
-    const float mk = d1 > 0.f ? 1.0f : 0.0f;
-    const float dl = sqrtf(fabsf(d1));
-    const float l1 = mk * (tr + dl) / 2.0f + 1000.0f * (1.0f - mk);
-    const float l2 = mk * (tr - dl) / 2.0f + 0.0001f * (1.0f - mk);
-    const float ratio = fabsf(l1 / (l2 + 1e-8f));
-    bool ok = (ratio < 6.0f) && (ratio > (float)(1.0 / 6.0));
-    // checkTouchBoundary (LAF.py:98-104): corners (+-1,+-1) of the frame must stay inside [0,1]^2
-    const float px[4] = {-1.f, -1.f, 1.f, 1.f}, py[4] = {-1.f, 1.f, -1.f, 1.f};
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const float ox = fmaf(cx, 1.0f, fmaf(n01, py[k], n00 * px[k]));
-        const float oy = fmaf(cy, 1.0f, fmaf(n11, py[k], n10 * px[k]));
-        if (ox > 1.0f || ox < 0.0f || oy > 1.0f || oy < 0.0f) ok = false;
-    }
-    good[i] = ok ? 1 : 0;
-    key[i] = resp[i] * (ok ? 1.0f : 0.0f);
-    if (ok) atomicAdd(&cnt[CNT_SURVIVED], 1);
+    aff_shape_filter_row(resp, lafs, A[4 * i], A[4 * i + 1], A[4 * i + 2], A[4 * i + 3], i, key, good, cnt);
 }
 
-// Selection, split over a 2-D grid like the detector's rank sort: block (bx, by) counts for its 256
-// rows how many rows of chunk `by` precede them; partial positions are accumulated with integer atomics.
-//   survivors > N  -> top-N of key (descending; ties by row index) - torch.topk branch (:151-153)
-//   otherwise      -> stable compaction of the good rows            - nonzero branch (:154-156)
-__global__ __launch_bounds__(256) void shape_rank_kernel(const float* __restrict__ key, const int32_t* __restrict__ good,
-                                                         const int32_t* __restrict__ d_count, int n_max, int N,
-                                                         const int32_t* __restrict__ cnt, int32_t* __restrict__ pos) {
-    __shared__ float t_key[256];
-    __shared__ int t_good[256];
+// Selection + emission in ONE launch, one 1024-thread workgroup per image (were: clear, 2-D rank sort with atomics, emit):
+//   survivors > N  -> top-N of key = response * good (descending; ties by row index) - torch.topk branch (:151-153)
+//   otherwise      -> stable compaction of the good rows                              - nonzero branch (:154-156)
+// The detector hands over rows sorted by descending response (CNT_SEL_MODE == 1) whenever it had more candidates than C, and then
+// "the N largest keys" are simply the first N good rows: both branches are a prefix count of the good flags.  Only when the rows
+// are NOT sorted (fewer than C candidates) and there are more than N survivors - or the N-th good row's key is not positive, so
+// that the zero keys of rejected rows compete with it - the keys are ranked by comparison (brute force from LDS tiles; rare and small).
+__global__ __launch_bounds__(1024) void shape_select_kernel(const float* __restrict__ resp, const float* __restrict__ lafs,
+                                                            const int32_t* __restrict__ ids, const float* __restrict__ A,
+                                                            const float* __restrict__ key, const int32_t* __restrict__ good,
+                                                            const int32_t* __restrict__ d_count, int n_max, int N, int out_cap, float* out_resp,
+                                                            float* out_lafs, int32_t* out_ids, int32_t* out_count, int32_t* cnt) {
+    __shared__ int s_wsum[16];
+    __shared__ int s_general;
+    __shared__ float t_key[1024];
     {
-        const size_t bi = blockIdx.z;
-        key += bi * n_max; good += bi * n_max; d_count += bi; cnt += bi * CNT_TOTAL; pos += bi * n_max;
-    }
-    const int n = min(*d_count, n_max);
-    const int i = blockIdx.x * 256 + threadIdx.x, base = blockIdx.y * 256;
-    if (blockIdx.x * 256 >= n || base >= n) return;
-    const bool topk = (N > 0) && (cnt[CNT_SURVIVED] > N);
-    const int j = base + threadIdx.x;
-    if (j < n) { t_key[threadIdx.x] = key[j]; t_good[threadIdx.x] = good[j]; }
-    __syncthreads();
-    if (i >= n) return;
-    const float ki = key[i];
-    const int m = (n - base) < 256 ? (n - base) : 256;
-    int r = 0;
-    if (topk) {
-        for (int t = 0; t < m; ++t) { const float kj = t_key[t]; r += (kj > ki) || (kj == ki && (base + t) < i); }
-    } else {
-        for (int t = 0; t < m; ++t) r += (t_good[t] != 0) && ((base + t) < i);
-    }
-    if (r) atomicAdd(&pos[i], r);
-}
-
-__global__ __launch_bounds__(256) void shape_emit_kernel(const float* __restrict__ resp, const float* __restrict__ lafs,
-                                                         const int32_t* __restrict__ ids, const float* __restrict__ A,
-                                                         const float* __restrict__ key, const int32_t* __restrict__ good,
-                                                         const int32_t* __restrict__ pos, const int32_t* __restrict__ d_count, int n_max,
-                                                         int N, int out_cap, float* out_resp, float* out_lafs, int32_t* out_ids,
-                                                         int32_t* out_count, int32_t* cnt) {
-    {
-        const size_t bi = blockIdx.y;
+        const size_t bi = blockIdx.x;
         resp += bi * n_max; lafs += bi * n_max * 6; ids += bi * n_max * 3; A += bi * n_max * 4; key += bi * n_max;
-        good += bi * n_max; pos += bi * n_max; d_count += bi; cnt += bi * CNT_TOTAL;
+        good += bi * n_max; d_count += bi; cnt += bi * CNT_TOTAL;
         out_resp += bi * out_cap; out_lafs += bi * out_cap * 6; out_ids += bi * out_cap * 3; out_count += bi;
     }
     const int n = min(*d_count, n_max);
     const int surv = cnt[CNT_SURVIVED];
     const bool topk = (N > 0) && (surv > N);
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i == 0) {
-        const int n_out = topk ? N : (surv < out_cap ? surv : out_cap);
+    const bool sorted = cnt[CNT_SEL_MODE] == 1;
+    const int n_out = topk ? N : (surv < out_cap ? surv : out_cap);
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    if (t == 0) {
         *out_count = n_out; cnt[CNT_SHAPED] = n_out;
         if (!topk && surv > out_cap) atomicOr(&cnt[CNT_OVERFLOW], 8);
+        s_general = (topk && !sorted) ? 1 : 0;
     }
-    if (i >= n) return;
-    const int p = pos[i];
-    if (topk ? (p >= N) : (!good[i] || p >= out_cap)) return;
-    out_resp[p] = topk ? key[i] : resp[i];
-    const float a00 = A[4 * i], a01 = A[4 * i + 1], a10 = A[4 * i + 2], a11 = A[4 * i + 3];
-    const float* L = lafs + 6 * (size_t)i;
-    float* O = out_lafs + 6 * (size_t)p;
-    O[0] = fmaf(a01, L[3], a00 * L[0]); O[1] = fmaf(a01, L[4], a00 * L[1]); O[2] = L[2];
-    O[3] = fmaf(a11, L[3], a10 * L[0]); O[4] = fmaf(a11, L[4], a10 * L[1]); O[5] = L[5];
-    out_ids[3 * p] = ids[3 * i]; out_ids[3 * p + 1] = ids[3 * i + 1]; out_ids[3 * p + 2] = ids[3 * i + 2];
+    // rows past the output count: zero (the caller's buffers are not cleared separately)
+    for (int r = n_out + t; r < out_cap; r += 1024) {
+        out_resp[r] = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) out_lafs[6 * (size_t)r + k] = 0.0f;
+        out_ids[3 * r] = 0; out_ids[3 * r + 1] = 0; out_ids[3 * r + 2] = 0;
+    }
+    // exclusive prefix count of the good flags: thread t owns rows [t * seg, (t + 1) * seg)
+    const int seg = (n + 1023) / 1024;
+    const int r0 = t * seg, r1 = min(r0 + seg, n);
+    int mine = 0;
+    for (int r = r0; r < r1; ++r) mine += good[r] != 0;
+    int inc = mine;
+#pragma unroll
+    for (int ofs = 1; ofs < 64; ofs <<= 1) {
+        const int v = __shfl_up(inc, ofs, 64);
+        if (lane >= ofs) inc += v;
+    }
+    if (lane == 63) s_wsum[wave] = inc;
+    __syncthreads();
+    int before = inc - mine;
+    for (int w = 0; w < wave; ++w) before += s_wsum[w];
+    if (topk && sorted && before < N && N <= before + mine) {          // the thread that owns the N-th good row: is its key positive?
+        int c = before;
+        for (int r = r0; r < r1; ++r)
+            if (good[r] != 0 && ++c == N && !(key[r] > 0.0f)) s_general = 1;
+    }
+    __syncthreads();
+    auto emit = [&](int i, int p) {
+        out_resp[p] = topk ? key[i] : resp[i];
+        const float a00 = A[4 * i], a01 = A[4 * i + 1], a10 = A[4 * i + 2], a11 = A[4 * i + 3];
+        const float* L = lafs + 6 * (size_t)i;
+        float* O = out_lafs + 6 * (size_t)p;
+        O[0] = fmaf(a01, L[3], a00 * L[0]); O[1] = fmaf(a01, L[4], a00 * L[1]); O[2] = L[2];
+        O[3] = fmaf(a11, L[3], a10 * L[0]); O[4] = fmaf(a11, L[4], a10 * L[1]); O[5] = L[5];
+        out_ids[3 * p] = ids[3 * i]; out_ids[3 * p + 1] = ids[3 * i + 1]; out_ids[3 * p + 2] = ids[3 * i + 2];
+    };
+    if (!s_general) {
+        int p = before;
+        for (int r = r0; r < r1; ++r)
+            if (good[r] != 0) { if (p < n_out) emit(r, p); ++p; }
+        return;
+    }
+    // general top-N: rank of row i = rows j with key_j > key_i, or equal key and j < i (the rejected rows' zero keys take part)
+    for (int i0 = 0; i0 < n; i0 += 1024) {                              // uniform trip count: barriers inside
+        const int i = i0 + t;
+        const float ki = i < n ? key[i] : 0.0f;
+        int r = 0;
+        for (int j0 = 0; j0 < n; j0 += 1024) {
+            __syncthreads();
+            t_key[t] = (j0 + t < n) ? key[j0 + t] : -INFINITY;
+            __syncthreads();
+            const int m = min(1024, n - j0);
+            for (int q = 0; q < m; ++q) { const float kj = t_key[q]; r += (kj > ki) || (kj == ki && (j0 + q) < i); }
+        }
+        if (i < n && r < N) emit(i, r);
+    }
 }
 
 __global__ void shape_freeze_kernel(int32_t* cnt) {        // survivors of the first pass, read by the second pass's predicates
@@ -253,17 +253,8 @@ int aff_shape_filter_rows(affnet_ctx* ctx, const float* resp, const float* lafs,
 
 int aff_shape_select(affnet_ctx* ctx, const float* d_resp_in, const float* d_lafs_in, const int32_t* d_ids_in, const float* d_A,
                      const int32_t* d_count_in, float* d_resp_out, float* d_lafs_out, int32_t* d_ids_out, int32_t* d_count_out, hipStream_t st) {
-    const int P = ctx->cap_pre, F = ctx->cap_final, B = ctx->B;
-    { int zrc = aff_zero_async(ctx, d_resp_out, (size_t)B * F * sizeof(float), st); if (zrc) return zrc; }
-    { int zrc = aff_zero_async(ctx, d_lafs_out, (size_t)B * F * 6 * sizeof(float), st); if (zrc) return zrc; }
-    { int zrc = aff_zero_async(ctx, d_ids_out, (size_t)B * F * 3 * sizeof(int32_t), st); if (zrc) return zrc; }
-    { int zrc = aff_zero_async(ctx, ctx->st_rank, (size_t)B * P * sizeof(int32_t), st); if (zrc) return zrc; }
-    const int nb = aff_cdiv(P, 256);
-    hipLaunchKernelGGL(shape_rank_kernel, dim3(nb, nb, B), dim3(256), 0, st, ctx->st_key, ctx->st_good, d_count_in, P, ctx->cfg.num_features,
-                       ctx->cnt, ctx->st_rank);
-    AFF_LAUNCH_CHECK(ctx);
-    hipLaunchKernelGGL(shape_emit_kernel, dim3(nb, B), dim3(256), 0, st, d_resp_in, d_lafs_in, d_ids_in, d_A, ctx->st_key, ctx->st_good,
-                       ctx->st_rank, d_count_in, P, ctx->cfg.num_features, F, d_resp_out, d_lafs_out, d_ids_out, d_count_out, ctx->cnt);
+    hipLaunchKernelGGL(shape_select_kernel, dim3(ctx->B), dim3(1024), 0, st, d_resp_in, d_lafs_in, d_ids_in, d_A, ctx->st_key, ctx->st_good, d_count_in,
+                       ctx->cap_pre, ctx->cfg.num_features, ctx->cap_final, d_resp_out, d_lafs_out, d_ids_out, d_count_out, ctx->cnt);
     AFF_LAUNCH_CHECK(ctx);
     return AFFNET_OK;
 }
@@ -394,6 +385,53 @@ __global__ void level_select_kernel(const float* __restrict__ lafs_px, const int
     float* O = lafs_norm + 6 * (size_t)i;
     O[0] = ca * L[0]; O[1] = ca * L[1]; O[2] = cx * L[2];
     O[3] = ca * L[3]; O[4] = ca * L[4]; O[5] = cy * L[5];
+}
+
+// scale_lafs_kernel (denormalizeLAFs) + level_select_kernel in one launch (the fused pipeline): out_px = denormalised frames, then
+// the level choice and the re-normalised frames from out_px's values exactly as the two kernels compute them.
+__global__ void denorm_level_select_kernel(const float* __restrict__ in, float* __restrict__ out_px, const int32_t* __restrict__ d_count, int n_max,
+                                           float c_a, float c_x, float c_y, float ps, LevelTable lt, float ca, float cx, float cy,
+                                           int32_t* __restrict__ ids, float* __restrict__ lafs_norm) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t bi = blockIdx.y;
+    const int n = d_count ? min(d_count[bi], n_max) : n_max;
+    if (i >= n_max) return;
+    const float* L = in + 6 * (bi * n_max + i);
+    float* P = out_px + 6 * (bi * n_max + i);
+    if (i >= n) { P[0] = P[1] = P[2] = P[3] = P[4] = P[5] = 0.f; return; }
+    const float q0 = c_a * L[0], q1 = c_a * L[1], q2 = c_x * L[2], q3 = c_a * L[3], q4 = c_a * L[4], q5 = c_y * L[5];
+    P[0] = q0; P[1] = q1; P[2] = q2; P[3] = q3; P[4] = q4; P[5] = q5;
+    const float p1 = q0 * q4, p2 = q1 * q3;
+    const float sc = sqrtf(fabsf(p1 - p2) + 1e-12f);
+    const double need = (double)(sc / ps);
+    int best = 0;
+    double bd = INFINITY;
+    const int tot = lt.n_oct * lt.n_lvl;
+    for (int k = 0; k < tot; ++k) {
+        const double df = lt.sig[k] - need;
+        const double d = sqrt(df * df);               // scipy cdist 'euclidean' on 1-D points
+        if (d < bd) { bd = d; best = k; }
+    }
+    int32_t* I = ids + 3 * (bi * n_max + i);
+    I[0] = best / lt.n_lvl; I[1] = best % lt.n_lvl; I[2] = 0;
+    float* O = lafs_norm + 6 * (bi * n_max + i);
+    O[0] = ca * q0; O[1] = ca * q1; O[2] = cx * q2;
+    O[3] = ca * q3; O[4] = ca * q4; O[5] = cy * q5;
+}
+
+int aff_denorm_level_select(affnet_ctx* ctx, const float* d_lafs_norm_in, float* d_lafs_px, const int32_t* d_count, int n_max, int ps, int32_t* d_ids,
+                            float* d_lafs_norm, hipStream_t st) {
+    if (n_max == 0) return AFFNET_OK;
+    LevelTable lt;
+    const affnet_config& c = ctx->cfg;
+    lt.n_oct = c.n_octaves; lt.n_lvl = c.levels_per_octave;
+    for (int o = 0; o < lt.n_oct; ++o)
+        for (int l = 0; l < lt.n_lvl; ++l) lt.sig[o * lt.n_lvl + l] = c.level_sigma_px[o][l];
+    const float fw = (float)c.width, fh = (float)c.height, m = fw < fh ? fw : fh;
+    hipLaunchKernelGGL(denorm_level_select_kernel, dim3(aff_cdiv(n_max, 256), ctx->B), dim3(256), 0, st, d_lafs_norm_in, d_lafs_px, d_count, n_max, m, fw,
+                       fh, (float)ps, lt, 1.0f / m, (float)(1.0 / (double)fw), (float)(1.0 / (double)fh), d_ids, d_lafs_norm);
+    AFF_LAUNCH_CHECK(ctx);
+    return AFFNET_OK;
 }
 
 extern "C" int affnet_level_select(affnet_ctx* ctx, const float* d_lafs_px, const int32_t* d_count, int n_max, int ps, int32_t* d_ids,

@@ -64,6 +64,14 @@ int aff_shape_select(affnet_ctx* ctx, const float* d_resp_in, const float* d_laf
 int aff_cnn_forward_pyr_rows(affnet_ctx* ctx, int kind, const float* packed, const float* lafs, const int32_t* ids, const int32_t* count, int n_max,
                              float* out, float* scratch, int row_begin, int row_count, const int32_t* skip_cnt, int skip_n, hipStream_t st);
 
+// fused launches of the one-image-per-call latency path (cnn32.hip / laf_ops.hip)
+int aff_affnet_filter_rows(affnet_ctx* ctx, const float* packed, const float* resp, const float* lafs, const int32_t* ids, const int32_t* count,
+                           float* out, float* scratch, int row_begin, int row_count, bool lazy, int shape_op, hipStream_t st);
+int aff_orinet_rotate(affnet_ctx* ctx, const float* packed, float* lafs, const int32_t* ids, const int32_t* count, int n_max, float* out, float* scratch,
+                      hipStream_t st);
+int aff_denorm_level_select(affnet_ctx* ctx, const float* d_lafs_norm_in, float* d_lafs_px, const int32_t* d_count, int n_max, int ps, int32_t* d_ids,
+                            float* d_lafs_norm, hipStream_t st);
+
 int aff_detect_impl(affnet_ctx* ctx, const float* d_responses, float* d_resp, float* d_lafs, int32_t* d_ids, int32_t* d_count, void* stream);
 
 // Detector half for a custom RespNet slot: the caller has built the pyramid (affnet_pyramid_build), evaluated its RespNet on
@@ -151,19 +159,15 @@ extern "C" int affnet_describe_detected(affnet_ctx* ctx, const affnet_nets* nets
     const int lazy = (nets->d_affnet && ctx->cfg.baum_iters <= 1 && N > 0 && ctx->cfg.lazy_shape_rows != 0)
                          ? (ctx->cfg.lazy_shape_rows > 0 ? ctx->cfg.lazy_shape_rows : N + (N + 4) / 5) : 0;
     if (lazy > 0 && lazy < P) {
-        rc = aff_cnn_forward_pyr_rows(ctx, AFFNET_NET_AFFNET, nets->d_affnet, ctx->st_det_lafs, ctx->st_det_ids, det_count, P, ctx->st_A,
-                                      ctx->st_hard_scratch, 0, lazy, nullptr, 0, st);
+        // four launches: trunk + (finish + shape filter) per pass; the first trunk launch clears the survivor counters, the second
+        // freezes the first pass's survivor count (were: trunk, finish, clear, begin, filter, freeze, trunk, finish, filter)
+        rc = aff_affnet_filter_rows(ctx, nets->d_affnet, ctx->st_det_resp, ctx->st_det_lafs, ctx->st_det_ids, det_count, ctx->st_A, ctx->st_hard_scratch,
+                                    0, lazy, false, 1, st);
         if (rc) return rc;
-        rc = aff_shape_filter_begin(ctx, st);
-        if (rc) return rc;
-        rc = aff_shape_filter_rows(ctx, ctx->st_det_resp, ctx->st_det_lafs, ctx->st_A, det_count, 0, lazy, false, st, true);
-        if (rc) return rc;
-        rc = aff_cnn_forward_pyr_rows(ctx, AFFNET_NET_AFFNET, nets->d_affnet, ctx->st_det_lafs, ctx->st_det_ids, det_count, P, ctx->st_A,
-                                      ctx->st_hard_scratch, lazy, P - lazy, ctx->cnt, N, st);
+        rc = aff_affnet_filter_rows(ctx, nets->d_affnet, ctx->st_det_resp, ctx->st_det_lafs, ctx->st_det_ids, det_count, ctx->st_A, ctx->st_hard_scratch,
+                                    lazy, P - lazy, true, 2, st);
         if (rc) return rc;
         aff_prof_mark(ctx, 3, st);
-        rc = aff_shape_filter_rows(ctx, ctx->st_det_resp, ctx->st_det_lafs, ctx->st_A, det_count, lazy, P, true, st);
-        if (rc) return rc;
         rc = aff_shape_select(ctx, ctx->st_det_resp, ctx->st_det_lafs, ctx->st_det_ids, ctx->st_A, det_count, d_resp, ctx->st_lafs_shaped, d_ids,
                               d_count, st);
         if (rc) return rc;
@@ -197,28 +201,29 @@ extern "C" int affnet_describe_detected(affnet_ctx* ctx, const affnet_nets* nets
     }
     aff_prof_mark(ctx, 4, st);
     if (do_ori) {
-        if (nets->d_orinet)
-            rc = affnet_cnn32_forward_pyr(ctx, AFFNET_NET_ORINET, nets->d_orinet, ctx->st_lafs_shaped, d_ids, d_count, F, ctx->st_R,
-                                          ctx->st_hard_scratch, stream);
-        else
+        if (nets->d_orinet) {       // LAF <- LAF * R inside OriNet's finish kernel
+            rc = aff_orinet_rotate(ctx, nets->d_orinet, ctx->st_lafs_shaped, d_ids, d_count, F, ctx->st_R, ctx->st_hard_scratch, st);
+            if (rc) return rc;
+        } else {
             rc = aff_handcrafted_launch(ctx, AFFNET_HC_ORIENTATION, nullptr, ctx->st_lafs_shaped, d_ids, d_count, F, nets->h_orientation_window,
                                         ctx->st_R, nullptr, st);
-        if (rc) return rc;
-        rc = affnet_apply_rotation(ctx, ctx->st_lafs_shaped, ctx->st_R, d_count, F, stream);
-        if (rc) return rc;
+            if (rc) return rc;
+            rc = affnet_apply_rotation(ctx, ctx->st_lafs_shaped, ctx->st_R, d_count, F, stream);
+            if (rc) return rc;
+        }
     }
     aff_prof_mark(ctx, 5, st);
-    rc = affnet_scale_lafs(ctx, ctx->st_lafs_shaped, d_lafs_px, d_count, F, ctx->cfg.width, ctx->cfg.height, 0, stream);
-    if (rc) return rc;
     if (d_desc) {
-        rc = affnet_level_select(ctx, d_lafs_px, d_count, F, 32, ctx->st_lvl_ids, ctx->st_lafs_norm, stream);
+        // denormalise + level choice in one launch; descriptor rows past the row count are cleared by hardnet_finish_kernel
+        rc = aff_denorm_level_select(ctx, ctx->st_lafs_shaped, d_lafs_px, d_count, F, 32, ctx->st_lvl_ids, ctx->st_lafs_norm, st);
         if (rc) return rc;
-        { int zrc = aff_zero_async(ctx, d_desc, B * F * 128 * sizeof(float), st); if (zrc) return zrc; }
         aff_prof_mark(ctx, 6, st);
         rc = aff_hardnet_forward_pyr_marked(ctx, nets->d_hardnet, ctx->st_lafs_norm, ctx->st_lvl_ids, d_count, F, d_desc,
                                             ctx->st_hard_scratch, st);
         if (rc) return rc;
     } else {
+        rc = affnet_scale_lafs(ctx, ctx->st_lafs_shaped, d_lafs_px, d_count, F, ctx->cfg.width, ctx->cfg.height, 0, stream);
+        if (rc) return rc;
         aff_prof_mark(ctx, 6, st);
         aff_prof_mark(ctx, 7, st);
     }

@@ -28,6 +28,10 @@
 template <int K>
 struct Taps { float w[K * K]; };
 
+// acc = fma(a, w, acc) as ONE v_fmac_f32 with the (wave-uniform) tap in an SGPR: written as asm so that the vectoriser does not
+// pair it with its neighbour and rebuild the register pairs with v_mov (IEEE fma: bit-identical to fmaf)
+#define constexpr_fmac(acc, a, w) asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "s"(w), "v"(a))
+
 template <int K, int BT_R>
 __global__ __launch_bounds__(256) void blur2d_kernel(const float* __restrict__ in, float* __restrict__ out,
                                                      float* __restrict__ dec_out, int h, int w, int w2, size_t in_stride,
@@ -70,35 +74,30 @@ __global__ __launch_bounds__(256) void blur2d_kernel(const float* __restrict__ i
     __syncthreads();
     const int tx = (threadIdx.x & 15) * 4, ty = (threadIdx.x >> 4) * BT_R;
     if (y0 + ty >= h) return;
-    // The four outputs of a thread are two packed pairs (x, x+1), (x+2, x+3): tap j multiplies the input pairs
-    // (r[j], r[j+1]) and (r[j+2], r[j+3]).  Even j takes them from E[k] = (r[2k], r[2k+1]) (the aligned 16-byte reads),
-    // odd j from O[k] = (r[2k+1], r[2k+2]), a second read of the same row one float further - every v_pk_fma_f32 then has
-    // its operands in place (built from ONE copy of the row the compiler spent 88 v_mov per 120 v_pk_fma on re-pairing).
-    // Per accumulator the fmaf chain is unchanged: taps in row-major order.
+    // The four outputs of a thread are two packed pairs (x, x+1), (x+2, x+3): tap j multiplies the input pairs (r[j], r[j+1]) and
+    // (r[j+2], r[j+3]) of the row window r[0 .. K+2].  Even j finds them as E[k] = (r[2k], r[2k+1]), the halves of the aligned
+    // 16-byte LDS reads: one v_pk_fma_f32 per pair.  Odd j straddles those registers; its four products are plain v_fmac_f32 on
+    // the single halves (same fp32 VALU rate as the packed form: 2 x 2 cycles against 4), with the tap as the SGPR operand.
+    // (Round 2 read the odd pairs O[k] = (r[2k+1], r[2k+2]) a second time from LDS with 4-byte reads: lanes 16 bytes apart hit 8
+    // of the 32 banks, two tile rows per 32-lane group the same 8: 4-way conflicts on 16 reads per row - 65 % of the LDS cycles
+    // of the K = 11 kernel, and what bound the latency shape.)  Per accumulator the fmaf chain is unchanged: taps in row-major order.
     typedef float f32x2 __attribute__((ext_vector_type(2)));
     f32x2 acc01[BT_R], acc23[BT_R];
 #pragma unroll
     for (int rr = 0; rr < BT_R; ++rr) { acc01[rr] = (f32x2){0.f, 0.f}; acc23[rr] = (f32x2){0.f, 0.f}; }
     constexpr int NV = (K + 3 + 3) / 4;            // float4 loads covering K+3 values
-    constexpr int NO = (K + 1) / 2;                // odd-aligned pairs O[0 .. NO-1] (largest index used: (K - 2 + 1) / 2 = (K - 1) / 2)
-    // Input-row loop stays rolled (register window + K scalar taps per (row, output row) pair).
-#pragma unroll 1
+    // Input-row loop: rolled in the throughput shape (register window + K scalar taps per (row, output row) pair); fully unrolled in
+    // the latency shape.
+    constexpr int UNR = (BT_R == 1) ? K : 1;
+#pragma unroll UNR
     for (int i = 0; i < BT_R + K - 1; ++i) {
-        f32x2 E[NV * 2], O[NO];
-        const float* rowp = &tile[(ty + i) * LS + tx];
-        const float4* row = reinterpret_cast<const float4*>(rowp);
+        f32x2 E[NV * 2];
+        const float4* row = reinterpret_cast<const float4*>(&tile[(ty + i) * LS + tx]);
 #pragma unroll
         for (int v = 0; v < NV; ++v) {
             const float4 q = row[v];
             E[2 * v] = (f32x2){q.x, q.y}; E[2 * v + 1] = (f32x2){q.z, q.w};
         }
-        // (through an opaque LDS address: otherwise the compiler recognises the values it already holds and rebuilds the
-        // odd pairs with v_mov again)
-        unsigned oaddr = (unsigned)(size_t)(__attribute__((address_space(3))) const float*)rowp + 4;
-        asm("" : "+v"(oaddr));
-        typedef __attribute__((address_space(3))) const float LdsF;
-#pragma unroll
-        for (int k = 0; k < NO; ++k) O[k] = (f32x2){*(LdsF*)(size_t)(oaddr + 8 * k), *(LdsF*)(size_t)(oaddr + 8 * k + 4)};
 #pragma unroll
         for (int rr = 0; rr < BT_R; ++rr) {
             const int ti = i - rr;                  // tap row for output row rr (uniform across the workgroup)
@@ -106,11 +105,13 @@ __global__ __launch_bounds__(256) void blur2d_kernel(const float* __restrict__ i
 #pragma unroll
             for (int j = 0; j < K; ++j) {
                 const float wt = taps.w[ti * K + j];
-                const f32x2 wv = (f32x2){wt, wt};
                 if (j & 1) {
-                    acc01[rr] = __builtin_elementwise_fma(O[(j - 1) / 2], wv, acc01[rr]);
-                    acc23[rr] = __builtin_elementwise_fma(O[(j + 1) / 2], wv, acc23[rr]);
+                    constexpr_fmac(acc01[rr].x, E[(j - 1) / 2].y, wt);
+                    constexpr_fmac(acc01[rr].y, E[(j + 1) / 2].x, wt);
+                    constexpr_fmac(acc23[rr].x, E[(j + 1) / 2].y, wt);
+                    constexpr_fmac(acc23[rr].y, E[(j + 3) / 2].x, wt);
                 } else {
+                    const f32x2 wv = (f32x2){wt, wt};
                     acc01[rr] = __builtin_elementwise_fma(E[j / 2], wv, acc01[rr]);
                     acc23[rr] = __builtin_elementwise_fma(E[j / 2 + 1], wv, acc23[rr]);
                 }
