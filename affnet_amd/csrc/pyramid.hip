@@ -33,19 +33,22 @@ struct Taps { float w[K * K]; };
 #define constexpr_fmac(acc, a, w) asm("v_fmac_f32 %0, %1, %2" : "+v"(acc) : "s"(w), "v"(a))
 
 template <int K, int BT_R>
-__global__ __launch_bounds__(256) void blur2d_kernel(const float* __restrict__ in, float* __restrict__ out,
-                                                     float* __restrict__ dec_out, int h, int w, int w2, size_t in_stride,
-                                                     size_t out_stride, Taps<K> taps) {
+struct BlurTile {
+    static constexpr int R = K / 2;
+    static constexpr int LW = BT_X + 2 * R;               // tile width incl. halo
+    static constexpr int LS = (LW + 15) & ~15;            // row stride: multiple of 16 floats (16-B aligned rows, conflict-free b128)
+    static constexpr int LH = 16 * BT_R + 2 * R;
+    static constexpr int FLOATS = LH * LS;
+};
+
+// One output tile (tile coordinates bx, by) of one blur; `tile` = BlurTile<K, BT_R>::FLOATS floats of LDS.
+template <int K, int BT_R>
+__device__ __forceinline__ void blur2d_tile(float* tile, const float* __restrict__ in, float* __restrict__ out, float* __restrict__ dec_out, int h, int w,
+                                            int w2, int bx, int by, const Taps<K>& taps) {
     constexpr int R = K / 2;
     constexpr int BT_Y = 16 * BT_R;
-    constexpr int LW = BT_X + 2 * R;               // tile width incl. halo
-    constexpr int LS = (LW + 15) & ~15;            // row stride: multiple of 16 floats (16-B aligned rows, conflict-free b128)
-    constexpr int LH = BT_Y + 2 * R;
-    __shared__ __attribute__((aligned(16))) float tile[LH * LS];
-    const int x0 = blockIdx.x * BT_X, y0 = blockIdx.y * BT_Y;
-    in += blockIdx.z * in_stride;                   // blockIdx.z = image of the batch
-    out += blockIdx.z * out_stride;
-    if (dec_out) dec_out += blockIdx.z * out_stride;
+    constexpr int LW = BlurTile<K, BT_R>::LW, LS = BlurTile<K, BT_R>::LS, LH = BlurTile<K, BT_R>::LH;
+    const int x0 = bx * BT_X, y0 = by * BT_Y;
     const int rows_needed = min(LH, h - y0 + 2 * R);           // tiles at the bottom edge: skip rows nobody reads
     {
         // every load of a thread is in flight before the first LDS store (a load-store loop with a run-time trip count
@@ -144,6 +147,52 @@ __global__ __launch_bounds__(256) void blur2d_kernel(const float* __restrict__ i
     }
 }
 
+template <int K, int BT_R>
+__global__ __launch_bounds__(256) void blur2d_kernel(const float* __restrict__ in, float* __restrict__ out,
+                                                     float* __restrict__ dec_out, int h, int w, int w2, size_t in_stride,
+                                                     size_t out_stride, Taps<K> taps) {
+    __shared__ __attribute__((aligned(16))) float tile[BlurTile<K, BT_R>::FLOATS];
+    in += blockIdx.z * in_stride;                   // blockIdx.z = image of the batch
+    out += blockIdx.z * out_stride;
+    if (dec_out) dec_out += blockIdx.z * out_stride;
+    blur2d_tile<K, BT_R>(tile, in, out, dec_out, h, w, w2, blockIdx.x, blockIdx.y, taps);
+}
+
+// Two INDEPENDENT blurs in one launch: the last level of octave o (L-1 from L-2) and the first blur of octave o + 1 (level 1 from the
+// decimated level 0) both depend only on octave o's level L-2.  blockIdx.x < a.tiles: a tile of job a, else of job b (tiles_x per
+// job).  One launch less per octave on the serial chain of the pyramid (5 of 25 at 6 octaves).
+struct BlurJob { const float* in; float* out; int h, w, tiles_x, tiles; };
+template <int KA, int KB, int BT_R>
+__global__ __launch_bounds__(256) void blur2d_pair_kernel(BlurJob a, BlurJob b, size_t stride, Taps<KA> ta, Taps<KB> tb) {
+    constexpr int FL = BlurTile<KA, BT_R>::FLOATS > BlurTile<KB, BT_R>::FLOATS ? BlurTile<KA, BT_R>::FLOATS : BlurTile<KB, BT_R>::FLOATS;
+    __shared__ __attribute__((aligned(16))) float tile[FL];
+    const size_t img = blockIdx.z * stride;
+    if ((int)blockIdx.x < a.tiles) {
+        const int t = blockIdx.x;
+        blur2d_tile<KA, BT_R>(tile, a.in + img, a.out + img, nullptr, a.h, a.w, 0, t % a.tiles_x, t / a.tiles_x, ta);
+    } else {
+        const int t = (int)blockIdx.x - a.tiles;
+        blur2d_tile<KB, BT_R>(tile, b.in + img, b.out + img, nullptr, b.h, b.w, 0, t % b.tiles_x, t / b.tiles_x, tb);
+    }
+}
+
+// The reference's default schedule (init_sigma 1.6, 3 levels): 15 x 15 taps for the last level, 9 x 9 for level 1.  Other tap pairs
+// take the two separate launches.
+static bool launch_blur_pair(const float* in_a, float* out_a, int ha, int wa, const float* taps_a, int ka, const float* in_b, float* out_b, int hb, int wb,
+                             const float* taps_b, int kb, int batch, size_t stride, hipStream_t st) {
+    if (ka != 15 || kb != 9) return false;
+    Taps<15> ta; Taps<9> tb;
+    memcpy(ta.w, taps_a, sizeof(ta.w)); memcpy(tb.w, taps_b, sizeof(tb.w));
+    const int t64 = (aff_cdiv(wa, BT_X) * aff_cdiv(ha, 64) + aff_cdiv(wb, BT_X) * aff_cdiv(hb, 64)) * batch;
+    const int ty = t64 >= 1024 ? 64 : 16;
+    BlurJob a{in_a, out_a, ha, wa, aff_cdiv(wa, BT_X), aff_cdiv(wa, BT_X) * aff_cdiv(ha, ty)};
+    BlurJob b{in_b, out_b, hb, wb, aff_cdiv(wb, BT_X), aff_cdiv(wb, BT_X) * aff_cdiv(hb, ty)};
+    const dim3 grid(a.tiles + b.tiles, 1, batch);
+    if (ty == 64) hipLaunchKernelGGL((blur2d_pair_kernel<15, 9, 4>), grid, dim3(256), 0, st, a, b, stride, ta, tb);
+    else hipLaunchKernelGGL((blur2d_pair_kernel<15, 9, 1>), grid, dim3(256), 0, st, a, b, stride, ta, tb);
+    return true;
+}
+
 template <int K>
 static void launch_blur(const float* in, float* out, float* dec, int h, int w, int batch, size_t in_stride, size_t out_stride,
                         const float* taps, hipStream_t st) {
@@ -205,10 +254,12 @@ extern "C" int affnet_pyramid_build(affnet_ctx* ctx, const float* d_img, void* s
     const affnet_config& c = ctx->cfg;
     const int L = c.levels_per_octave;
     const int dec_level = L - 2;  // i == nLevels (HandCraftedModules.py:46)
+    int first_level = 1;             // 2 when the previous octave's paired launch already produced this octave's level 1
     for (int o = 0; o < c.n_octaves; ++o) {
         const OctaveGeom& g = ctx->oct[o];
         float* base = ctx->pyr + g.pyr_off;
         const size_t lvl = (size_t)g.h * g.w;
+        int next_first_level = 1;
         if (o == 0) {
             if (c.first_blur_taps > 0) {
                 int rc = blur_dispatch(ctx, d_img, base, nullptr, g.h, g.w, c.first_blur, c.first_blur_taps, st, ctx->B, lvl,
@@ -219,14 +270,27 @@ extern "C" int affnet_pyramid_build(affnet_ctx* ctx, const float* d_img, void* s
                 if (crc) return crc;
             }
         }
-        for (int l = 1; l < L; ++l) {
+        for (int l = first_level; l < L; ++l) {
             float* dec = nullptr;
             if (l == dec_level && o + 1 < c.n_octaves) dec = ctx->pyr + ctx->oct[o + 1].pyr_off;
             const bool own = (o == 0 && c.level_blur0_taps[1] > 0);      // octave 0 with its own blur sequence (init_sigma <= 0.5)
-            int rc = blur_dispatch(ctx, base + (l - 1) * lvl, base + l * lvl, dec, g.h, g.w, own ? c.level_blur0[l] : c.level_blur[l],
-                                   own ? c.level_blur0_taps[l] : c.level_blur_taps[l], st, ctx->B, ctx->pyr_stride, ctx->pyr_stride);
+            const float* taps = own ? c.level_blur0[l] : c.level_blur[l];
+            const int k = own ? c.level_blur0_taps[l] : c.level_blur_taps[l];
+            if (l == L - 1 && dec_level == L - 2 && o + 1 < c.n_octaves) {
+                // this octave's last level and the next octave's level 1 in one launch (both read what level L-2 produced)
+                const OctaveGeom& g1 = ctx->oct[o + 1];
+                float* base1 = ctx->pyr + g1.pyr_off;
+                if (launch_blur_pair(base + (l - 1) * lvl, base + l * lvl, g.h, g.w, taps, k, base1, base1 + (size_t)g1.h * g1.w, g1.h, g1.w, c.level_blur[1],
+                                     c.level_blur_taps[1], ctx->B, ctx->pyr_stride, st)) {
+                    AFF_LAUNCH_CHECK(ctx);
+                    next_first_level = 2;
+                    continue;
+                }
+            }
+            int rc = blur_dispatch(ctx, base + (l - 1) * lvl, base + l * lvl, dec, g.h, g.w, taps, k, st, ctx->B, ctx->pyr_stride, ctx->pyr_stride);
             if (rc) return rc;
         }
+        first_level = next_first_level;
     }
     return AFFNET_OK;
 }
