@@ -388,11 +388,19 @@ def affnet_batched(sd, patches, bs=256):
     return out
 
 
-def orinet_forward(sd, patches, return_rot=True):
-    """architectures.py:33-82 (OriNetFast.forward); head conv 8x8 padding 1."""
+def orinet_vector(sd, patches):
+    """architectures.py:33-80: the (n, 2) mean vector OriNetFast feeds to atan2 (head conv 8x8 padding 1, tanh, average pool).
+    Its length says how well conditioned the angle is: the parity report records it for LAF rows outside 1e-3 px."""
     y = cnn_trunk(sd, input_norm(patches))
     y = torch.tanh(F.conv2d(y, sd["features.19.weight"], sd["features.19.bias"], padding=1))
-    xy = F.adaptive_avg_pool2d(y, 1).view(-1, 2)
+    return F.adaptive_avg_pool2d(y, 1).view(-1, 2)
+
+
+def orinet_forward(sd, patches, return_rot=True, keep=None):
+    """architectures.py:33-82 (OriNetFast.forward).  keep: optional dict that receives the pre-atan2 vector under "vec"."""
+    xy = orinet_vector(sd, patches)
+    if keep is not None:
+        keep["vec"] = xy.clone()
     ang = torch.atan2(xy[:, 0] + 1e-8, xy[:, 1] + 1e-8)
     return rotation_matrix(ang) if return_rot else ang
 
@@ -486,7 +494,9 @@ class OracleExtractor(object):
         """SparseImgRepresenter.py:167-180."""
         ps = self.PS if self.ori is not None else 19
         patches = extract_from_pyramid(self.scale_pyr, octs, levs, lafs, ps)
-        R = orinet_forward(self.ori, patches) if self.ori is not None else angles_to_rotation(orientation_detector(patches))
+        keep = {}
+        R = orinet_forward(self.ori, patches, keep=keep) if self.ori is not None else angles_to_rotation(orientation_detector(patches))
+        self.ori_vec = keep.get("vec")           # (n, 2) OriNet output before atan2, row order of the returned LAFs (None: hand-crafted detector)
         lafs = torch.cat([torch.bmm(lafs[:, :, :2], R), lafs[:, :, 2:]], dim=2)
         if self.waste:  # :178-179, result discarded by the reference
             extract_from_pyramid(self.scale_pyr, octs, levs, lafs, ps)

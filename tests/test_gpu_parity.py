@@ -20,6 +20,7 @@ import pytest
 import torch
 
 import affnet_oracle as orc
+from _rowmatch import match_rows, tie_groups
 from conftest import load_gray, record_parity
 
 pytestmark = pytest.mark.gpu
@@ -50,12 +51,24 @@ def _report(name, got, want):
     return d
 
 
-def _row_stats(name, ids_g, L, D, r, keys_w, Lw, Dw, rw, extra=None):
-    """Key-matched comparison of one image's rows with the oracle's; records the numbers in the parity report."""
+def _row_stats(name, ids_g, L, D, r, keys_w, Lw, Dw, rw, extra=None, ori_vec=None):
+    """Key-matched comparison of one image's rows with the oracle's; records the numbers in the parity report.  ori_vec: the oracle's
+    OriNet output vectors before atan2 (row order of Lw): for every LAF row outside 1e-3 px the report then carries the vector's
+    length - a short vector is what makes the angle (and with it the frame) sensitive to the CNN's summation order."""
     gi, wi = _match(ids_g, keys_w)
     n = len(keys_w)
     dl = np.abs(L[gi] - Lw[wi]).reshape(len(gi), -1).max(axis=1)
     worst = int(np.argmax(dl)) if len(gi) else 0
+    if ori_vec is not None and len(gi):
+        nv = np.linalg.norm(np.asarray(ori_vec, dtype=np.float64), axis=1)
+        out = np.nonzero(dl >= 1e-3)[0]
+        # a pure rotation of the frame by d_angle moves its entries by |A| d_angle: report the implied angle error as well
+        extra = dict(extra or {})
+        extra["rows_outside_1e-3"] = [{"key_octave_level_pixel": [int(v) for v in np.asarray(ids_g)[gi[k]]], "laf_err_px": float(dl[k]),
+                                       "orinet_norm": float(nv[wi[k]]),
+                                       "centre_err_px": float(np.abs(L[gi[k]][:, 2] - Lw[wi[k]][:, 2]).max()),
+                                       "det_rel_err": float(abs(np.linalg.det(L[gi[k]][:, :2]) / np.linalg.det(Lw[wi[k]][:, :2]) - 1.0))} for k in out]
+        extra["orinet_norm_percentiles_all_rows_p1_p10_p50"] = [float(np.percentile(nv, q)) for q in (1, 10, 50)]
     rec = {"keypoints": int(n), "matched": int(len(gi)), "match_rate": len(gi) / float(max(n, 1)), "same_row_order": bool(len(gi) == n and np.array_equal(gi, wi)),
            "laf_p50_px": float(np.percentile(dl, 50)), "laf_p99_px": float(np.percentile(dl, 99)), "laf_max_px": float(dl.max()),
            "laf_rows_within_1e-3": float((dl < 1e-3).mean()), "worst_row_key_octave_level_pixel": [int(v) for v in np.asarray(ids_g)[gi[worst]]],
@@ -271,7 +284,7 @@ def _check_full(amd, nets, x, n, weights, want=None, min_match=0.995, name=None)
     inside = row_err < 1e-3 + 1e-6 * np.abs(Lw.numpy()).max()
     print("rows within 1e-3 px: %.4f ; worst row %.3g px" % (inside.mean(), row_err.max()))
     _row_stats(name or "full path %dx%d n=%d" % (x.size(3), x.size(2), n), res["ids"].cpu().numpy(), L, D, r, ex.keys.numpy(), Lw.numpy(), Dw.numpy(),
-               rw.numpy())
+               rw.numpy(), ori_vec=None if ex.ori_vec is None else ex.ori_vec.numpy())
     assert inside.mean() >= 0.995 and row_err.max() < 5e-3, "LAF error above tolerance"
     assert dd[inside].max() < 1e-3 and np.percentile(dd, 99.5) < 1e-3, "descriptor error above 1e-3"
     assert np.array_equal(r[gi], rw.numpy()[wi]), "responses of matched keypoints must be bit-identical"
@@ -280,11 +293,15 @@ def _check_full(amd, nets, x, n, weights, want=None, min_match=0.995, name=None)
     dp = np.abs(P[gi] - Pw.numpy()[wi])
     print("descriptor patches max diff %.3g (0..255 scale)" % dp.max())
     assert np.percentile(dp, 99.9) < 5e-2
-    if want is not None:   # committed golden vectors from the unmodified reference (authoring host)
-        eg = np.abs(L[gi] - want["LAFs"][wi]).reshape(len(gi), -1).max(axis=1)
-        print("vs golden: rows within 1e-3 px %.4f, worst %.3g" % ((eg < 1e-3).mean(), eg.max()))
-        assert (eg < 1e-3).mean() >= 0.995 and eg.max() < 1e-2
-        assert np.percentile(np.abs(D[gi] - want["desc"][wi]), 99.5) < 1e-3
+    if want is not None:   # committed golden vectors from the unmodified reference (authoring host): rows matched by response bits + centre
+        g2, w2 = match_rows(r, L, want["resp"], want["LAFs"])
+        eg = np.abs(L[g2] - want["LAFs"][w2]).reshape(len(g2), -1).max(axis=1)
+        print("vs golden: matched %d of %d, rows within 1e-3 px %.4f, worst %.3g" % (len(g2), len(want["resp"]), (eg < 1e-3).mean(), eg.max()))
+        record_parity((name or "full path") + " vs the reference's golden output", golden_rows=int(len(want["resp"])), matched=int(len(g2)),
+                      golden_rows_with_tied_responses=tie_groups(want["resp"]), laf_max_px=float(eg.max()), laf_rows_within_1e_3=float((eg < 1e-3).mean()),
+                      desc_max=float(np.abs(D[g2] - want["desc"][w2]).max()))
+        assert len(g2) >= min_match * len(want["resp"]) and (eg < 1e-3).mean() >= 0.995 and eg.max() < 1e-2
+        assert np.percentile(np.abs(D[g2] - want["desc"][w2]), 99.5) < 1e-3
     return det, res
 
 
@@ -510,14 +527,16 @@ def test_handcrafted_default_slots(amd, nets, golden_dir):
     x = orc.synthetic_image(240, 320, 1).to(DEV)
     det = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=0).to(DEV)     # default slots
     L, r = det(x, do_ori=True)
-    assert np.array_equal(r.cpu().numpy(), g["default_resp"])
-    row_err = np.abs(L.cpu().numpy() - g["default_LAFs"]).reshape(len(L), -1).max(axis=1)
+    assert np.array_equal(np.sort(r.cpu().numpy()), np.sort(g["default_resp"]))
+    gi, wi = match_rows(r.cpu().numpy(), L.cpu().numpy(), g["default_resp"], g["default_LAFs"])
+    assert len(gi) == len(g["default_resp"])
+    row_err = np.abs(L.cpu().numpy()[gi] - g["default_LAFs"][wi]).reshape(len(gi), -1).max(axis=1)
     print("default extractor: rows within 1e-3 px %.4f (a flipped orientation bin rotates the frame)" % (row_err < 1e-3).mean())
     record_parity("default-constructed extractor (hand-crafted slots) 320x240", rows=int(len(L)), rows_within_1e_3=float((row_err < 1e-3).mean()),
                   worst_row_px=float(row_err.max()))
     assert (row_err < 1e-3).mean() >= 0.99
     # frames that differ must differ by a pure rotation: same centre, same determinant
-    assert np.abs(L.cpu().numpy()[:, :, 2] - g["default_LAFs"][:, :, 2]).max() < 1e-3
+    assert np.abs(L.cpu().numpy()[gi][:, :, 2] - g["default_LAFs"][wi][:, :, 2]).max() < 1e-3
     # LAFs2ellT (section 8f row 3) on the reference's own LAFs
     ell = amd.LAF.LAFs2ellT(torch.from_numpy(g["default_LAFs"]).to(DEV)).cpu().numpy()
     rel = np.abs(ell - g["default_ellT"]) / (np.abs(g["default_ellT"]) + 1e-6 * np.abs(g["default_ellT"]).max())
@@ -526,12 +545,18 @@ def test_handcrafted_default_slots(amd, nets, golden_dir):
     assert rel.max() < 2e-4 and np.array_equal(ell[:, :2], g["default_ellT"][:, :2])
     det = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=4).to(DEV)
     L, r = det(x, do_ori=False)
-    assert L.shape == g["baum4_LAFs"].shape and np.array_equal(r.cpu().numpy(), g["baum4_resp"])
-    row_err = np.abs(L.cpu().numpy() - g["baum4_LAFs"]).reshape(len(L), -1).max(axis=1)
+    # The golden holds two rows with the SAME response (rows 206 / 207, centres 50.77 px apart: an exact tie, whose order torch.topk
+    # leaves unspecified); rows are therefore matched by response bits + centre, and then every row has to agree.  (Round 2 compared row
+    # by row, saw the swapped pair as a 50.77 px "error" and explained it with near-singular shapes - wrongly.)
+    assert L.shape == g["baum4_LAFs"].shape and np.array_equal(np.sort(r.cpu().numpy()), np.sort(g["baum4_resp"]))
+    gi, wi = match_rows(r.cpu().numpy(), L.cpu().numpy(), g["baum4_resp"], g["baum4_LAFs"])
+    assert len(gi) == len(g["baum4_resp"])
+    row_err = np.abs(L.cpu().numpy()[gi] - g["baum4_LAFs"][wi]).reshape(len(gi), -1).max(axis=1)
     print("Baumberg x4: worst row %.3g px, rows within 1e-3 px %.4f" % (row_err.max(), (row_err < 1e-3).mean()))
-    record_parity("4 Baumberg iterations 320x240 vs golden", rows=int(len(L)), rows_within_1e_3=float((row_err < 1e-3).mean()), worst_row_px=float(row_err.max()),
-                  note="rows outside are near-singular shapes: the iteration amplifies any ulp")
-    assert (row_err < 1e-3).mean() >= 0.99
+    record_parity("4 Baumberg iterations 320x240 vs golden", rows=int(len(L)), matched=int(len(gi)), golden_rows_with_tied_responses=tie_groups(g["baum4_resp"]),
+                  rows_within_1e_3=float((row_err < 1e-3).mean()), worst_row_px=float(row_err.max()),
+                  note="rows matched by response bits + centre (the golden holds one exact response tie)")
+    assert (row_err < 1e-3).all(), "rows %s" % np.nonzero(row_err >= 1e-3)[0].tolist()
 
 
 def test_matching_snn_and_homography_check(amd, golden_dir):
@@ -682,7 +707,7 @@ def test_metric_configuration_batched_b32_vs_oracle(amd, nets, weights, golden_d
         Lw, rw, Pw, Dw = orc.describe(orc.synthetic_image(768, 1024, seeds[i]), ex, weights["HardNet"], do_ori=True, ps=32)
         gi, wi, dl, dd, rec = _row_stats("configs[2] metric configuration: image %d of a 32-image batch, 1024x768, 2000 kp" % i,
                                          got["ids"].cpu().numpy(), got["LAFs"].cpu().numpy(), got["descriptors"].cpu().numpy(),
-                                         got["responses"].cpu().numpy(), ex.keys.numpy(), Lw.numpy(), Dw.numpy(), rw.numpy())
+                                         got["responses"].cpu().numpy(), ex.keys.numpy(), Lw.numpy(), Dw.numpy(), rw.numpy(), ori_vec=ex.ori_vec.numpy())
         assert rec["match_rate"] >= 0.995, rec
         assert rec["responses_equal"], "responses of matched keypoints must be bit-identical"
         assert rec["laf_rows_within_1e-3"] >= 0.995 and rec["laf_max_px"] < 1e-2, rec
@@ -693,17 +718,33 @@ def test_metric_configuration_batched_b32_vs_oracle(amd, nets, weights, golden_d
     g = np.load(os.path.join(golden_dir, "synth_768x1024_s31_n2000.npz"))
     assert int(g["seed"]) == seeds[31]
     got = batched[31]
-    rg, rw = got["responses"].cpu().numpy().view(np.uint32), g["resp"].view(np.uint32)
-    uniq = {v for v, c in zip(*np.unique(rw, return_counts=True)) if c == 1}
-    pos = {v: i for i, v in enumerate(rw)}
-    gi = np.array([i for i, v in enumerate(rg) if v in uniq], dtype=np.int64)
-    wi = np.array([pos[rg[i]] for i in gi], dtype=np.int64)
+    gi, wi = match_rows(got["responses"].cpu().numpy(), got["LAFs"].cpu().numpy(), g["resp"], g["LAFs"])
     dl = np.abs(got["LAFs"].cpu().numpy()[gi] - g["LAFs"][wi]).reshape(len(gi), -1).max(axis=1)
     dd = np.abs(got["descriptors"].cpu().numpy()[gi] - g["desc"][wi]).max(axis=1)
     record_parity("configs[2] metric configuration: image 31 of the batch vs the reference's golden output", keypoints=2000, matched=int(len(gi)),
                   same_row_order=bool(np.array_equal(gi, wi)), laf_max_px=float(dl.max()), laf_rows_within_1e_3=float((dl < 1e-3).mean()),
                   desc_max=float(dd.max()), desc_rows_within_1e_3=float((dd < 1e-3).mean()))
     assert len(gi) >= 0.995 * 2000 and (dl < 1e-3).mean() >= 0.995 and (dd < 1e-3).mean() >= 0.995 and dl.max() < 1e-2
+
+
+@pytest.mark.parametrize("case", ["hesaffnet_cat", "hesaffnet_fox1", "synth_481x641_s5"])
+def test_odd_sized_reference_images_full_path(amd, nets, weights, golden_dir, case):
+    """Odd-sized level 0 through the whole path (SparseImgRepresenter.py:189-209 on inputs the reference itself ships):
+    examples/hesaffnet/img/cat.png (598 x 1000), fox1.png (1000 x 563) and a synthetic 641 x 481 image, 2000 kp, do_ori + HardNet,
+    against the oracle on this host AND the unmodified reference's golden output (tests/golden/make_golden_oddsize.py); then the same
+    image inside a batch of 4 (different images around it): bit-identical to its single-image call."""
+    g = np.load(os.path.join(golden_dir, case + "_n2000.npz"))
+    x = load_gray(os.path.join(golden_dir, case + ".png")) if case.startswith("hesaffnet") else orc.synthetic_image(481, 641, 5)
+    assert tuple(x.shape[2:]) == tuple(int(v) for v in g["hw"])
+    det, res = _check_full(amd, nets, x, 2000, weights, want=g, name="odd-sized input %s %dx%d, 2000 kp" % (case, x.size(3), x.size(2)))
+    A, O, H = nets
+    h, w = x.shape[2:]
+    others = [orc.synthetic_image(h, w, s) for s in (11, 12, 13)]
+    xb = torch.cat([others[0], x, others[1], others[2]], 0).to(DEV)
+    bdet = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=2000, border=5, num_Baum_iters=1, AffNet=A, OriNet=O).to(DEV)
+    batched = bdet.run_batch(xb, do_ori=True, desc=H)
+    for k in ("LAFs", "responses", "descriptors", "ids"):
+        assert torch.equal(batched[1][k], res[k]), "image 1 of the batch of 4 differs from its single-image call in %s" % k
 
 
 def test_exact_response_ties_are_resolved_deterministically(amd, nets):

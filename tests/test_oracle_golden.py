@@ -149,6 +149,22 @@ def test_metric_configuration_1024x768_n2000(golden_dir, weights):
     _close(D.numpy(), g["desc"], 1e-4, "descriptors")
 
 
+@pytest.mark.parametrize("case", ["hesaffnet_cat", "hesaffnet_fox1", "synth_481x641_s5"])
+def test_odd_sized_inputs(golden_dir, weights, case):
+    """The oracle on odd-sized inputs the reference ships (examples/hesaffnet/img/cat.png 598 x 1000, fox1.png 1000 x 563) and a
+    synthetic 641 x 481 image against the unmodified reference's output (tests/golden/make_golden_oddsize.py); rows matched by
+    response bits + centre (the synthetic case holds an exact response tie, whose order topk leaves open)."""
+    from _rowmatch import match_rows
+    g = np.load(os.path.join(golden_dir, case + "_n2000.npz"))
+    x = load_gray(os.path.join(golden_dir, case + ".png")) if case.startswith("hesaffnet") else orc.synthetic_image(481, 641, 5)
+    assert tuple(x.shape[2:]) == tuple(int(v) for v in g["hw"])
+    ex, (L, r, P, D) = _full(x, 2000, weights)
+    gi, wi = match_rows(r.numpy(), L.numpy(), g["resp"], g["LAFs"])
+    assert len(gi) >= 1998, "only %d of 2000 rows carry a response of the golden" % len(gi)
+    _close(L.numpy()[gi], g["LAFs"][wi], 1e-3, "LAFs px")
+    _close(D.numpy()[gi], g["desc"][wi], 1e-4, "descriptors")
+
+
 def test_onepass_oracle_vs_reference_golden(golden_dir, weights):
     """oracle/onepass_oracle.py (OnePassSIR path) against the reference's own outputs
     (tests/golden/make_golden_onepass.py: AffNetFastFullConv / LocalNorm2d classes + OnePassSIR.py through the in-memory shim)."""

@@ -20,7 +20,9 @@ WIDTHS = {
     "hardnet_head_kernel": ("read", "16B_per_lane", 4),        # conv5 slabs + weights as 16-byte buffer loads; partials as 4-byte stores
     "hardnet_finish_kernel": ("read", "4B_per_lane", 4),
     "grid_sample_kernel": ("read", "4B_per_lane", 4),
-    "cnn16_finish_kernel": ("read", "16B_per_lane", 4),
+    "affnet_finish_kernel": ("read", "16B_per_lane", 4),
+    "orinet_finish_kernel": ("read", "4B_per_lane", 4),
+    "blur2d_pair_kernel": ("tile", "4B_per_lane_halo7", 16),
 }
 
 
