@@ -58,7 +58,7 @@ def record_counts(records):
 def gather_features_async(local_records, n_total, group=None, force=False, dst=None):
     """Starts the exchange and returns a `finish()` callable that waits for it and returns the records in global image
     order - lets the caller overlap the exchange of step k with the compute of step k+1 (bench.py).  dst=None: all_gather
-    (every rank gets all records); dst=r: gather to rank r only (finish() returns None on the other ranks).  force=True runs
+    (every rank gets all records); dst=r: gather to GLOBAL rank r only (finish() returns None on the other ranks).  force=True runs
     the collective even in a 1-rank group (single-GPU dry run of the RCCL path)."""
     if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not force):
         return lambda: local_records
@@ -92,7 +92,10 @@ def _gather_to_rank_async(local_records, n_total, group, dst, world):
     if dist.get_backend(group) == "gloo" and local_records.is_cuda:
         local_records = local_records.cpu()
     local_records = local_records.contiguous()
-    me = dist.get_rank(group)
+    me = dist.get_rank()                 # dst is a GLOBAL rank (what dist.gather expects), so compare with the global rank: with a sub-group
+                                         # dist.get_rank(group) is the group-local rank and the wrong rank (or none) would allocate the output
+    if group is not None and dst not in dist.get_process_group_ranks(group):
+        raise ValueError("gather destination %d (global rank) is not a member of the group" % dst)
     parts = [torch.empty_like(local_records) for _ in range(world)] if me == dst else None
     work = dist.gather(local_records, parts, dst=dst, group=group, async_op=True)      # RCCL: grouped send / recv to one rank
 

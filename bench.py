@@ -249,6 +249,11 @@ def main():
     ap.add_argument("--onepass", action="store_true",
                     help="OnePassSIR path (SURVEY section 8f row 4) instead of the headline path: affine shapes from ONE dense AffNetFastFullConv "
                          "evaluation per octave (shipped AffNet.pth weights), border = 15 like the reference's scripts; a separately labelled line")
+    ap.add_argument("--verify-gather", nargs="?", const="all", default=None, metavar="all|sample|off",
+                    help="after the timed region rank 0 re-computes gathered records of the LAST step itself (single-image calls on the same "
+                         "seeds) and compares them bit for bit with what arrived through the exchange: right content, count and global order. "
+                         "Default for N > 1: 'sample' (first and last image of every rank); 'all' checks every record; N = 1 with "
+                         "AFFNET_BENCH_SELF_GATHER=1 checks the 1-rank RCCL path")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: ranks rendezvous (backend from AFFNET_BENCH_BACKEND, default gloo here), exchange fake records and "
                          "print the JSON skeleton - exercises the launch / world-size / gather bookkeeping on a CPU host")
@@ -504,10 +509,12 @@ def run(args, world):
             pending[0] = sharded.gather_features_async(rec, args.batch * world, force=SELF, dst=gather_dst)
         return results
 
+    gathered = [None]                  # records of the last drained step in global image order (None on ranks a rank-0 gather skips)
+
     def drain():
         if pending[0] is not None:
             with torch.cuda.stream(streams[0]):
-                pending[0]()
+                gathered[0] = pending[0]()
             pending[0] = None
         torch.cuda.synchronize()
 
@@ -555,9 +562,39 @@ def run(args, world):
         sums = [a + b for a, b in zip(sums, list(buf))]
     t_all = torch.tensor([dt], dtype=torch.float64, device=dev)
     kp_all = torch.tensor([kp], dtype=torch.float64, device=dev)
+    rank_ms = [dt / args.steps * 1e3]
     if world > 1:
+        per_rank = [torch.zeros_like(t_all) for _ in range(world)]
+        dist.all_gather(per_rank, t_all)
+        rank_ms = [float(t.item()) / args.steps * 1e3 for t in per_rank]
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
         dist.all_reduce(kp_all, op=dist.ReduceOp.SUM)
+    # ---- the exchange on its own (outside the timed region): bytes, stand-alone duration, and the content check ----------------------
+    exchange = None
+    if DIST:
+        rec_local = sharded.pack_batched_records(last, NKP)                      # this rank's records of the last step
+        times = []
+        for _ in range(5):
+            barrier()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fin = sharded.gather_features_async(rec_local, args.batch * world, force=SELF, dst=gather_dst)
+            got = fin()
+            e1.record()
+            torch.cuda.synchronize()
+            times.append(e0.elapsed_time(e1))
+        times.sort()
+        rec_bytes = int(rec_local.size(1)) * 4
+        exchange = {"record_bytes": rec_bytes, "records_per_step": args.batch * world,
+                    "exchange_bytes_per_step": rec_bytes * args.batch * world * (world if gather_dst is None else 1),
+                    "what": "all_gather: every rank receives every record" if gather_dst is None else "gather: rank 0 receives every record",
+                    "gather_ms": times[len(times) // 2], "gather_ms_min": times[0],
+                    "how": "median of 5 stand-alone exchanges of one step's records after the timed region (HIP events around issue + wait, "
+                           "barrier first); inside the timed region the exchange of step k runs under the kernels of step k+1"}
+    mode = args.verify_gather or ("sample" if world > 1 else ("sample" if SELF else "off"))
+    gather_check = None
+    if DIST and mode != "off":
+        gather_check = verify_gather(gathered[0], mode, world, rank, args.batch, dev, (A, O, Hn), ONEPASS)
     if rank == 0:
         tmax, kps = float(t_all.item()), float(kp_all.item())
         stage_ms = [s / max(call_imgs, 1) for s in sums]           # per image (rank 0's launches)
@@ -598,6 +635,7 @@ def run(args, world):
                                           "RCCL" if backend == "nccl" else backend + " (dry run of the N-rank path)")) if world > 1 else "1 GPU"},
             "ms_per_image": tmax / (args.steps * args.batch) * 1e3,
             "stage_ms_per_image": dict(zip(names, [round(v, 4) for v in stage_ms])),
+            "ms_per_step_per_rank": {"min": min(rank_ms), "max": max(rank_ms), "all": [round(v, 3) for v in rank_ms]},
             "roofline": {"kernel": "cnn32_trunk_kernel<HardNet> (fp32 MFMA 16x16x4, fused sampler+norm+6 convs)", "bound": "mfma",
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": achieved / PEAK_FP32_MFMA_TFLOPS,
                          "traffic": traffic, "traffic_source": traffic_note, "flops_per_launch": flops_launch, "launch_ms": trunk_ms,
@@ -607,6 +645,10 @@ def run(args, world):
                          "affnet_tflops": aff_eval_per_img * FLOP_AFF / (max(stage_ms[2], 1e-9) * 1e-3) / 1e12,
                          "orinet_tflops": kp_per_img * FLOP_ORI / (max(stage_ms[4], 1e-9) * 1e-3) / 1e12},
         }
+        if exchange is not None:
+            out["exchange"] = exchange
+        if gather_check is not None:
+            out["gather_check"] = gather_check
         if ONEPASS:
             out["stage_ms_per_image"]["detector"] = round(stage_ms[1], 4)
             out["config"]["workload"] = ("OnePassSIR path (SURVEY section 8f row 4) on the BASELINE configs[2] images: batch of %d synthetic %dx%d images, %d kp, "
@@ -629,6 +671,40 @@ def run(args, world):
         print(json.dumps(out), flush=True)
     if DIST:
         dist.destroy_process_group()
+
+
+def verify_gather(records, mode, world, rank, batch, dev, nets, onepass):
+    """The N-rank path checked with REAL kernels: rank 0 takes the records the exchange delivered for the last timed step (global
+    image order: image i was computed by rank i % world from seed i) and re-computes the checked ones itself with a single-image call on
+    the same seed: equal count, bit-equal LAFs / responses / descriptors (batched == single-image is bit-exact, tests/test_gpu_parity.py).
+    Wrong order, a swapped rank, stale or truncated records all show here.  Returns the dict for the bench line (rank 0) or None."""
+    import affnet_amd
+    from affnet_amd import sharded
+    from affnet_amd.synthetic import synthetic_image
+    if rank != 0:
+        return None
+    n_total = batch * world
+    if records is None or records.size(0) != n_total:
+        return {"identical": False, "error": "rank 0 holds %s records, expected %d" % (None if records is None else records.size(0), n_total)}
+    if mode == "all":
+        idx = list(range(n_total))
+    else:                                         # first and last image of every rank
+        idx = sorted(set([r for r in range(world)] + [r + world * (batch - 1) for r in range(world)]))
+    A, O, Hn = nets
+    if onepass:
+        return {"identical": None, "error": "not implemented for --onepass"}
+    det = affnet_amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=NKP, border=5, num_Baum_iters=1, AffNet=A, OriNet=O).to(dev)
+    bad, counts = [], sharded.record_counts(records).tolist()
+    for i in idx:
+        res = det.run(synthetic_image(H, W, i).to(dev), do_ori=True, desc=Hn)
+        got = sharded.unpack_record(records[i], NKP)
+        n = int(res["LAFs"].shape[0])
+        same = counts[i] == n and all(torch.equal(got[k], res[k]) for k in ("LAFs", "responses", "descriptors"))
+        if not same:
+            bad.append({"record": i, "from_rank": i % world, "count_gathered": counts[i], "count_recomputed": n})
+    return {"records": n_total, "checked": len(idx), "mode": mode, "identical": not bad, "mismatches": bad[:8],
+            "what": "gathered record i of the last timed step vs a single-image call on seed i by rank 0: count, LAFs, responses, "
+                    "descriptors bit-equal, global order i -> rank i % world"}
 
 
 def secondary_rooflines(dets, chunks, stage_ms, dev):

@@ -981,3 +981,27 @@ def test_config5_4k_deep_pyramid(amd, nets, weights):
             assert torch.equal(batched[i][k], res[k]), "4K batch image %d differs from the single-image call in %s" % (i, k)
     for b in batched:
         assert b["LAFs"].shape == (8000, 2, 3) and np.abs(np.linalg.norm(b["descriptors"].cpu().numpy(), axis=1) - 1.0).max() < 1e-4
+
+
+@pytest.mark.parametrize("ranks,gather", [(2, "all"), (3, "rank0")])
+def test_bench_n_rank_gather_with_real_kernels(ranks, gather):
+    """The N-rank path of bench.py with REAL kernels: N self-spawned ranks share this one device (gloo for the
+    exchange - RCCL cannot put two ranks on one GPU), every rank computes its images, the records travel through all_gather / the
+    gather to rank 0, and rank 0 re-computes EVERY record of the last step with a single-image call on the same seed
+    (--verify-gather all): counts, LAFs, responses and descriptors bit-equal, global order image i -> rank i % world."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"AFFNET_BENCH_ONE_DEVICE": "1", "AFFNET_BENCH_BACKEND": "gloo", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(ranks), "--steps", "2", "--warmup", "1", "--batch", "4", "--chunk", "2",
+                        "--no-secondary", "--gather", gather, "--verify-gather", "all"], env=env, capture_output=True, text=True, timeout=900)
+    lines = [json.loads(l) for l in p.stdout.splitlines() if l.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, p.stderr[-2000:]
+    d = lines[0]
+    gc = d["gather_check"]
+    record_parity("bench.py --gpus %d (one device, gloo, %s): gathered records vs single-image recomputation on rank 0" % (ranks, gather), **gc)
+    assert d["n_gpus"] == ranks and gc["records"] == 4 * ranks and gc["checked"] == 4 * ranks and gc["identical"] is True, gc
+    assert d["exchange"]["exchange_bytes_per_step"] == (4 + 540 * 2000) * 4 * ranks * (ranks if gather == "all" else 1)
+    assert len(d["ms_per_step_per_rank"]["all"]) == ranks

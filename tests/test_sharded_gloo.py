@@ -94,6 +94,52 @@ def test_bench_self_spawns_n_ranks(gather):
     assert out[0]["config"]["gather"] == ("all_gather" if gather == "all" else "gather to rank 0")
 
 
+def test_bench_eight_ranks_config5_dry_run():
+    """`python bench.py --gpus 8 --config5` (BASELINE.json configs[4] on the whole node) through the self-spawn / rendezvous / gather /
+    JSON path: 8 ranks, the 4K geometry's defaults (8 images per rank per step), one line."""
+    rc, out, err = _bench("--gpus", "8", "--config5", "--steps", "1", "--warmup", "0", "--dry-run")
+    assert rc == 0, err
+    assert len(out) == 1, out
+    assert out[0]["n_gpus"] == 8 and out[0]["config"]["global_batch"] == 64 and out[0]["records_in_global_order"] is True
+    assert "8000 kp @3840x2160" in out[0]["metric"]
+
+
+def test_gather_to_rank_in_a_subgroup_uses_global_ranks():
+    """_gather_to_rank_async compared the group-LOCAL rank with the GLOBAL dst.  World of 3, sub-group {1, 2}, gather to
+    global rank 2: rank 2 must receive both records in order, rank 1 gets None, rank 0 is not involved."""
+    import torch.multiprocessing as mp
+    mp.spawn(_subgroup_worker, args=(3, _free_port()), nprocs=3, join=True)
+
+
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def _subgroup_worker(rank, world, port):
+    import torch.distributed as dist
+    from affnet_amd import sharded
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    grp = dist.new_group([1, 2])
+    if rank in (1, 2):
+        rec = torch.full((1, 4), float(rank))
+        got = sharded.gather_features_async(rec, 2, group=grp, dst=2)()
+        if rank == 2:
+            assert got is not None and got[:, 0].tolist() == [1.0, 2.0], got
+        else:
+            assert got is None
+        try:
+            sharded.gather_features_async(rec, 2, group=grp, dst=0)
+            raise AssertionError("a destination outside the group must be refused")
+        except ValueError:
+            pass
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def test_bench_refuses_wrong_world_or_missing_devices():
     # a launcher-provided WORLD_SIZE that disagrees with --gpus must not silently report n_gpus = WORLD_SIZE
     rc, out, err = _bench("--gpus", "4", "--dry-run", env={"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
