@@ -24,6 +24,7 @@
 // gxx = (l - 2c) + r, gxy from replicate-padded gx, |gxx*gyy - gxy*gxy| * float32(sigma^4),
 // keep iff (c - max27) + 1e-5f > 0, centroid sums as fmaf chains in (level, ky, kx) order.
 #include <math.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -31,9 +32,12 @@
 #define HT_Y 16
 #define HX_W (HT_X + 4)   // blurred tile with 2-px halo
 #define HX_H (HT_Y + 4)
+#define HX_S 70           // LDS row stride of the blurred tile: thread t = 14 * row + segment reads X at 70 * row + 5 * segment + k, i.e. bank
+                          // 5 * t + const (mod 32) - distinct over any 32 consecutive threads (stride 68 gave 2-way conflicts on the 105
+                          // window reads per thread that dominate this kernel's LDS traffic: 45 % of its LDS cycles)
 #define HR_W (HT_X + 2)   // response tile with 1-px halo
 #define HR_H (HT_Y + 2)
-#define HR_S (HR_W + 1)   // padded row stride
+#define HR_S (HR_W + 2)   // row stride 68 floats: rows 16-byte aligned, so that the NMS reads its 6-float windows as b128 + b64
 #define HN_CAP 320        // per-workgroup staging capacity (1024 px x 3 levels; ~2% are maxima)
 
 struct HessOct {           // one octave of the launch
@@ -52,6 +56,7 @@ struct HessOct {           // one octave of the launch
 struct HessParams {
     HessOct oct[AFFNET_MAX_OCTAVES];
     int n_oct, n_levels;   // n_levels = levels_per_octave (5)
+    int n_tiles, tiles_per_wg;   // tiles of all octaves; consecutive tiles one workgroup walks
     float th;
     int border;            // int(mrSize)
     int32_t* overflow;
@@ -74,156 +79,223 @@ __device__ __forceinline__ float hessian_at(const float* __restrict__ X, int ty,
     return fmaxf(r - th, 0.0f);
 }
 
-// NL = levels per octave = nLevels + 2 (5 for the reference's default nlevels = 3; 3..8 are instantiated)
+// run-time level index into the per-octave sigma table held in registers (a select chain: no scratch array)
 template <int NL>
-__global__ __launch_bounds__(256) void hessian_nms_kernel(HessParams hp) {
+__device__ __forceinline__ float sigma_at(const float (&sg)[NL], int idx) {
+    float v = sg[0];
+#pragma unroll
+    for (int k = 1; k < NL; ++k) v = (idx == k) ? sg[k] : v;
+    return v;
+}
+
+// Uniform (scalar) state of one tile: its octave's geometry, level pointers, raw list and sigma tables.
+template <int NL>
+struct HessTile {
+    const float* levels; RawMax* raw; int32_t* raw_cnt;
+    int h, w, raw_cap, x0, y0;
+    float sigma[NL], sigma4[NL];
+};
+
+template <int NL>
+__device__ __forceinline__ void hess_tile_setup(const HessParams& hp, int flat_tile, HessTile<NL>& t) {
+    int oi = 0;
+    while (oi + 1 < hp.n_oct && flat_tile >= hp.oct[oi + 1].tile_begin) ++oi;      // uniform: scalar loads from the kernel arguments
+    t.h = hp.oct[oi].h; t.w = hp.oct[oi].w; t.raw_cap = hp.oct[oi].raw_cap;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) { t.sigma[l] = hp.oct[oi].sigma[l]; t.sigma4[l] = hp.oct[oi].sigma4[l]; }
+    const int tile = flat_tile - hp.oct[oi].tile_begin, tiles_x = hp.oct[oi].tiles_x;
+    t.x0 = (tile % tiles_x) * HT_X; t.y0 = (tile / tiles_x) * HT_Y;
+    t.levels = hp.oct[oi].levels + blockIdx.z * hp.levels_stride;
+    t.raw = hp.oct[oi].raw + blockIdx.z * hp.raw_stride;
+    t.raw_cnt = hp.oct[oi].raw_cnt + blockIdx.z * CNT_TOTAL;
+}
+
+#define HESS_NLD ((HX_H * HX_W + 255) / 256)
+// All NL x 6 loads of a thread are issued before the first one is consumed (the element -> pixel mapping is the same for every
+// level).  Written as load-then-store per element the compiler put s_waitcnt vmcnt(0) behind each load: 30 serialized HBM round
+// trips per thread, ~29 us per workgroup, 0.55 TB/s for the whole kernel.
+template <int NL>
+__device__ __forceinline__ void hess_tile_load(const HessTile<NL>& t, float (&tmp)[NL][HESS_NLD]) {
+    int goff[HESS_NLD];
+#pragma unroll
+    for (int k = 0; k < HESS_NLD; ++k) {
+        const int i = threadIdx.x + 256 * k;
+        const int ty = i / HX_W, tx = i - ty * HX_W;
+        int gy = t.y0 + ty - 2, gx = t.x0 + tx - 2;
+        gy = gy < 0 ? 0 : (gy >= t.h ? t.h - 1 : gy);   // replicate padding of the Hessian filters
+        gx = gx < 0 ? 0 : (gx >= t.w ? t.w - 1 : gx);
+        goff[k] = (i < HX_H * HX_W) ? gy * t.w + gx : 0;
+    }
+    const size_t lvl_stride = (size_t)t.h * t.w;
+#pragma unroll
+    for (int l = 0; l < NL; ++l)
+#pragma unroll
+        for (int k = 0; k < HESS_NLD; ++k) tmp[l][k] = t.levels[l * lvl_stride + goff[k]];
+}
+
+// NL = levels per octave = nLevels + 2 (5 for the reference's default nlevels = 3; 3..8 are instantiated).
+// A workgroup walks hp.tiles_per_wg consecutive tiles and requests the blurred levels of the NEXT tile (registers) right after the
+// current one's are in LDS, so the HBM round trip runs under the response / NMS / centroid work instead of in front of it
+// (PMC, 4K batch: SQ_WAIT_ANY 45 % of the wave cycles with one tile per workgroup and 3 workgroups per CU, 0.9 TB/s).
+template <int NL>
+__global__ __launch_bounds__(256, 3) void hessian_nms_kernel(HessParams hp) {
     // LDS: NL blurred tiles (20x68) + NL response tiles (18x67)
-    __shared__ __attribute__((aligned(16))) float X[NL][HX_H * HX_W];
-    __shared__ float Rr[NL][HR_H * HR_S];
+    __shared__ __attribute__((aligned(16))) float X[NL][HX_H * HX_S];
+    __shared__ __attribute__((aligned(16))) float Rr[NL][HR_H * HR_S];
     // Maxima found by this workgroup are staged and appended with ONE global atomic (a single contended counter retires
     // only ~90 atomics/us: per-candidate atomics cost 150 us on octave 0).  The staging list aliases the blurred tiles,
     // which are dead once the responses are in Rr: 51 KB of LDS -> 3 workgroups per CU instead of 2.
     RawMax* s_list = reinterpret_cast<RawMax*>(&X[0][0]);
-    static_assert(sizeof(RawMax) * HN_CAP <= sizeof(float) * NL * HX_H * HX_W, "staging list must fit in the tile area");
+    static_assert(sizeof(RawMax) * HN_CAP <= sizeof(float) * NL * HX_H * HX_S, "staging list must fit in the tile area");
+    // Maxima are sparse (~2 % of the pixels per level): the test runs on every pixel, but the 27-tap centroid only on the hits, which
+    // are first QUEUED in LDS (behind the staging list) and then worked off one per thread.  Computed inside the test loop, every
+    // wavefront with a single hit among its 64 lanes x 4 pixels x (NL - 2) levels walked the whole centroid code for it.
+    uint16_t* s_queue = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(&X[0][0]) + sizeof(RawMax) * HN_CAP);
+    static_assert(sizeof(RawMax) * HN_CAP + 2 * HT_X * HT_Y * (NL - 2) <= sizeof(float) * NL * HX_H * HX_S, "staging list + queue must fit in the tile area");
     __shared__ int s_n, s_base;
-    if (threadIdx.x == 0) s_n = 0;
-    int oi = 0;
-    while (oi + 1 < hp.n_oct && (int)blockIdx.x >= hp.oct[oi + 1].tile_begin) ++oi;      // uniform: scalar loads from the kernel arguments
-    struct {                                       // this tile's octave + the launch-wide fields, under the names the body uses
-        const float* levels; RawMax* raw; int32_t* raw_cnt; int32_t* overflow;
-        int h, w, raw_cap, border, precomputed;
-        float th;
-        float sigma[NL], sigma4[NL];
-    } p;
-    p.h = hp.oct[oi].h; p.w = hp.oct[oi].w; p.raw_cap = hp.oct[oi].raw_cap; p.border = hp.border; p.precomputed = hp.precomputed; p.th = hp.th;
-#pragma unroll
-    for (int l = 0; l < NL; ++l) { p.sigma[l] = hp.oct[oi].sigma[l]; p.sigma4[l] = hp.oct[oi].sigma4[l]; }
-    const int h = p.h, w = p.w;
-    const int tile = (int)blockIdx.x - hp.oct[oi].tile_begin, tiles_x = hp.oct[oi].tiles_x;
-    const int x0 = (tile % tiles_x) * HT_X, y0 = (tile / tiles_x) * HT_Y;
-    const size_t lvl_stride = (size_t)h * w;
-    p.levels = hp.oct[oi].levels + blockIdx.z * hp.levels_stride;
-    p.raw = hp.oct[oi].raw + blockIdx.z * hp.raw_stride;
-    p.raw_cnt = hp.oct[oi].raw_cnt + blockIdx.z * CNT_TOTAL;
-    p.overflow = hp.overflow + blockIdx.z * CNT_TOTAL;
-    if (!p.precomputed) {
-        // All NL x 6 loads of a thread are issued before the first one is consumed (the element -> pixel mapping is the same
-        // for every level).  Written as load-then-store per element the compiler put s_waitcnt vmcnt(0) behind each load:
-        // 30 serialized HBM round trips per thread, ~29 us per workgroup, 0.55 TB/s for the whole kernel.
-        constexpr int NLD = (HX_H * HX_W + 255) / 256;
-        int goff[NLD];
-#pragma unroll
-        for (int k = 0; k < NLD; ++k) {
-            const int i = threadIdx.x + 256 * k;
-            const int ty = i / HX_W, tx = i - ty * HX_W;
-            int gy = y0 + ty - 2, gx = x0 + tx - 2;
-            gy = gy < 0 ? 0 : (gy >= h ? h - 1 : gy);   // replicate padding of the Hessian filters
-            gx = gx < 0 ? 0 : (gx >= w ? w - 1 : gx);
-            goff[k] = (i < HX_H * HX_W) ? gy * w + gx : 0;
-        }
-        float tmp[NL][NLD];
-#pragma unroll
-        for (int l = 0; l < NL; ++l)
-#pragma unroll
-            for (int k = 0; k < NLD; ++k) tmp[l][k] = p.levels[l * lvl_stride + goff[k]];
-#pragma unroll
-        for (int l = 0; l < NL; ++l)
-#pragma unroll
-            for (int k = 0; k < NLD; ++k) {
-                const int i = threadIdx.x + 256 * k;
-                if (i < HX_H * HX_W) X[l][i] = tmp[l][k];
-            }
+    const int first = blockIdx.x * hp.tiles_per_wg;
+    const int last = min(first + hp.tiles_per_wg, hp.n_tiles);
+    int32_t* const overflow = hp.overflow + blockIdx.z * CNT_TOTAL;
+    float tmp[NL][HESS_NLD];
+    if (!hp.precomputed) {
+        HessTile<NL> nxt;
+        hess_tile_setup<NL>(hp, first, nxt);
+        hess_tile_load<NL>(nxt, tmp);
     }
-    __syncthreads();
-    // Responses: one thread = 5 consecutive pixels of one response row (18 rows x 14 segments = 252 threads), all NL levels.
-    // The 3 x 7 window of the blurred tile is read once into registers (21 LDS reads for 5 responses instead of 45); every
-    // response is the same expression tree as hessian_at().
-    if (p.precomputed) {
-        for (int l = 0; l < NL; ++l)
-            for (int i = threadIdx.x; i < HR_H * HR_W; i += 256) {
-                const int ry = i / HR_W, rx = i - ry * HR_W;
-                const int gy = y0 + ry - 1, gx = x0 + rx - 1;
-                float r = -INFINITY;                   // outside the image: -inf for max_pool3d padding
-                if (gy >= 0 && gy < h && gx >= 0 && gx < w) r = fmaxf(p.levels[l * lvl_stride + (size_t)gy * w + gx] - p.th, 0.0f);   // SparseImgRepresenter.py:77
-                Rr[l][ry * HR_S + rx] = r;
-            }
-    } else if (threadIdx.x < HR_H * 14) {
-        const int ry = threadIdx.x / 14, rx0 = (threadIdx.x - ry * 14) * 5;
-        const int gy = y0 + ry - 1;
-        const bool row_in = gy >= 0 && gy < h;
+    for (int ft = first; ft < last; ++ft) {
+        HessTile<NL> p;                                 // this tile (uniform: scalar registers)
+        hess_tile_setup<NL>(hp, ft, p);
+        if (ft > first) __syncthreads();               // the previous tile's staging list / queue (alias X) and Rr are consumed
+        if (threadIdx.x == 0) s_n = 0;
+        if (!hp.precomputed) {
 #pragma unroll
-        for (int l = 0; l < NL; ++l) {
-            const float s4 = p.sigma4[l];
-            const float* xr = &X[l][ry * HX_W + rx0];  // top-left of the window: response (ry, rx) is centred on X (ry + 1, rx + 1)
-            float u[7], c[7], d[7];
+            for (int l = 0; l < NL; ++l)
 #pragma unroll
-            for (int k = 0; k < 7; ++k) {
-                const bool ok = rx0 + k < HX_W;
-                u[k] = ok ? xr[k] : 0.0f; c[k] = ok ? xr[HX_W + k] : 0.0f; d[k] = ok ? xr[2 * HX_W + k] : 0.0f;
-            }
+                for (int k = 0; k < HESS_NLD; ++k) {
+                    const int i = threadIdx.x + 256 * k;
+                    if (i < HX_H * HX_W) X[l][(i / HX_W) * HX_S + (i % HX_W)] = tmp[l][k];
+                }
+        }
+        __syncthreads();
+        if (ft + 1 < last && !hp.precomputed) {
+            HessTile<NL> nxt;                           // only its geometry and level pointer live on, inside the addresses of the loads
+            hess_tile_setup<NL>(hp, ft + 1, nxt);
+            hess_tile_load<NL>(nxt, tmp);               // in flight until the next iteration's LDS stores
+        }
+        const int h = p.h, w = p.w, x0 = p.x0, y0 = p.y0;
+        const size_t lvl_stride = (size_t)h * w;
+        // Responses: one thread = 5 consecutive pixels of one response row (18 rows x 14 segments = 252 threads), all NL levels.
+        // The 3 x 7 window of the blurred tile is read once into registers (21 LDS reads for 5 responses instead of 45); every
+        // response is the same expression tree as hessian_at().
+        if (hp.precomputed) {
+            for (int l = 0; l < NL; ++l)
+                for (int i = threadIdx.x; i < HR_H * HR_W; i += 256) {
+                    const int ry = i / HR_W, rx = i - ry * HR_W;
+                    const int gy = y0 + ry - 1, gx = x0 + rx - 1;
+                    float r = -INFINITY;                   // outside the image: -inf for max_pool3d padding
+                    if (gy >= 0 && gy < h && gx >= 0 && gx < w) r = fmaxf(p.levels[l * lvl_stride + (size_t)gy * w + gx] - hp.th, 0.0f);   // SparseImgRepresenter.py:77
+                    Rr[l][ry * HR_S + rx] = r;
+                }
+        } else if (threadIdx.x < HR_H * 14) {
+            const int ry = threadIdx.x / 14, rx0 = (threadIdx.x - ry * 14) * 5;
+            const int gy = y0 + ry - 1;
+            const bool row_in = gy >= 0 && gy < h;
 #pragma unroll
-            for (int k = 0; k < 5; ++k) {
-                const int rx = rx0 + k;
-                if (rx >= HR_W) break;
-                const int gx = x0 + rx - 1;
-                const float cc = c[k + 1];
-                const float gxx = (c[k] - 2.0f * cc) + c[k + 2];
-                const float gyy = (u[k + 1] - 2.0f * cc) + d[k + 1];
-                const float gx_up = 0.5f * u[k] - 0.5f * u[k + 2];
-                const float gx_dn = 0.5f * d[k] - 0.5f * d[k + 2];
-                const float gxy = 0.5f * gx_up - 0.5f * gx_dn;
-                const float t1 = gxx * gyy;
-                const float t2 = gxy * gxy;
-                const float r = fmaxf(fabsf(t1 - t2) * s4 - p.th, 0.0f);
-                Rr[l][ry * HR_S + rx] = (row_in && gx >= 0 && gx < w) ? r : -INFINITY;   // outside the image: -inf (max_pool3d padding)
+            for (int l = 0; l < NL; ++l) {
+                const float s4 = p.sigma4[l];
+                const float* xr = &X[l][ry * HX_S + rx0];  // top-left of the window: response (ry, rx) is centred on X (ry + 1, rx + 1)
+                float u[7], c[7], d[7];
+#pragma unroll
+                for (int k = 0; k < 7; ++k) {
+                    const bool ok = rx0 + k < HX_W;
+                    u[k] = ok ? xr[k] : 0.0f; c[k] = ok ? xr[HX_S + k] : 0.0f; d[k] = ok ? xr[2 * HX_S + k] : 0.0f;
+                }
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const int rx = rx0 + k;
+                    if (rx >= HR_W) break;
+                    const int gx = x0 + rx - 1;
+                    const float cc = c[k + 1];
+                    const float gxx = (c[k] - 2.0f * cc) + c[k + 2];
+                    const float gyy = (u[k + 1] - 2.0f * cc) + d[k + 1];
+                    const float gx_up = 0.5f * u[k] - 0.5f * u[k + 2];
+                    const float gx_dn = 0.5f * d[k] - 0.5f * d[k + 2];
+                    const float gxy = 0.5f * gx_up - 0.5f * gx_dn;
+                    const float t1 = gxx * gyy;
+                    const float t2 = gxy * gxy;
+                    const float r = fmaxf(fabsf(t1 - t2) * s4 - hp.th, 0.0f);
+                    Rr[l][ry * HR_S + rx] = (row_in && gx >= 0 && gx < w) ? r : -INFINITY;   // outside the image: -inf (max_pool3d padding)
+                }
             }
         }
-    }
-    __syncthreads();
-    const bool border_ok = (p.border < w) && (p.border < h);
-    // NMS: each thread owns 4 pixels of one row.  Per level the 3 x 6 response window is read once; the three-row column
-    // maxima are shared by the 4 pixels and by the NL - 2 detection levels (max is order-independent: same values).
-    const int ty = threadIdx.x >> 4, txb = (threadIdx.x & 15) * 4;
-    const int gy = y0 + ty;
-    float cm[NL][6], ctr[NL][4];
+        __syncthreads();
+        {
+            const bool border_ok = (hp.border < w) && (hp.border < h);
+            // NMS: each thread owns 4 pixels of one row.  Per level the 3 x 6 response window is read once; the three-row column
+            // maxima are shared by the 4 pixels and by the NL - 2 detection levels (max is order-independent: same values).
+            const int ty = threadIdx.x >> 4, txb = (threadIdx.x & 15) * 4;
+            const int gy = y0 + ty;
+            float cm[NL][6], ctr[NL][4];
 #pragma unroll
-    for (int l = 0; l < NL; ++l) {
-        const float* r = &Rr[l][ty * HR_S + txb];      // top-left of the window of pixel txb (response tile has a 1-px halo)
+            for (int l = 0; l < NL; ++l) {
+                // top-left of the window of pixel txb (response tile has a 1-px halo); txb is a multiple of 4 and the rows are 16-byte
+                // aligned: one 16-byte + one 8-byte read per row (conflict-free: the 16 lanes of a row read 64 consecutive floats)
+                // instead of six 4-byte reads at a 4-float lane stride (8 of 32 banks: 2..4-way conflicts, 37 % of the LDS cycles)
+                const float* r = &Rr[l][ty * HR_S + txb];
+                float win[3][6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const float a0 = r[k], a1 = r[HR_S + k], a2 = r[2 * HR_S + k];
-            cm[l][k] = fmaxf(fmaxf(a0, a1), a2);
-            if (k >= 1 && k <= 4) ctr[l][k - 1] = a1;
+                for (int dy = 0; dy < 3; ++dy) {
+                    const float4 q4 = *reinterpret_cast<const float4*>(r + dy * HR_S);
+                    const float2 q2 = *reinterpret_cast<const float2*>(r + dy * HR_S + 4);
+                    win[dy][0] = q4.x; win[dy][1] = q4.y; win[dy][2] = q4.z; win[dy][3] = q4.w; win[dy][4] = q2.x; win[dy][5] = q2.y;
+                }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) {
+                    cm[l][k] = fmaxf(fmaxf(win[0][k], win[1][k]), win[2][k]);
+                    if (k >= 1 && k <= 4) ctr[l][k - 1] = win[1][k];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int tx = txb + q, gx = x0 + tx;
+                if (gx >= w || gy >= h) break;
+                const bool in_border = !border_ok || gy < hp.border || gy >= h - hp.border || gx < hp.border || gx >= w - hp.border;
+                if (in_border) continue;                      // zero_response_at_border -> nms value 0 -> never a candidate
+                float m5[NL];
+#pragma unroll
+                for (int l = 0; l < NL; ++l) m5[l] = fmaxf(fmaxf(cm[l][q], cm[l][q + 1]), cm[l][q + 2]);
+#pragma unroll
+                for (int l = 1; l <= NL - 2; ++l) {
+                    const float c = ctr[l][q];
+                    const float M = fmaxf(fmaxf(m5[l - 1], m5[l]), m5[l + 1]);
+                    const float d = c - M;
+                    const float e = d + 1e-5f;
+                    if (!(e > 0.0f) || c == 0.0f) continue;    // keep * x == 0 -> contributes nothing anywhere
+                    s_queue[atomicAdd(&s_n, 1)] = (uint16_t)((l << 10) | (ty << 6) | tx);
+                }
+            }
         }
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int tx = txb + q, gx = x0 + tx;
-        if (gx >= w || gy >= h) break;
-        const bool in_border = !border_ok || gy < p.border || gy >= h - p.border || gx < p.border || gx >= w - p.border;
-        if (in_border) continue;                      // zero_response_at_border -> nms value 0 -> never a candidate
-        float m5[NL];
-#pragma unroll
-        for (int l = 0; l < NL; ++l) m5[l] = fmaxf(fmaxf(cm[l][q], cm[l][q + 1]), cm[l][q + 2]);
-#pragma unroll
-        for (int l = 1; l <= NL - 2; ++l) {
-            const float c = ctr[l][q];
-            const float M = fmaxf(fmaxf(m5[l - 1], m5[l]), m5[l + 1]);
-            const float d = c - M;
-            const float e = d + 1e-5f;
-            if (!(e > 0.0f) || c == 0.0f) continue;    // keep * x == 0 -> contributes nothing anywhere
+        __syncthreads();
+        const int n_q = s_n;
+        if (n_q == 0) continue;                               // uniform
+        int n_lvl1 = 0;
+        for (int e = threadIdx.x; e < n_q; e += 256) {
+            const int code = s_queue[e];
+            const int l = code >> 10, qy = (code >> 6) & 15, qx = code & 63;
+            const int py = y0 + qy, px = x0 + qx;
+            const float c = Rr[l][(qy + 1) * HR_S + qx + 1];
             // 27-tap centroid on the UNMASKED responses, zero padding (HandCraftedModules.py:279)
             float ns = 0.f, ny = 0.f, nx = 0.f, den = 0.f;
 #pragma unroll
             for (int dl = 0; dl < 3; ++dl) {
-                const float sg = p.sigma[l - 1 + dl];
+                const float sg = sigma_at<NL>(p.sigma, l - 1 + dl);
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     const float oy = (ky == 0) ? -0.5f : (ky == 1 ? 0.5f : 1.5f);
 #pragma unroll
                     for (int kx = 0; kx < 3; ++kx) {
                         const float ox = (kx == 0) ? -0.5f : (kx == 1 ? 0.5f : 1.5f);
-                        float r = Rr[l - 1 + dl][(ty + ky) * HR_S + tx + kx];
+                        float r = Rr[l - 1 + dl][(qy + ky) * HR_S + qx + kx];
                         if (r == -INFINITY) r = 0.0f;  // conv2d zero padding
                         ns = fmaf(r, sg, ns);
                         ny = fmaf(r, oy, ny);
@@ -234,35 +306,36 @@ __global__ __launch_bounds__(256) void hessian_nms_kernel(HessParams hp) {
             }
             const float dd = den + 1e-8f;
             float cs = ns / dd, cy = ny / dd, cx = nx / dd;
-            cy = cy + (float)gy;
-            cx = cx + (float)gx;
+            cy = cy + (float)py;
+            cx = cx + (float)px;
             const float msz = (float)(h < w ? h : w);
             RawMax rm;
-            rm.pix = gy * w + gx;
+            rm.pix = py * w + px;
             rm.lvl = l;
             rm.val = c;
             rm.s = cs / msz;
             rm.y = cy / (float)h;
             rm.x = cx / (float)w;
-            const int ls = atomicAdd(&s_n, 1);
-            if (ls < HN_CAP) {
-                s_list[ls] = rm;
+            n_lvl1 += (l == 1) ? 1 : 0;
+            if (e < HN_CAP) {
+                s_list[e] = rm;
             } else {                                   // staging full (pathological tile): direct append
                 const int slot = atomicAdd(p.raw_cnt, 1);
                 if (slot < p.raw_cap) p.raw[slot] = rm;
-                else atomicOr(p.overflow, 1);
+                else atomicOr(overflow, 1);
             }
         }
-    }
-    __syncthreads();
-    const int n_loc = s_n < HN_CAP ? s_n : HN_CAP;
-    if (n_loc == 0) return;
-    if (threadIdx.x == 0) s_base = atomicAdd(p.raw_cnt, n_loc);
-    __syncthreads();
-    const int base = s_base;
-    for (int i = threadIdx.x; i < n_loc; i += 256) {
-        if (base + i < p.raw_cap) p.raw[base + i] = s_list[i];
-        else atomicOr(p.overflow, 1);
+        // positives of detection level 1 = its raw maxima (octaveMap is still all zero: v = val > 0): the level's counting pass is free
+        if (n_lvl1) atomicAdd(p.raw_cnt + (CNT_POS0 - CNT_RAW0), n_lvl1);
+        __syncthreads();
+        const int n_loc = n_q < HN_CAP ? n_q : HN_CAP;
+        if (threadIdx.x == 0) s_base = atomicAdd(p.raw_cnt, n_loc);
+        __syncthreads();
+        const int base = s_base;
+        for (int i = threadIdx.x; i < n_loc; i += 256) {
+            if (base + i < p.raw_cap) p.raw[base + i] = s_list[i];
+            else atomicOr(overflow, 1);
+        }
     }
 }
 
@@ -318,6 +391,7 @@ __global__ __launch_bounds__(256) void level_resolve_kernel(ResolveParams p, int
     int n = cnt[CNT_RAW0 + o];
     if (n > p.raw_cap[o]) n = p.raw_cap[o];
     const int lane = threadIdx.x & 63;
+    __shared__ int s_wcnt[4], s_wbase;
     int32_t* pos = cnt + CNT_POS0 + (l - 1) * AFFNET_MAX_OCTAVES + o;
     if (mode == 1 && *pos <= 1) return;                 // HandCraftedModules.py:252-254: level skipped, octaveMap unchanged
     uint8_t* omap = p.omap[o] + img * p.map_stride;
@@ -341,12 +415,19 @@ __global__ __launch_bounds__(256) void level_resolve_kernel(ResolveParams p, int
             omap[r.pix] = (uint8_t)(long long)sum;     // float -> int64 -> uint8 wrap, as torch's CPU .byte()
             emit = v != 0.0f;
         }
-        const unsigned long long bal = __ballot(emit); // one global atomic per wavefront instead of one per candidate
-        int wbase = 0;
-        if (bal) {
-            if (lane == 0) wbase = atomicAdd(&cnt[CNT_CAND], __popcll(bal));
-            wbase = __shfl(wbase, 0, 64);
+        // one global atomic per WORKGROUP iteration (the image's candidate counter is a single address: ~90 atomics / us; one per
+        // wavefront made the apply passes of a 4K batch atomic-bound)
+        const unsigned long long bal = __ballot(emit);
+        if (lane == 0) s_wcnt[threadIdx.x >> 6] = __popcll(bal);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+            s_wbase = tot ? atomicAdd(&cnt[CNT_CAND], tot) : 0;
         }
+        __syncthreads();
+        int wbase = s_wbase;
+        for (int wv = 0; wv < (int)(threadIdx.x >> 6); ++wv) wbase += s_wcnt[wv];
+        __syncthreads();                                // s_wcnt / s_wbase are rewritten by the next iteration
         if (emit) {
             const int slot = wbase + __popcll(bal & ((1ull << lane) - 1ull));
             if (slot < p.cand_cap) {
@@ -823,7 +904,11 @@ static int detect_candidates(affnet_ctx* ctx, const float* d_responses, AffZeroS
         rp.raw[o] = ho.raw; rp.omap[o] = ctx->omap + g.map_off; rp.raw_cap[o] = g.raw_cap;
     }
     {
-        const dim3 hgrid(n_tiles, 1, B);
+        // big grids: 4 tiles per workgroup (next tile's loads under this tile's work); small grids: one tile each (latency)
+        hp.n_tiles = n_tiles;
+        hp.tiles_per_wg = ((long long)n_tiles * B >= 8192) ? 2 : 1;
+        if (const char* e = getenv("AFFNET_HESS_TPW")) { const int v = atoi(e); if (v >= 1 && v <= 64) hp.tiles_per_wg = v; }   // tuning aid
+        const dim3 hgrid(aff_cdiv(n_tiles, hp.tiles_per_wg), 1, B);
         switch (NLv) {
             case 3: hipLaunchKernelGGL(hessian_nms_kernel<3>, hgrid, dim3(256), 0, st, hp); break;
             case 4: hipLaunchKernelGGL(hessian_nms_kernel<4>, hgrid, dim3(256), 0, st, hp); break;
@@ -840,10 +925,12 @@ static int detect_candidates(affnet_ctx* ctx, const float* d_responses, AffZeroS
     {
         int max_cap = 0;
         for (int o = 0; o < c.n_octaves; ++o) max_cap = ctx->oct[o].raw_cap > max_cap ? ctx->oct[o].raw_cap : max_cap;
+        // up to 128 workgroups per (octave, image), grid-stride over the raw list (the count is on the device: workgroups past the end
+        // leave at once).  (A cap of 32 left octave 0 of a 4K batch to 8 x 32 workgroups: 42 us per image for the five passes.)
         const int rb = aff_cdiv(max_cap, 256);
-        const dim3 rgrid(rb < 32 ? rb : 32, c.n_octaves, B);
+        const dim3 rgrid(rb < 128 ? rb : 128, c.n_octaves, B);
         for (int l = 1; l <= rp.n_detect_levels; ++l) {
-            hipLaunchKernelGGL(level_resolve_kernel, rgrid, dim3(256), 0, st, rp, l, 0);
+            if (l > 1) hipLaunchKernelGGL(level_resolve_kernel, rgrid, dim3(256), 0, st, rp, l, 0);   // level 1 was counted by hessian_nms_kernel
             hipLaunchKernelGGL(level_resolve_kernel, rgrid, dim3(256), 0, st, rp, l, 1);
         }
     }
