@@ -34,15 +34,15 @@ class OnePassSIR(nn.Module):
         else:
             self.th = 0
         self.nlevels, self.num_Baum_iters, self.init_sigma = nlevels, num_Baum_iters, init_sigma
-        if RespNet is not None:
-            raise NotImplementedError("OnePassSIR mirror: custom RespNet slot not wired (ScaleSpaceAffinePatchExtractor supports it)")
+        self.RespNet = RespNet       # None = the built-in Hessian response; otherwise any callable RespNet(level (1,1,h,w), sigma) ->
+                                     # (1,1,h,w) (OnePassSIR.py:24,38-41,71), evaluated per pyramid level by this mirror
         if AffNet is None:
             raise ValueError("OnePassSIR needs a dense AffNet (AffNetFastFullConv or any image -> (1,4,h,w) callable); the reference's default "
                              "AffineShapeEstimator is a per-patch module and fails in OnePassSIR.py:69 as well")
         self.AffNet = AffNet
-        self.OriNet = OriNet if OriNet is not None else OrientationDetector(patch_size=19)       # OnePassSIR.py:44-47
-        if not isinstance(self.OriNet, (_HipPatchNet, _HipHandCrafted)):
-            raise NotImplementedError("OnePassSIR mirror: OriNet must be affnet_amd.OriNetFast or the default OrientationDetector")
+        # OnePassSIR.py:44-47; a foreign OriNet (any callable patches (n,1,PS,PS) -> angles (n,) or rotations (n,2,2) with a .PS
+        # attribute, OnePassSIR.py:117-130) runs between the stages (_staged_orientation)
+        self.OriNet = OriNet if OriNet is not None else OrientationDetector(patch_size=19)
         self.scale_pyr = self.sigmas = self.pix_dists = self.aff_maps = None
         self.max_keep, self.raw_div = 16384, 4
         self._ctx = self._ctx_key = None
@@ -71,17 +71,9 @@ class OnePassSIR(nn.Module):
         ids = torch.empty(B, F, 3, dtype=torch.int32, device=dev)
         count = torch.zeros(B, dtype=torch.int32, device=dev)
         dsc = torch.empty(B, F, 128, dtype=torch.float32, device=dev) if desc is not None else None
-        if isinstance(self.AffNet, AffNetFastFullConv):
-            check(lib.affnet_detect_image_onepass(ctx.handle, ptr(self.AffNet.packed_weights(dev)), ptr(img), st), ctx.handle,
-                  "affnet_detect_image_onepass")
-        else:                       # foreign dense AffNet slot: any callable image -> (1,4,h,w), evaluated per octave (OnePassSIR.py:69)
-            check(lib.affnet_pyramid_build(ctx.handle, ptr(img), st), ctx.handle, "affnet_pyramid_build")
-            with torch.no_grad():
-                for b in range(B):
-                    pyr, maps = ctx.pyramid_views(b), ctx.affmap_views(b)
-                    for o in range(len(pyr)):
-                        maps[o].copy_(self.AffNet(pyr[o][0]).to(dev, torch.float32))
-            check(lib.affnet_detect_image_onepass(ctx.handle, None, None, st), ctx.handle, "affnet_detect_image_onepass")
+        self._detect(ctx, img, st)
+        if do_ori and not isinstance(self.OriNet, (_HipPatchNet, _HipHandCrafted)):
+            raise NotImplementedError("enqueue() is the no-synchronisation path: a foreign OriNet runs Python between the stages - use run() / forward()")
         nets = _lib.Nets()
         if do_ori:
             if isinstance(self.OriNet, _HipHandCrafted):
@@ -91,13 +83,87 @@ class OnePassSIR(nn.Module):
         nets.d_hardnet = desc.packed_weights(dev).data_ptr() if desc is not None else None
         check(lib.affnet_describe_detected(ctx.handle, C.byref(nets), int(bool(do_ori)), ptr(lafs), ptr(resp), ptr(ids), ptr(dsc), ptr(count), st),
               ctx.handle, "affnet_describe_detected")
-        return {"LAFs": lafs, "responses": resp, "ids": ids, "descriptors": dsc, "count": count, "_img": img}
+        return {"LAFs": lafs, "responses": resp, "ids": ids, "descriptors": dsc, "count": count, "overflow": ctx.counter_view(0), "_img": img}
+
+    def _detect(self, ctx, img, st):
+        """Detector half into the context's internal list: pyramid, dense affine maps (native net on the device, or a foreign dense
+        AffNet evaluated per octave, OnePassSIR.py:69), response maps of a custom RespNet slot if any, per-level top-k + boundary test."""
+        dev, B = img.device, img.size(0)
+        native = isinstance(self.AffNet, AffNetFastFullConv)
+        packed = ptr(self.AffNet.packed_weights(dev)) if native else None
+        if native and self.RespNet is None:
+            check(lib.affnet_detect_image_onepass(ctx.handle, packed, ptr(img), st), ctx.handle, "affnet_detect_image_onepass")
+            return
+        check(lib.affnet_pyramid_build(ctx.handle, ptr(img), st), ctx.handle, "affnet_pyramid_build")
+        if not native:              # foreign dense AffNet slot: any callable image -> (1,4,h,w)
+            with torch.no_grad():
+                for b in range(B):
+                    pyr, maps = ctx.pyramid_views(b), ctx.affmap_views(b)
+                    for o in range(len(pyr)):
+                        maps[o].copy_(self.AffNet(pyr[o][0]).to(dev, torch.float32))
+        if self.RespNet is None:
+            check(lib.affnet_detect_image_onepass(ctx.handle, None, None, st), ctx.handle, "affnet_detect_image_onepass")
+            return
+        stride = lib.affnet_pyramid_image_stride(ctx.handle)
+        base = lib.affnet_pyramid_level_offset(ctx.handle, 0, 0)
+        rmaps = torch.zeros(B * stride, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for b in range(B):
+                pyr = ctx.pyramid_views(b)
+                for o, (h, w) in enumerate(ctx.plan.sizes):
+                    for l in range(ctx.plan.levels_per_octave):
+                        off = b * stride + lib.affnet_pyramid_level_offset(ctx.handle, o, l) - base
+                        rmaps[off:off + h * w].copy_(self.RespNet(pyr[o][l], ctx.plan.sigmas[o][l]).reshape(-1).to(dev, torch.float32))
+        check(lib.affnet_detect_image_onepass_responses(ctx.handle, packed, ptr(rmaps), st), ctx.handle, "affnet_detect_image_onepass_responses")
+        self._rmaps = rmaps         # stays alive until the kernels that read it have run
+
+    def _staged_orientation(self, x, desc):
+        """Foreign OriNet slot (OnePassSIR.py:117-130 getOrientation with any callable): detector on the device, the slot called on the
+        patch tensor, rotation / denormalisation / descriptors by the stage kernels the fused path is made of."""
+        ctx = self._context(x)
+        dev, st = x.device, engine.stream_of(x.device)
+        img = x.contiguous().float()
+        P = ctx.cap_pre
+        self._detect(ctx, img, st)
+        resp = torch.empty(P, dtype=torch.float32, device=dev)
+        lafs = torch.empty(P, 2, 3, dtype=torch.float32, device=dev)
+        ids = torch.empty(P, 3, dtype=torch.int32, device=dev)
+        cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+        check(lib.affnet_detected_list(ctx.handle, ptr(resp), ptr(lafs), ptr(ids), ptr(cnt), st), ctx.handle, "affnet_detected_list")
+        ctx.read_counts()
+        n = int(cnt.item())
+        PS = self.OriNet.PS
+        patches = torch.empty(n, 1, PS, PS, dtype=torch.float32, device=dev)
+        check(lib.affnet_pyr_grid_sample(ctx.handle, ptr(lafs), ptr(ids), ptr(cnt), n, PS, ptr(patches), st), ctx.handle, "affnet_pyr_grid_sample")
+        with torch.no_grad():
+            ang = self.OriNet(patches)
+        if ang.dim() <= 2:          # angles -> rotation matrices (LAF.py:306-311)
+            c, s = torch.cos(ang).view(-1, 1, 1), torch.sin(ang).view(-1, 1, 1)
+            ang = torch.cat([torch.cat([c, s], 2), torch.cat([-s, c], 2)], 1)
+        R = ang.to(dev, torch.float32).contiguous()
+        check(lib.affnet_apply_rotation(ctx.handle, ptr(lafs), ptr(R), ptr(cnt), n, st), ctx.handle, "affnet_apply_rotation")
+        out = torch.empty_like(lafs)
+        check(lib.affnet_scale_lafs(ctx.handle, ptr(lafs), ptr(out), ptr(cnt), P, x.size(3), x.size(2), 0, st), ctx.handle, "affnet_scale_lafs")
+        dsc = None
+        if desc is not None:
+            lids = torch.empty(n, 3, dtype=torch.int32, device=dev)
+            norm = torch.empty(n, 2, 3, dtype=torch.float32, device=dev)
+            dp = torch.empty(n, 1, 32, 32, dtype=torch.float32, device=dev)
+            check(lib.affnet_level_select(ctx.handle, ptr(out), None, n, 32, ptr(lids), ptr(norm), st), ctx.handle, "affnet_level_select")
+            check(lib.affnet_pyr_grid_sample(ctx.handle, ptr(norm), ptr(lids), None, n, 32, ptr(dp), st), ctx.handle, "affnet_pyr_grid_sample")
+            with torch.no_grad():
+                dsc = desc(dp)
+        return {"LAFs": out[:n].unsqueeze(0), "responses": resp[:n].unsqueeze(0), "ids": ids[:n].unsqueeze(0),
+                "descriptors": None if dsc is None else dsc.unsqueeze(0), "count": cnt}
 
     def run(self, x, do_ori=True, desc=None):
         """x (1,1,H,W) -> dict(LAFs px (N,2,3), responses (N,), ids (N,3) = (octave, level - 1, pixel), descriptors (N,128) | None)."""
         if x.size(0) != 1:
             raise ValueError("run() / forward() are batch-size-1 like the reference; use enqueue() for batches")
-        r = self.enqueue(x, do_ori=do_ori, desc=desc)
+        if do_ori and not isinstance(self.OriNet, (_HipPatchNet, _HipHandCrafted)):
+            r = self._staged_orientation(x, desc)
+        else:
+            r = self.enqueue(x, do_ori=do_ori, desc=desc)
         ctx = self._ctx
         self.scale_pyr = ctx.pyramid_views()
         self.sigmas = [list(s) for s in ctx.plan.sigmas]

@@ -228,17 +228,28 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
             check(lib.affnet_detect(ctx.handle, ptr(resp), ptr(lafs), ptr(ids), ptr(cnt), st), ctx.handle, "affnet_detect")
         n = int(cnt.item())
         ctx.read_counts()                   # raises AffnetEmptyError ("no keypoints detected") / on capacity overflow
-        if self.num_Baum_iters > 1:
-            raise NotImplementedError("num_Baum_iters > 1 with a foreign AffNet slot: use the native AffNetFast (fused path)")
         if self.num_Baum_iters > 0:
             PS = self.AffNet.PS
             patches = torch.empty(n, 1, PS, PS, dtype=torch.float32, device=dev)
-            check(lib.affnet_pyr_grid_sample(ctx.handle, ptr(lafs), ptr(ids), ptr(cnt), n, PS, ptr(patches), st), ctx.handle,
-                  "affnet_pyr_grid_sample")
-            with torch.no_grad():
-                A = torch.cat([self.AffNet(patches[s:s + 256], {}) for s in range(0, n, 256)], 0)   # Utils.py:37-66
-            Afull = torch.zeros(P, 2, 2, dtype=torch.float32, device=dev)
-            Afull[:n] = A.to(dev, torch.float32)
+
+            def shape_pass(frames):             # one evaluation of the slot on patches cut along `frames` (P,2,3), rows < n
+                check(lib.affnet_pyr_grid_sample(ctx.handle, ptr(frames), ptr(ids), ptr(cnt), n, PS, ptr(patches), st), ctx.handle,
+                      "affnet_pyr_grid_sample")
+                with torch.no_grad():
+                    a = torch.cat([self.AffNet(patches[s:s + 256], {}) for s in range(0, n, 256)], 0)   # Utils.py:37-66
+                full = torch.zeros(P, 2, 2, dtype=torch.float32, device=dev)
+                full[:n] = a.to(dev, torch.float32)
+                return full
+            A = shape_pass(lafs)                # base_A = bmm(A_0, I) = A_0
+            if self.num_Baum_iters > 1:
+                # SparseImgRepresenter.py:127-146: patches re-extracted along [base_A * LAF | centre], base_A = A_i * base_A - the steps
+                # the fused path runs between its shape passes (affnet_shape_iterate), here around a foreign slot
+                frames = torch.empty(P, 2, 3, dtype=torch.float32, device=dev)
+                for _ in range(1, self.num_Baum_iters):
+                    check(lib.affnet_shape_iterate(ctx.handle, None, ptr(A), ptr(lafs), ptr(cnt), 0, ptr(frames), st), ctx.handle, "affnet_shape_iterate")
+                    Ai = shape_pass(frames)
+                    check(lib.affnet_shape_iterate(ctx.handle, ptr(Ai), ptr(A), ptr(lafs), ptr(cnt), 1, ptr(frames), st), ctx.handle, "affnet_shape_iterate")
+            Afull = A
             r2 = torch.empty(F, dtype=torch.float32, device=dev)
             l2 = torch.empty(F, 2, 3, dtype=torch.float32, device=dev)
             i2 = torch.empty(F, 3, dtype=torch.int32, device=dev)
@@ -311,7 +322,13 @@ class CapturedPath(object):
         self.out = {"LAFs": torch.empty(B, F, 2, 3, dtype=torch.float32, device=dev), "responses": torch.empty(B, F, dtype=torch.float32, device=dev),
                     "ids": torch.empty(B, F, 3, dtype=torch.int32, device=dev), "count": torch.zeros(B, dtype=torch.int32, device=dev),
                     "descriptors": torch.empty(B, F, 128, dtype=torch.float32, device=dev) if desc is not None else None}
-        self._nets = det._nets(dev, do_ori, desc)              # packed weight tensors are owned (and kept alive) by the net modules
+        self._nets = det._nets(dev, do_ori, desc)
+        # The graph bakes in the ADDRESSES of the packed weight blobs: hold references (a net whose weights change later builds a new
+        # blob and would free the captured one under the graph) and remember what they were built from, so that launch() can refuse to
+        # replay stale weights instead of silently doing so.
+        self._mods = [m for m in (det.AffNet, det.OriNet if do_ori else None, desc) if m is not None and hasattr(m, "packed_weights")]
+        self._blobs = [m.packed_weights(dev) for m in self._mods]
+        self._stamps = [m._weights_stamp() for m in self._mods]
         self._stream = torch.cuda.Stream(device=dev)           # capture needs an explicit stream; nothing executes on it
         torch.cuda.synchronize(dev)
         o = self.out
@@ -323,12 +340,19 @@ class CapturedPath(object):
         """One graph launch on the current stream; no host synchronisation.  x (same shape as at capture) is copied into `.image` first.
         (The captured path contains only kernels of this library - its fills and copies are kernels too: hipMemsetAsync nodes of a
         captured graph share blit state with eager null-stream memsets on ROCm 7.2 and faulted on replay.)"""
+        for m, stamp in zip(self._mods, self._stamps):
+            if m._weights_stamp() != stamp:
+                raise RuntimeError("the weights of %s changed after capture(): the graph holds the old packed weights - capture again" % type(m).__name__)
         if x is not None:
             self.image.copy_(x, non_blocking=True)
+        busy = getattr(self.det, "_busy", None)
+        if busy is not None:                                        # an enqueue() with a detector stream may still read the shared workspace
+            torch.cuda.current_stream(self.image.device).wait_event(busy)
         check(lib.affnet_graph_launch(self.ctx.handle, engine.stream_of(self.image.device)), self.ctx.handle, "affnet_graph_launch")
+        out = dict(self.out, overflow=self.ctx.counter_view(0), _img=self.image)       # the same keys as enqueue()
         if self.image.size(0) == 1:
-            return {k: (v[0] if (v is not None and k != "count") else v) for k, v in self.out.items()}
-        return self.out
+            return {k: (v[0] if (v is not None and k not in ("count", "overflow", "_img")) else v) for k, v in out.items()}
+        return out
 
     def run(self, x=None):
         """launch() + the one count read-back: dict(LAFs px (N,2,3), responses, ids, descriptors) of a single image."""

@@ -85,6 +85,9 @@ SYMBOLS = {
     "affnet_detect_image": (_I, [_P, _P, _P]),
     "affnet_detect_image_responses": (_I, [_P, _P, _P]),
     "affnet_detect_image_onepass": (_I, [_P, _P, _P, _P]),
+    "affnet_detect_image_onepass_responses": (_I, [_P, _P, _P, _P]),
+    "affnet_detected_list": (_I, [_P, _P, _P, _P, _P, _P]),
+    "affnet_shape_iterate": (_I, [_P, _P, _P, _P, _P, _I, _P, _P]),
     "affnet_affmap_offset": (C.c_int64, [_P, _I]),
     "affnet_affmap_image_stride": (C.c_int64, [_P]),
     "affnet_describe_detected": (_I, [_P, C.POINTER(Nets), _I, _P, _P, _P, _P, _P, _P]),

@@ -31,14 +31,18 @@ class _HipPatchNet(nn.Module):
         self._packed_version = None    # _weights_stamp() it was built from
 
     def _weights_stamp(self):
-        """Changes whenever a parameter or buffer is replaced (.to(other device), .float()) or modified in place (load_state_dict,
-        p.data.copy_(), BN running-stat updates, direct state-dict tensor edits all bump the tensor's `_version`).  A no-op
-        `.to(same device)` - e.g. moving an extractor that holds this net - leaves it unchanged, so the packed blob is NOT
-        rebuilt (and never freed) under kernels that may still be reading it on another stream."""
+        """Changes whenever a parameter or buffer is replaced (.to(other device), .float()) or modified in place through the tensor itself
+        (load_state_dict, nn.init.*_ / no_grad in-place ops on the parameter, BN running-stat updates: they bump the tensor's `_version`).
+        NOT detected: writes through `.data` (`p.data.copy_()`, `nn.init.orthogonal(m.weight.data)` - the reference's own weights_init
+        style): `.data` has a version counter of its own, the parameter's stays put, and the cached blob would keep serving the old
+        weights - call invalidate_packed() after such edits.  A no-op `.to(same device)` - e.g. moving an extractor that holds this
+        net - leaves the stamp unchanged, so the packed blob is NOT rebuilt (and never freed) under kernels that may still be reading
+        it on another stream."""
         return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
 
     def invalidate_packed(self):
-        """Drops the cached BN-folded weight blob (it is rebuilt on the next call)."""
+        """Drops the cached BN-folded weight blob (it is rebuilt on the next call).  Required after weight edits through `.data`
+        (see _weights_stamp); a CapturedPath taken before must be captured again."""
         self._packed = None
 
     def packed_weights(self, device):

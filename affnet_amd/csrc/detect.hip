@@ -138,7 +138,7 @@ __device__ __forceinline__ void hess_tile_load(const HessTile<NL>& t, float (&tm
 // current one's are in LDS, so the HBM round trip runs under the response / NMS / centroid work instead of in front of it
 // (PMC, 4K batch: SQ_WAIT_ANY 45 % of the wave cycles with one tile per workgroup and 3 workgroups per CU, 0.9 TB/s).
 template <int NL>
-__global__ __launch_bounds__(256, 3) void hessian_nms_kernel(HessParams hp) {
+__global__ __launch_bounds__(256, (NL <= 5 ? 3 : 1)) void hessian_nms_kernel(HessParams hp) {
     // LDS: NL blurred tiles (20x68) + NL response tiles (18x67)
     __shared__ __attribute__((aligned(16))) float X[NL][HX_H * HX_S];
     __shared__ __attribute__((aligned(16))) float Rr[NL][HR_H * HR_S];
@@ -994,7 +994,7 @@ int aff_fullconv_launch(affnet_ctx* ctx, const float* packed, const float* img, 
 // AffNetFastFullConv maps of every octave are computed here (level 0 of each octave, OnePassSIR.py:69); NULL: the caller has written
 // them into the workspace (affnet_affmap_offset) - the slot form for a foreign dense AffNet.  Results go to the context's internal
 // detection list, consumed by affnet_describe_detected (with nets->d_affnet == NULL: no per-patch shape stage).
-int aff_detect_onepass_impl(affnet_ctx* ctx, const float* d_packed_fullconv, hipStream_t st) {
+int aff_detect_onepass_impl(affnet_ctx* ctx, const float* d_packed_fullconv, const float* d_responses, hipStream_t st) {
     if (!ctx || !ctx->ws) return aff_fail(ctx, AFFNET_ERR_INVALID, "detect_onepass: context not bound");
     if (!ctx->cfg.onepass) return aff_fail(ctx, AFFNET_ERR_INVALID, "detect_onepass: the context was not created with cfg.onepass");
     const affnet_config& c = ctx->cfg;
@@ -1012,7 +1012,7 @@ int aff_detect_onepass_impl(affnet_ctx* ctx, const float* d_packed_fullconv, hip
             if (rc) return rc;
         }
     }
-    int rc = detect_candidates(ctx, nullptr, clear_outputs(ctx, ctx->st_det_resp, ctx->st_det_lafs, ctx->st_det_ids), st);
+    int rc = detect_candidates(ctx, d_responses, clear_outputs(ctx, ctx->st_det_resp, ctx->st_det_lafs, ctx->st_det_ids), st);
     if (rc) return rc;
     const int n_detect = c.levels_per_octave - 2;
     hipLaunchKernelGGL(onepass_level_select_kernel, dim3(c.n_octaves * n_detect, B), dim3(1024), 0, st, ctx->cand_resp, ctx->cand_ids, ctx->cnt,

@@ -103,7 +103,7 @@ extern "C" int affnet_detect_image(affnet_ctx* ctx, const float* d_img, void* st
     return AFFNET_OK;
 }
 
-int aff_detect_onepass_impl(affnet_ctx* ctx, const float* d_packed_fullconv, hipStream_t st);
+int aff_detect_onepass_impl(affnet_ctx* ctx, const float* d_packed_fullconv, const float* d_responses, hipStream_t st);
 
 // OnePassSIR detector half (OnePassSIR.py:53-115,146): pyramid (when d_img != NULL; NULL = already built with
 // affnet_pyramid_build), dense AffNetFastFullConv map per octave (when d_packed_fullconv != NULL; NULL = the caller wrote the maps
@@ -120,10 +120,42 @@ extern "C" int affnet_detect_image_onepass(affnet_ctx* ctx, const float* d_packe
         if (rc) return rc;
     }
     aff_prof_mark(ctx, 1, st);
-    int rc = aff_detect_onepass_impl(ctx, d_packed_fullconv, st);
+    int rc = aff_detect_onepass_impl(ctx, d_packed_fullconv, nullptr, st);
     if (rc) return rc;
     aff_prof_mark(ctx, 9, st);
     return AFFNET_OK;
+}
+
+extern "C" int affnet_detect_image_onepass_responses(affnet_ctx* ctx, const float* d_packed_fullconv, const float* d_responses, void* stream) {
+    AFF_DEVICE(ctx);
+    if (!ctx || !ctx->ws || !d_responses) return aff_fail(ctx, AFFNET_ERR_INVALID, "detect_image_onepass_responses: context not bound or null responses");
+    hipStream_t st = (hipStream_t)stream;
+    aff_prof_mark(ctx, 0, st);
+    aff_prof_mark(ctx, 1, st);
+    int rc = aff_detect_onepass_impl(ctx, d_packed_fullconv, d_responses, st);
+    if (rc) return rc;
+    aff_prof_mark(ctx, 9, st);
+    return AFFNET_OK;
+}
+
+extern "C" int affnet_detected_list(affnet_ctx* ctx, float* d_resp, float* d_lafs, int32_t* d_ids, int32_t* d_count, void* stream) {
+    AFF_DEVICE(ctx);
+    if (!ctx || !ctx->ws || !d_resp || !d_lafs || !d_ids || !d_count) return aff_fail(ctx, AFFNET_ERR_INVALID, "detected_list: context not bound or null output");
+    hipStream_t st = (hipStream_t)stream;
+    const size_t P = (size_t)ctx->B * ctx->cap_pre;
+    int rc = aff_copy_async(ctx, d_resp, ctx->st_det_resp, P * sizeof(float), st);
+    if (!rc) rc = aff_copy_async(ctx, d_lafs, ctx->st_det_lafs, P * 6 * sizeof(float), st);
+    if (!rc) rc = aff_copy_async(ctx, d_ids, ctx->st_det_ids, P * 3 * sizeof(int32_t), st);
+    if (!rc) rc = aff_copy_async(ctx, d_count, ctx->st_det_count, (size_t)ctx->B * sizeof(int32_t), st);
+    return rc;
+}
+
+extern "C" int affnet_shape_iterate(affnet_ctx* ctx, const float* d_A, float* d_base, const float* d_lafs, const int32_t* d_count, int mode,
+                                    float* d_lafs_out, void* stream) {
+    AFF_DEVICE(ctx);
+    if (!ctx || !ctx->ws || !d_base || !d_lafs || !d_count || !d_lafs_out || (mode != 0 && mode != 1) || (mode == 1 && !d_A))
+        return aff_fail(ctx, AFFNET_ERR_INVALID, "shape_iterate: bad argument");
+    return aff_shape_iterate(ctx, d_A, d_base, d_lafs, d_count, mode, d_lafs_out, (hipStream_t)stream);
 }
 
 extern "C" int affnet_describe_detected(affnet_ctx* ctx, const affnet_nets* nets, int do_ori, float* d_lafs_px, float* d_resp,

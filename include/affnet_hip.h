@@ -264,6 +264,14 @@ int affnet_shape_filter_select(affnet_ctx* ctx, const float* d_resp_in, const fl
                                float* d_resp_out, float* d_lafs_out, int32_t* d_ids_out,
                                int32_t* d_count_out, void* stream);
 
+/* One step of the iterated shape estimation (num_Baum_iters > 1, SparseImgRepresenter.py:127-146), rows < d_count[image] of
+ * capacity affnet_capacity_prefilter(ctx):
+ *   mode 0: d_lafs_out = [d_base * LAF_2x2 | centre]                                   (the frames the next patches are cut from)
+ *   mode 1: d_base = d_A * d_base (in place), then d_lafs_out as above                 (d_A = the shape net's output on those patches)
+ * d_A may be NULL in mode 0. */
+int affnet_shape_iterate(affnet_ctx* ctx, const float* d_A, float* d_base, const float* d_lafs, const int32_t* d_count, int mode,
+                         float* d_lafs_out, void* stream);
+
 /* LAF_2x2 <- LAF_2x2 * R for rows < *d_count.  SparseImgRepresenter.py:173-177. */
 int affnet_apply_rotation(affnet_ctx* ctx, float* d_lafs, const float* d_R, const int32_t* d_count,
                           int n_max, void* stream);
@@ -358,6 +366,16 @@ int affnet_describe_detected(affnet_ctx* ctx, const affnet_nets* nets, int do_or
  *   planar (4, h_o, w_o) per octave, at affnet_affmap_offset(ctx, o) (+ affnet_affmap_image_stride per image).
  * Follow with affnet_describe_detected(nets->d_affnet = NULL, ...): orientation, denormalisation, descriptors. */
 int affnet_detect_image_onepass(affnet_ctx* ctx, const float* d_packed_fullconv, const float* d_img, void* stream);
+/* Same with a custom RespNet slot (OnePassSIR.py:24,38-41,71: RespNet(level, sigma) per pyramid level): the pyramid has been built
+ * with affnet_pyramid_build and d_responses holds the slot's response maps laid out like the pyramid (affnet_pyramid_level_offset /
+ * affnet_pyramid_image_stride); only clamp(r - th, 0) is applied to them. */
+int affnet_detect_image_onepass_responses(affnet_ctx* ctx, const float* d_packed_fullconv, const float* d_responses, void* stream);
+
+/* Copies the context's internal detection list (what affnet_detect_image / _responses / _onepass produced and
+ * affnet_describe_detected consumes) into caller buffers of capacity affnet_capacity_prefilter(ctx) rows per image: responses,
+ * NORMALISED LAFs (x mrSize), (octave, level, pixel) ids, row counts.  For callers that run a foreign (Python) OriNet / AffNet /
+ * descriptor between the stages (SparseImgRepresenter.py:38-49, OnePassSIR.py:44-47) on exactly the rows the fused path would use. */
+int affnet_detected_list(affnet_ctx* ctx, float* d_resp, float* d_lafs, int32_t* d_ids, int32_t* d_count, void* stream);
 /* Float offset (from the workspace base) of the (4, h_o, w_o) affine-shape map of octave o of image 0, and the floats between the
  * maps of consecutive images; -1 / 0 when the context has no OnePassSIR areas. */
 int64_t affnet_affmap_offset(const affnet_ctx* ctx, int octave);

@@ -219,3 +219,45 @@ def test_onepass_cli(amd, golden_dir, tmp_path):
     assert ell.shape == (500, 5) and (ell[:, 2] * ell[:, 4] - ell[:, 3] ** 2 > 0).all()
     d = np.load(str(out) + ".desc.npy")
     assert d.shape == (500, 128) and np.abs(np.linalg.norm(d, axis=1) - 1.0).max() < 1e-4
+
+
+def test_onepass_respnet_and_foreign_orinet_slots(amd, nets, weights):
+    """OnePassSIR's remaining slots (OnePassSIR.py:24,38-49): (1) a custom RespNet - a torch restatement of HessianResp passed through
+    the slot reproduces the built-in detector bit for bit, a different response function changes the keypoints; (2) a foreign OriNet
+    (any callable with .PS) wrapped around the native net gives the fused path's rows bit for bit, descriptors included."""
+    import torch.nn.functional as F
+    FC, O, H = nets
+    x = orc.synthetic_image(240, 320, 1).to(DEV)
+    mk = lambda **kw: amd.OnePassSIR(mrSize=5.192, num_features=300, border=15, num_Baum_iters=1, AffNet=FC, **kw).to(DEV)
+    builtin = mk(OriNet=O).run(x, do_ori=True, desc=H)
+
+    def hess(level, sigma):
+        return orc.hessian_response(level.cpu(), sigma).to(level.device)
+
+    def lap(level, sigma):
+        k = torch.tensor([[0.0, 1.0, 0.0], [1.0, -4.0, 1.0], [0.0, 1.0, 0.0]], device=level.device).view(1, 1, 3, 3)
+        return (F.conv2d(F.pad(level, (1, 1, 1, 1), "replicate"), k).abs() * float(sigma * sigma))
+
+    via_slot = mk(OriNet=O, RespNet=hess).run(x, do_ori=True, desc=H)
+    for k in ("LAFs", "responses", "ids", "descriptors"):
+        assert torch.equal(builtin[k], via_slot[k]), "RespNet slot: " + k
+    other = mk(OriNet=O, RespNet=lap).run(x, do_ori=True, desc=H)
+    assert other["LAFs"].shape[0] > 0 and not torch.equal(other["ids"], builtin["ids"])
+
+    class ForeignOri(torch.nn.Module):
+        def __init__(self, net):
+            super().__init__()
+            self.net, self.PS = net, 32
+
+        def forward(self, patches):
+            return self.net(patches)
+
+    staged = mk(OriNet=ForeignOri(O)).run(x, do_ori=True, desc=H)
+    for k in ("LAFs", "responses", "ids", "descriptors"):
+        assert torch.equal(builtin[k], staged[k]), "foreign OriNet: " + k
+    # angles instead of rotation matrices (OnePassSIR.py:121-124 accepts both)
+    class AngleOri(ForeignOri):
+        def forward(self, patches):
+            return self.net(patches, return_rot_matrix=False)
+    ang = mk(OriNet=AngleOri(O)).run(x, do_ori=True, desc=None)
+    assert float((ang["LAFs"] - builtin["LAFs"]).abs().max()) < 1e-3

@@ -374,6 +374,31 @@ def test_foreign_slots_staged_path_equals_fused(amd, nets, weights):
     assert float((L1 - L2).abs().max()) == 0.0
 
 
+def test_foreign_affnet_with_several_baumberg_iterations(amd, nets):
+    """SparseImgRepresenter.py:127-146 with a foreign AffNet slot and num_Baum_iters > 1: patches re-extracted along
+    [base_A * LAF | centre] around the slot call (affnet_shape_iterate), bit-equal to the fused path on the native net."""
+    A, O, H = nets
+    x = orc.synthetic_image(240, 320, 1).to(DEV)
+
+    class Foreign(torch.nn.Module):
+        def __init__(self, net):
+            super().__init__()
+            self.net, self.PS = net, 32
+
+        def forward(self, patches, *a):
+            return self.net(patches)
+
+    for iters in (2, 3):
+        fused = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=iters, AffNet=A, OriNet=O).to(DEV)
+        L1, r1 = fused(x, do_ori=True)
+        staged = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=iters, AffNet=Foreign(A), OriNet=O).to(DEV)
+        L2, r2 = staged(x, do_ori=True)
+        assert torch.equal(r1, r2) and torch.equal(fused.last_ids, staged.last_ids), iters
+        assert torch.equal(L1, L2), "iters = %d: max diff %g" % (iters, float((L1 - L2).abs().max()))
+    one = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=1, AffNet=A, OriNet=O).to(DEV)
+    assert not torch.equal(one(x, do_ori=True)[0], L1), "the iterations must change the frames"
+
+
 def test_two_stream_pipelining_gives_identical_results(amd, nets):
     """bench.py's throughput mode: detector on a second stream, two contexts alternating over an image stream."""
     A, O, H = nets
