@@ -30,8 +30,9 @@ enum {
     CNT_AFF_EVAL,                            // candidates the shape CNN was actually evaluated on (lazy second pass, pipeline.hip)
     CNT_SURVIVED1,                           // survivors of the first (lazy) shape pass, frozen before the second pass starts
     CNT_SEL_EQ_TOTAL,                        // candidates whose response equals the top-k threshold (ties: taken in key order)
-    CNT_POS0 = AFFNET_MAX_OCTAVES + 16,      // CNT_POS0 + (level-1)*AFFNET_MAX_OCTAVES + o : positive maxima of (octave, level)
-    CNT_TOTAL = AFFNET_MAX_OCTAVES + 16 + (AFFNET_MAX_LEVELS - 2) * AFFNET_MAX_OCTAVES
+    CNT_SEL_TIE_LO, CNT_SEL_TIE_HI,          // ties at the threshold are taken up to this (octave, level, pixel) key (64 bits, two halves)
+    CNT_POS0 = AFFNET_MAX_OCTAVES + 24,      // CNT_POS0 + (level-1)*AFFNET_MAX_OCTAVES + o : positive maxima of (octave, level)
+    CNT_TOTAL = AFFNET_MAX_OCTAVES + 24 + (AFFNET_MAX_LEVELS - 2) * AFFNET_MAX_OCTAVES
 };
 
 #define SEL_HIST_BINS 2048      // first digit (11 bits) of the global top-k's radix select, histogrammed by many workgroups

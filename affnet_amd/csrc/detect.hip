@@ -79,15 +79,6 @@ __device__ __forceinline__ float hessian_at(const float* __restrict__ X, int ty,
     return fmaxf(r - th, 0.0f);
 }
 
-// run-time level index into the per-octave sigma table held in registers (a select chain: no scratch array)
-template <int NL>
-__device__ __forceinline__ float sigma_at(const float (&sg)[NL], int idx) {
-    float v = sg[0];
-#pragma unroll
-    for (int k = 1; k < NL; ++k) v = (idx == k) ? sg[k] : v;
-    return v;
-}
-
 // Uniform (scalar) state of one tile: its octave's geometry, level pointers, raw list and sigma tables.
 template <int NL>
 struct HessTile {
@@ -153,6 +144,10 @@ __global__ __launch_bounds__(256, (NL <= 5 ? 3 : 1)) void hessian_nms_kernel(Hes
     uint16_t* s_queue = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(&X[0][0]) + sizeof(RawMax) * HN_CAP);
     static_assert(sizeof(RawMax) * HN_CAP + 2 * HT_X * HT_Y * (NL - 2) <= sizeof(float) * NL * HX_H * HX_S, "staging list + queue must fit in the tile area");
     __shared__ int s_n, s_base;
+    // sigma table of the current tile's octave for the centroid pass, whose level index is a run-time value (queue entry): read from
+    // LDS.  (Indexing the tile's scalar state with it - also through a chain of selects, which the compiler folds back into an indexed
+    // load - put the whole HessTile into scratch memory: 21 dwords stored per thread per tile, 24 MB of HBM writes per 1024x768 image.)
+    __shared__ float s_sigma[AFFNET_MAX_LEVELS];
     const int first = blockIdx.x * hp.tiles_per_wg;
     const int last = min(first + hp.tiles_per_wg, hp.n_tiles);
     int32_t* const overflow = hp.overflow + blockIdx.z * CNT_TOTAL;
@@ -166,7 +161,11 @@ __global__ __launch_bounds__(256, (NL <= 5 ? 3 : 1)) void hessian_nms_kernel(Hes
         HessTile<NL> p;                                 // this tile (uniform: scalar registers)
         hess_tile_setup<NL>(hp, ft, p);
         if (ft > first) __syncthreads();               // the previous tile's staging list / queue (alias X) and Rr are consumed
-        if (threadIdx.x == 0) s_n = 0;
+        if (threadIdx.x == 0) {
+            s_n = 0;
+#pragma unroll
+            for (int l = 0; l < NL; ++l) s_sigma[l] = p.sigma[l];
+        }
         if (!hp.precomputed) {
 #pragma unroll
             for (int l = 0; l < NL; ++l)
@@ -288,7 +287,7 @@ __global__ __launch_bounds__(256, (NL <= 5 ? 3 : 1)) void hessian_nms_kernel(Hes
             float ns = 0.f, ny = 0.f, nx = 0.f, den = 0.f;
 #pragma unroll
             for (int dl = 0; dl < 3; ++dl) {
-                const float sg = sigma_at<NL>(p.sigma, l - 1 + dl);
+                const float sg = s_sigma[l - 1 + dl];
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky) {
                     const float oy = (ky == 0) ? -0.5f : (ky == 1 ? 0.5f : 1.5f);
@@ -521,12 +520,13 @@ __device__ __forceinline__ void radix_pick(const uint32_t* hist, int nbins, uint
 }
 
 #define SEL_LIST_CAP 8192       // keys of the first digit's bucket kept in LDS (32 KB); larger buckets are re-read from global memory
-__global__ __launch_bounds__(1024) void select_prepare_kernel(const float* __restrict__ resp, int32_t* cnt, int cand_cap, int C,
-                                                              int sel_cap, const uint32_t* __restrict__ ghist) {
+__global__ __launch_bounds__(1024) void select_prepare_kernel(const float* __restrict__ resp, const int32_t* __restrict__ ids, int32_t* cnt, int cand_cap,
+                                                              int C, int sel_cap, const uint32_t* __restrict__ ghist) {
     __shared__ uint32_t hist[SEL_HIST_BINS];
     __shared__ uint32_t list[SEL_LIST_CAP];
     __shared__ uint32_t s_wsum[16], s_pick[2], s_ln;
     resp += (size_t)blockIdx.x * cand_cap;           // blockIdx.x = image
+    ids += (size_t)blockIdx.x * cand_cap * 3;
     cnt += blockIdx.x * CNT_TOTAL;
     ghist += (size_t)blockIdx.x * SEL_HIST_BINS;
     int n = cnt[CNT_CAND];
@@ -595,13 +595,39 @@ __global__ __launch_bounds__(1024) void select_prepare_kernel(const float* __res
     }
     __syncthreads();
     radix_pick(hist, 1024, need, s_wsum, s_pick);
+    const uint32_t T = (pre << 10) | s_pick[0];
+    const uint32_t need_eq = s_pick[1], eq_total = hist[s_pick[0]];
+    __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t T = (pre << 10) | s_pick[0];
         cnt[CNT_SEL_MODE] = 1;
         cnt[CNT_SEL_THRESH] = (int32_t)T;               // key of the C-th largest response
-        cnt[CNT_SEL_NEED_EQ] = (int32_t)s_pick[1];      // how many elements equal to it are inside the top C
-        cnt[CNT_SEL_EQ_TOTAL] = (int32_t)hist[s_pick[0]];   // how many elements equal it at all (last digit: bin = full key)
+        cnt[CNT_SEL_NEED_EQ] = (int32_t)need_eq;        // how many elements equal to it are inside the top C
+        cnt[CNT_SEL_EQ_TOTAL] = (int32_t)eq_total;      // how many elements equal it at all (last digit: bin = full key)
+        cnt[CNT_SEL_TIE_LO] = -1; cnt[CNT_SEL_TIE_HI] = -1;   // every tie is taken
     }
+    if (eq_total == need_eq) return;                    // (uniform) the usual case: all ties at the threshold are inside the top C
+    // More ties than needed (torch.topk's choice among equal values is unspecified): the first need_eq of them in (octave, level,
+    // pixel) order, found by a second radix select - over the 44-bit order keys of the tied rows, ascending, 4 digits of 11 bits.
+    // O(n) per digit whatever the number of ties (a scan of the whole list per tied row was O(n * ties): seconds on a flat
+    // response map whose clamp plateau ties most of the candidates).
+    unsigned long long prefix = 0ull, mask = 0ull;
+    uint32_t need_desc = eq_total - need_eq + 1;        // the need_eq-th smallest key = the (eq_total - need_eq + 1)-th largest
+    for (int shift = 33; shift >= 0; shift -= 11) {
+        for (int i = threadIdx.x; i < SEL_HIST_BINS; i += 1024) hist[i] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += 1024) {
+            if (order_key(resp[i]) != T) continue;
+            const unsigned long long o = ord_key(ids + 3 * i);
+            if ((o & mask) == prefix) atomicAdd(&hist[(uint32_t)(o >> shift) & 2047u], 1u);
+        }
+        __syncthreads();
+        radix_pick(hist, SEL_HIST_BINS, need_desc, s_wsum, s_pick);
+        prefix |= (unsigned long long)s_pick[0] << shift;
+        mask |= 2047ull << shift;
+        need_desc = s_pick[1];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { cnt[CNT_SEL_TIE_LO] = (int32_t)(uint32_t)prefix; cnt[CNT_SEL_TIE_HI] = (int32_t)(uint32_t)(prefix >> 32); }
 }
 
 __global__ __launch_bounds__(256) void select_compact_kernel(const float* __restrict__ resp, const float* __restrict__ syx,
@@ -622,16 +648,10 @@ __global__ __launch_bounds__(256) void select_compact_kernel(const float* __rest
         const uint32_t k = order_key(resp[i]), T = (uint32_t)cnt[CNT_SEL_THRESH];
         take = k > T;
         if (k == T) {
-            // Ties at the threshold (torch.topk's choice among equal values is unspecified): deterministic - the first NEED_EQ of them
-            // in (octave, level, pixel) order.  Almost always every tied element is needed and nothing has to be ranked.
-            const int need = cnt[CNT_SEL_NEED_EQ];
-            take = true;
-            if (cnt[CNT_SEL_EQ_TOTAL] != need) {
-                const unsigned long long mine = ord_key(ids + 3 * i);
-                int before = 0;
-                for (int j = 0; j < n; ++j) before += (order_key(resp[j]) == T && ord_key(ids + 3 * j) < mine) ? 1 : 0;
-                take = before < need;
-            }
+            // Ties at the threshold: deterministic - the first NEED_EQ of them in (octave, level, pixel) order = the tied rows whose
+            // order key does not exceed the key select_prepare_kernel found (all ones when every tie is taken: the usual case)
+            const unsigned long long lim = ((unsigned long long)(uint32_t)cnt[CNT_SEL_TIE_HI] << 32) | (uint32_t)cnt[CNT_SEL_TIE_LO];
+            take = ord_key(ids + 3 * i) <= lim;
         }
     }
     if (!take) return;
@@ -906,7 +926,7 @@ static int detect_candidates(affnet_ctx* ctx, const float* d_responses, AffZeroS
     {
         // big grids: 4 tiles per workgroup (next tile's loads under this tile's work); small grids: one tile each (latency)
         hp.n_tiles = n_tiles;
-        hp.tiles_per_wg = ((long long)n_tiles * B >= 8192) ? 2 : 1;
+        hp.tiles_per_wg = ((long long)n_tiles * B >= 8192) ? 2 : 1;     // measured at 4K: 1 -> 0.202, 2 -> 0.195, 4 -> 0.196 ms per image
         if (const char* e = getenv("AFFNET_HESS_TPW")) { const int v = atoi(e); if (v >= 1 && v <= 64) hp.tiles_per_wg = v; }   // tuning aid
         const dim3 hgrid(aff_cdiv(n_tiles, hp.tiles_per_wg), 1, B);
         switch (NLv) {
@@ -948,7 +968,7 @@ static int select_top(affnet_ctx* ctx, const float* resp, const float* syx, cons
         hipLaunchKernelGGL(select_hist_kernel, dim3(hb, B), dim3(256), 0, st, resp, ctx->cnt, (int)ctx->cand_cap, c.num_prefilter, ctx->sel_hist);
         AFF_LAUNCH_CHECK(ctx);
     }
-    hipLaunchKernelGGL(select_prepare_kernel, dim3(B), dim3(1024), 0, st, resp, ctx->cnt, (int)ctx->cand_cap, c.num_prefilter, ctx->cap_pre,
+    hipLaunchKernelGGL(select_prepare_kernel, dim3(B), dim3(1024), 0, st, resp, ids, ctx->cnt, (int)ctx->cand_cap, c.num_prefilter, ctx->cap_pre,
                        ctx->sel_hist);
     AFF_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(select_compact_kernel, dim3(aff_cdiv((int)ctx->cand_cap, 256), B), dim3(256), 0, st, resp, syx, ids, ctx->cnt,

@@ -1008,6 +1008,37 @@ def test_config5_4k_deep_pyramid(amd, nets, weights):
         assert b["LAFs"].shape == (8000, 2, 3) and np.abs(np.linalg.norm(b["descriptors"].cpu().numpy(), axis=1) - 1.0).max() < 1e-4
 
 
+def test_many_exact_ties_stay_cheap_and_deterministic(amd):
+    """with far more ties at the top-k threshold than needed, the tie break scanned the whole candidate list once per
+    tied row (O(n * ties)).  A 16 x 16 block tiled 20 x 15 times gives groups of ~300 identical responses: the cut is found by a radix
+    select over the order keys instead - the selected responses equal the oracle's as a multiset, ties are taken in (octave, level,
+    pixel) order, repeated runs agree, and the call stays in the millisecond range."""
+    import time
+    g = torch.Generator().manual_seed(5)
+    blk = torch.rand(1, 1, 16, 16, generator=g) * 255.0
+    x = blk.repeat(1, 1, 15, 20).contiguous()                             # 240 x 320
+    for n in (50, 500):
+        det = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=n, border=5, num_Baum_iters=0).to(DEV)
+        det.raw_div = 1          # the small octaves of this image are period-2 patterns: every second pixel is a maximum (default list capacity: h*w/4)
+        L, r = det(x.to(DEV))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        L2, r2 = det(x.to(DEV))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        assert torch.equal(L, L2) and torch.equal(r, r2)
+        ex = orc.OracleExtractor(mrSize=5.192, num_features=n, border=5, num_Baum_iters=0)
+        Lw, rw = ex(x)
+        got, want = np.sort(r.cpu().numpy()), np.sort(rw.numpy())
+        assert got.shape == want.shape and np.array_equal(got, want), "selected responses differ from the oracle's as a multiset"
+        u, c = np.unique(want, return_counts=True)
+        keys = _keys(det.last_ids.cpu().numpy())
+        last = r.cpu().numpy() == r.cpu().numpy().min()
+        assert np.all(np.diff(keys[last]) > 0) or last.sum() == 1, "ties at the cut must be the first ones in key order"
+        record_parity("many exact ties (16x16 block tiled, %d kp)" % n, largest_tie_group=int(c.max()), call_ms=dt * 1e3)
+        assert c.max() >= 8 and dt < 0.5, (int(c.max()), dt)       # groups of equal responses inside the selection; the cut falls inside one
+
+
 @pytest.mark.parametrize("ranks,gather", [(2, "all"), (3, "rank0")])
 def test_bench_n_rank_gather_with_real_kernels(ranks, gather):
     """The N-rank path of bench.py with REAL kernels: N self-spawned ranks share this one device (gloo for the

@@ -5,8 +5,12 @@ cp gpurun_out/parity_report.json profiles/${T}_parity_report.json
 grep '^{' gpurun_out/bench_default.log > profiles/${T}_bench_default.json
 grep '^{' gpurun_out/bench_config2.log > profiles/${T}_bench_config2_latency.json
 grep '^{' gpurun_out/bench_h2d.log > profiles/${T}_bench_include_h2d.json
-grep '^{' gpurun_out/bench_spawn2_onedev.log > profiles/${T}_bench_gpus2_selfspawn_onedevice_gloo.json
-grep '^{' gpurun_out/bench_self_gather.log > profiles/${T}_bench_self_gather_rccl_1rank.json
+for N in 2 4; do grep '^{' gpurun_out/bench_dist_dryrun_$N.log > profiles/${T}_bench_gpus${N}_onedevice_gloo_verify_gather.json; done
+grep '^{' gpurun_out/bench_self_gather.log > profiles/${T}_bench_self_gather_rccl_1rank_verify_gather.json
+python tools/trim_trace.py gpurun_out/prof_c2/run_kernel_trace.csv profiles/${T}_config2_kernel_trace.csv
+cp gpurun_out/prof_c2/run_kernel_stats.csv profiles/${T}_config2_kernel_stats.csv
+cp gpurun_out/gap_table.md profiles/${T}_config2_gap_table.md
+cp gpurun_out/prof_c5/run_kernel_stats.csv profiles/${T}_config5_kernel_stats.csv
 tail -n 1 gpurun_out/bench_gpus2_refused.log > profiles/${T}_bench_gpus2_refused_on_1gpu_box.txt
 cp gpurun_out/prof/run_kernel_stats.csv profiles/${T}_kernel_stats.csv
 [ -f gpurun_out/prof_onepass/run_kernel_stats.csv ] && cp gpurun_out/prof_onepass/run_kernel_stats.csv profiles/${T}_onepass_kernel_stats.csv

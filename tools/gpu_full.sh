@@ -10,12 +10,17 @@ timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smok
 timeout 900 python bench.py > gpurun_out/bench_default.log 2>&1; echo "bench exit: $?"; grep '^{' gpurun_out/bench_default.log | cut -c1-600
 timeout 300 python bench.py --config2 > gpurun_out/bench_config2.log 2>&1; echo "config2 exit: $?"; grep '^{' gpurun_out/bench_config2.log | cut -c1-400
 timeout 300 python bench.py --include-h2d --no-cpu-baseline --no-secondary > gpurun_out/bench_h2d.log 2>&1; echo "h2d exit: $?"; grep '^{' gpurun_out/bench_h2d.log | cut -c1-300
-# N > 1 path on one device: self-spawned 2 ranks, RCCL cannot share one GPU between ranks -> gloo for the exchange, real kernels
-AFFNET_BENCH_ONE_DEVICE=1 AFFNET_BENCH_BACKEND=gloo timeout 600 python bench.py --gpus 2 --steps 2 --warmup 1 --batch 32 --no-secondary > gpurun_out/bench_spawn2_onedev.log 2>&1; echo "spawn2 exit: $?"; grep '^{' gpurun_out/bench_spawn2_onedev.log | cut -c1-300
-AFFNET_BENCH_SELF_GATHER=1 timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary > gpurun_out/bench_self_gather.log 2>&1; echo "self-gather (1-rank RCCL) exit: $?"; grep '^{' gpurun_out/bench_self_gather.log | cut -c1-200
+# N > 1 path on one device: self-spawned ranks, RCCL cannot share one GPU between ranks -> gloo for the exchange, real kernels, every
+# gathered record re-computed by rank 0 (--verify-gather all); then the 1-rank RCCL flavour, verified too
+bash tools/gpu_dist_dryrun.sh
+cp gpurun_out/bench_dist_dryrun_2.log gpurun_out/bench_spawn2_onedev.log
 timeout 300 python bench.py --onepass > gpurun_out/bench_onepass.log 2>&1; echo "onepass exit: $?"; grep '^{' gpurun_out/bench_onepass.log | cut -c1-300
 timeout 600 python bench.py --config5 > gpurun_out/bench_config5.log 2>&1; echo "config5 exit: $?"; grep '^{' gpurun_out/bench_config5.log | cut -c1-300
 timeout 120 python bench.py --gpus 2 --steps 1 --warmup 0 > gpurun_out/bench_gpus2_refused.log 2>&1; echo "gpus2 on a 1-GPU box exit (2 = refused loudly): $?"; tail -n 2 gpurun_out/bench_gpus2_refused.log
+# kernel traces of the two non-headline configs: B = 1 latency (eager + graph) with its gap table, and 4K
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_c2 -o run -- python bench.py --config2 --steps 5 > gpurun_out/prof_c2.log 2>&1; echo "prof config2 exit: $?"
+(python tools/gap_table.py gpurun_out/prof_c2/run_kernel_trace.csv; echo; python tools/gap_table.py gpurun_out/prof_c2/run_kernel_trace.csv --graph) > gpurun_out/gap_table.md 2>&1; tail -n 11 gpurun_out/gap_table.md
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_c5 -o run -- python bench.py --config5 --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > gpurun_out/prof_c5.log 2>&1; echo "prof config5 exit: $?"
 CMD="python bench.py --steps 1 --warmup 1 --batch 64 --chunk 32 --no-cpu-baseline --no-secondary"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o run -- $CMD > gpurun_out/prof.log 2>&1; echo "prof exit: $?"
 f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -n 12 "$f" | cut -c1-200

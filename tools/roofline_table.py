@@ -71,7 +71,8 @@ def main(prefix):
     print("bench line: %.0f kp/s, HardNet trunk %.1f TFLOP/s = %.1f %% (HIP events), all CNN kernels %.1f TFLOP/s"
           % (bench["value"], r["achieved"], 100 * r["frac"], r["all_cnn_tflops"]))
     for s in bench.get("secondary_rooflines", []):
-        print("secondary: %s: %.0f GB/s = %.1f %% of 8 TB/s (%.4f ms/image)" % (s["kernel"][:70], s["achieved"], 100 * s["frac"], s["ms_per_image"]))
+        print("secondary: %s: %.1f %s = %.1f %% of the %s peak %.4g (%.4f ms/image)" % (s["kernel"][:70], s["achieved"], s["unit"], 100 * s["frac"], s["bound"], s["peak"],
+                                                                                   s["ms_per_image"]))
 
 
 if __name__ == "__main__":
