@@ -48,6 +48,15 @@ int affnet_selftest_mfma(const float* d_A, const float* d_B, float* d_out, void*
  * factors that tools/pmc_traffic.py applies. */
 int affnet_debug_stream(const void* d_src, void* d_dst, size_t n_bytes, int width, int mode, int halo, void* stream);
 
+/* EXPLORATORY (not used by any product path): fp32 operands as three bf16 terms on v_mfma_f32_16x16x32_bf16 (csrc/split_probe.hip).
+ *   affnet_split3_gemm: d_C (M x N) = d_A (M x K) * d_Bt^T (d_Bt: N x K), M, N multiples of 16, K of 32.  mode 0 = the exact-fp32
+ *     v_mfma_f32_16x16x4_f32 chain (today's arithmetic), 1 = six split terms, 2 = nine, 3 = the leading bf16 term only.
+ *   affnet_split3_rate: sustained rate of the inner-loop shape a trunk layer would have (fragments from LDS, 4 pixel tiles x 1 channel
+ *     tile); terms = 6 / 9 on bf16 MFMA, 1 = the fp32 16x16x4 loop over the same tiles.  One launch = n_blocks x 8 waves x reps x 4 tiles
+ *     x (16 x 16 x 32) multiply-adds.  d_out: 2 floats (sink). */
+int affnet_split3_gemm(const float* d_A, const float* d_Bt, int M, int N, int K, int mode, float* d_C, void* stream);
+int affnet_split3_rate(int reps, int terms, int n_blocks, float* d_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
