@@ -32,7 +32,9 @@ enum {
     CNT_SEL_EQ_TOTAL,                        // candidates whose response equals the top-k threshold (ties: taken in key order)
     CNT_SEL_TIE_LO, CNT_SEL_TIE_HI,          // ties at the threshold are taken up to this (octave, level, pixel) key (64 bits, two halves)
     CNT_POS0 = AFFNET_MAX_OCTAVES + 24,      // CNT_POS0 + (level-1)*AFFNET_MAX_OCTAVES + o : positive maxima of (octave, level)
-    CNT_TOTAL = AFFNET_MAX_OCTAVES + 24 + (AFFNET_MAX_LEVELS - 2) * AFFNET_MAX_OCTAVES
+    CNT_HYP0 = AFFNET_MAX_OCTAVES + 24 + (AFFNET_MAX_LEVELS - 2) * AFFNET_MAX_OCTAVES,   // CNT_HYP0 + 8 * o + k: positives of (octave o, level,
+                                             // hypothesis) k = 0: level 1; 1 + h1: level 2 given level 1 applied (h1); 3 + h1 + 2 h2: level 3
+    CNT_TOTAL = AFFNET_MAX_OCTAVES + 24 + (AFFNET_MAX_LEVELS - 2) * AFFNET_MAX_OCTAVES + 8 * AFFNET_MAX_OCTAVES
 };
 
 #define SEL_HIST_BINS 2048      // first digit (11 bits) of the global top-k's radix select, histogrammed by many workgroups
@@ -42,6 +44,8 @@ struct RawMax {            // one 3-D local maximum found by hessian_nms_kernel
     int32_t lvl;           // detection level 1..nLevels
     float val;             // NMS'ed (border-zeroed) response
     float s, y, x;         // normalised centroid scale / row / column
+    float prev[2];         // NMS'ed responses of the SAME pixel at detection levels lvl-1 and lvl-2 when it is a raw maximum there too (else 0):
+                           // what the octaveMap replay of this pixel needs (detect.hip, resolve_*_kernel); used for <= 3 detection levels
 };
 
 struct OctaveGeom {

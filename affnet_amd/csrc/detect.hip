@@ -141,8 +141,10 @@ __global__ __launch_bounds__(256, (NL <= 5 ? 3 : 1)) void hessian_nms_kernel(Hes
     // Maxima are sparse (~2 % of the pixels per level): the test runs on every pixel, but the 27-tap centroid only on the hits, which
     // are first QUEUED in LDS (behind the staging list) and then worked off one per thread.  Computed inside the test loop, every
     // wavefront with a single hit among its 64 lanes x 4 pixels x (NL - 2) levels walked the whole centroid code for it.
-    uint16_t* s_queue = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(&X[0][0]) + sizeof(RawMax) * HN_CAP);
-    static_assert(sizeof(RawMax) * HN_CAP + 2 * HT_X * HT_Y * (NL - 2) <= sizeof(float) * NL * HX_H * HX_S, "staging list + queue must fit in the tile area");
+    // Queue entry: level << 10 | row << 6 | column, and from bit 16 on the mask of the LOWER detection levels at which the same pixel is
+    // a maximum too (bit l' - 1): their responses go into RawMax::prev for the octaveMap replay.
+    uint32_t* s_queue = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(&X[0][0]) + sizeof(RawMax) * HN_CAP);
+    static_assert(sizeof(RawMax) * HN_CAP + 4 * HT_X * HT_Y * (NL - 2) <= sizeof(float) * NL * HX_H * HX_S, "staging list + queue must fit in the tile area");
     __shared__ int s_n, s_base;
     // sigma table of the current tile's octave for the centroid pass, whose level index is a run-time value (queue entry): read from
     // LDS.  (Indexing the tile's scalar state with it - also through a chain of selects, which the compiler folds back into an indexed
@@ -263,6 +265,7 @@ __global__ __launch_bounds__(256, (NL <= 5 ? 3 : 1)) void hessian_nms_kernel(Hes
                 float m5[NL];
 #pragma unroll
                 for (int l = 0; l < NL; ++l) m5[l] = fmaxf(fmaxf(cm[l][q], cm[l][q + 1]), cm[l][q + 2]);
+                unsigned hits = 0;
 #pragma unroll
                 for (int l = 1; l <= NL - 2; ++l) {
                     const float c = ctr[l][q];
@@ -270,17 +273,18 @@ __global__ __launch_bounds__(256, (NL <= 5 ? 3 : 1)) void hessian_nms_kernel(Hes
                     const float d = c - M;
                     const float e = d + 1e-5f;
                     if (!(e > 0.0f) || c == 0.0f) continue;    // keep * x == 0 -> contributes nothing anywhere
-                    s_queue[atomicAdd(&s_n, 1)] = (uint16_t)((l << 10) | (ty << 6) | tx);
+                    s_queue[atomicAdd(&s_n, 1)] = (hits << 16) | (unsigned)((l << 10) | (ty << 6) | tx);
+                    hits |= 1u << (l - 1);
                 }
             }
         }
         __syncthreads();
         const int n_q = s_n;
         if (n_q == 0) continue;                               // uniform
-        int n_lvl1 = 0;
         for (int e = threadIdx.x; e < n_q; e += 256) {
-            const int code = s_queue[e];
-            const int l = code >> 10, qy = (code >> 6) & 15, qx = code & 63;
+            const unsigned code = s_queue[e];
+            const int l = (code >> 10) & 63, qy = (code >> 6) & 15, qx = code & 63;
+            const unsigned lower = code >> 16;
             const int py = y0 + qy, px = x0 + qx;
             const float c = Rr[l][(qy + 1) * HR_S + qx + 1];
             // 27-tap centroid on the UNMASKED responses, zero padding (HandCraftedModules.py:279)
@@ -315,7 +319,8 @@ __global__ __launch_bounds__(256, (NL <= 5 ? 3 : 1)) void hessian_nms_kernel(Hes
             rm.s = cs / msz;
             rm.y = cy / (float)h;
             rm.x = cx / (float)w;
-            n_lvl1 += (l == 1) ? 1 : 0;
+            rm.prev[0] = (l >= 2 && ((lower >> (l - 2)) & 1u)) ? Rr[l - 1][(qy + 1) * HR_S + qx + 1] : 0.0f;
+            rm.prev[1] = (l >= 3 && ((lower >> (l - 3)) & 1u)) ? Rr[l - 2][(qy + 1) * HR_S + qx + 1] : 0.0f;
             if (e < HN_CAP) {
                 s_list[e] = rm;
             } else {                                   // staging full (pathological tile): direct append
@@ -324,8 +329,6 @@ __global__ __launch_bounds__(256, (NL <= 5 ? 3 : 1)) void hessian_nms_kernel(Hes
                 else atomicOr(overflow, 1);
             }
         }
-        // positives of detection level 1 = its raw maxima (octaveMap is still all zero: v = val > 0): the level's counting pass is free
-        if (n_lvl1) atomicAdd(p.raw_cnt + (CNT_POS0 - CNT_RAW0), n_lvl1);
         __syncthreads();
         const int n_loc = n_q < HN_CAP ? n_q : HN_CAP;
         if (threadIdx.x == 0) s_base = atomicAdd(p.raw_cnt, n_loc);
@@ -451,12 +454,137 @@ __global__ __launch_bounds__(256) void level_resolve_kernel(ResolveParams p, int
     }
 }
 
-// ---- global top-C --------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t order_key(float f) {   // larger float -> larger uint
     const uint32_t u = __float_as_uint(f);
     return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
 
+// ---- the same replay in TWO launches (<= 3 detection levels) --------------------------------------
+// The octaveMap of a pixel changes only through that pixel's own maxima, and a raw maximum carries the responses of the same pixel at
+// the lower detection levels (RawMax::prev).  So its masked response v is a function of (val, prev, which lower levels were applied),
+// and the only global facts are the per-level skip decisions "<= 1 positive -> level skipped", each depending on the lower levels'
+// decisions.  resolve_count_kernel counts the positives of every level under EVERY combination of lower-level decisions (1 + 2 + 4
+// counters per octave); resolve_apply_kernel derives the actual decisions from them and emits the candidates.  The octaveMap itself is
+// never materialised (nor cleared: 11 MB per 4K image).  Five dependent launches and five passes over the raw lists become two.
+__device__ __forceinline__ float omap_step(float m, float pv) {             // octaveMap value of the pixel after a level with NMS'ed value pv
+    const float v = pv * (1.0f - m);
+    return (float)(uint8_t)(long long)(m + v);                                // float -> int64 -> uint8 wrap, as torch's CPU .byte()
+}
+// masked response of a raw maximum given which lower levels were applied (a1: level 1, a2: level 2)
+__device__ __forceinline__ float masked_value(const RawMax& r, bool a1, bool a2) {
+    float m = 0.0f;
+    if (r.lvl == 2) { if (a1 && r.prev[0] != 0.0f) m = omap_step(m, r.prev[0]); }
+    else if (r.lvl == 3) {
+        if (a1 && r.prev[1] != 0.0f) m = omap_step(m, r.prev[1]);            // level 1 first, then level 2: the reference's order
+        if (a2 && r.prev[0] != 0.0f) m = omap_step(m, r.prev[0]);
+    }
+    return r.val * (1.0f - m);
+}
+
+__global__ __launch_bounds__(256) void resolve_count_kernel(ResolveParams p) {
+    const int o = blockIdx.y;
+    const size_t img = blockIdx.z;
+    int32_t* cnt = p.cnt + img * CNT_TOTAL;
+    int n = cnt[CNT_RAW0 + o];
+    if (n > p.raw_cap[o]) n = p.raw_cap[o];
+    if ((int)blockIdx.x * 256 >= n) return;
+    const RawMax* raw = p.raw[o] + img * p.raw_stride;
+    int c[7] = {0, 0, 0, 0, 0, 0, 0};
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+        const RawMax r = raw[i];
+        if (r.lvl == 1) c[0] += r.val > 0.0f;
+        else if (r.lvl == 2) { c[1] += masked_value(r, false, false) > 0.0f; c[2] += masked_value(r, true, false) > 0.0f; }
+        else {
+#pragma unroll
+            for (int h = 0; h < 4; ++h) c[3 + h] += masked_value(r, h & 1, h >> 1) > 0.0f;
+        }
+    }
+    __shared__ int s_c[7];
+    if (threadIdx.x < 7) s_c[threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        int v = c[k];
+#pragma unroll
+        for (int ofs = 32; ofs > 0; ofs >>= 1) v += __shfl_xor(v, ofs, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&s_c[k], v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 7 && s_c[threadIdx.x]) atomicAdd(&cnt[CNT_HYP0 + 8 * o + threadIdx.x], s_c[threadIdx.x]);
+}
+
+__global__ __launch_bounds__(256) void resolve_apply_kernel(ResolveParams p, uint32_t* __restrict__ ghist) {
+    const int o = blockIdx.y;
+    const size_t img = blockIdx.z;
+    int32_t* cnt = p.cnt + img * CNT_TOTAL;
+    int n = cnt[CNT_RAW0 + o];
+    if (n > p.raw_cap[o]) n = p.raw_cap[o];
+    // the reference's sequential decisions (HandCraftedModules.py:252-254: a level with <= 1 positive is skipped, octaveMap unchanged)
+    const int32_t* hy = cnt + CNT_HYP0 + 8 * o;
+    const int n1 = hy[0];
+    const bool a1 = n1 > 1;
+    const int n2 = hy[1 + (a1 ? 1 : 0)];
+    const bool a2 = n2 > 1;
+    const int n3 = hy[3 + (a1 ? 1 : 0) + (a2 ? 2 : 0)];
+    const bool a3 = n3 > 1;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {                                // per-level positives, as the multi-pass replay records them
+        cnt[CNT_POS0 + 0 * AFFNET_MAX_OCTAVES + o] = n1;
+        if (p.n_detect_levels > 1) cnt[CNT_POS0 + 1 * AFFNET_MAX_OCTAVES + o] = n2;
+        if (p.n_detect_levels > 2) cnt[CNT_POS0 + 2 * AFFNET_MAX_OCTAVES + o] = n3;
+    }
+    if ((int)blockIdx.x * 256 >= n) return;
+    const RawMax* raw = p.raw[o] + img * p.raw_stride;
+    const int lane = threadIdx.x & 63;
+    __shared__ int s_wcnt[4], s_wbase;
+    __shared__ uint32_t s_hist[SEL_HIST_BINS];
+    if (ghist) {
+        for (int i = threadIdx.x; i < SEL_HIST_BINS; i += 256) s_hist[i] = 0;
+        ghist += img * SEL_HIST_BINS;
+    }
+    __syncthreads();
+    for (int i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {          // grid-stride: uniform trip count per workgroup
+        const int i = i0 + threadIdx.x;
+        RawMax r;
+        r.lvl = 0; r.val = 0.f; r.prev[0] = r.prev[1] = 0.f; r.pix = 0; r.s = r.y = r.x = 0.f;
+        if (i < n) r = raw[i];
+        const bool applied = r.lvl == 1 ? a1 : (r.lvl == 2 ? a2 : (r.lvl == 3 ? a3 : false));
+        const float v = applied ? masked_value(r, a1, a2) : 0.0f;
+        const bool emit = applied && v != 0.0f;
+        // one global atomic per WORKGROUP iteration (the image's candidate counter is a single address: ~90 atomics / us)
+        const unsigned long long bal = __ballot(emit);
+        if (lane == 0) s_wcnt[threadIdx.x >> 6] = __popcll(bal);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int tot = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+            s_wbase = tot ? atomicAdd(&cnt[CNT_CAND], tot) : 0;
+        }
+        __syncthreads();
+        int wbase = s_wbase;
+        for (int wv = 0; wv < (int)(threadIdx.x >> 6); ++wv) wbase += s_wcnt[wv];
+        __syncthreads();                                // s_wcnt / s_wbase are rewritten by the next iteration
+        if (emit) {
+            const int slot = wbase + __popcll(bal & ((1ull << lane) - 1ull));
+            if (slot < p.cand_cap) {
+                float* cr = p.cand_resp + img * p.cand_cap;
+                float* cs = p.cand_syx + img * p.cand_cap * 3;
+                int32_t* ci = p.cand_ids + img * p.cand_cap * 3;
+                cr[slot] = v;
+                cs[3 * slot] = r.s; cs[3 * slot + 1] = r.y; cs[3 * slot + 2] = r.x;
+                ci[3 * slot] = o; ci[3 * slot + 1] = r.lvl - 1; ci[3 * slot + 2] = r.pix;
+                if (ghist) atomicAdd(&s_hist[order_key(v) >> 21], 1u);
+            } else {
+                atomicOr(&cnt[CNT_OVERFLOW], 2);
+            }
+        }
+    }
+    if (ghist) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < SEL_HIST_BINS; i += 256)
+            if (s_hist[i]) atomicAdd(&ghist[i], s_hist[i]);
+    }
+}
+
+// ---- global top-C --------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long ord_key(const int32_t* ids) {  // (octave, level, pixel) lexicographic
     return ((unsigned long long)(uint32_t)ids[0] << 40) | ((unsigned long long)(uint32_t)ids[1] << 32) | (uint32_t)ids[2];
 }
@@ -891,13 +1019,14 @@ __global__ __launch_bounds__(256) void select_emit_onepass_kernel(const float* _
 // sequential-in-level octaveMap replay -> candidate list (ctx->cand_*, CNT_CAND) and per-level positive counts (CNT_POS0).
 // d_responses == NULL: Hessian responses computed from the pyramid in the workspace; otherwise response maps of a custom
 // RespNet slot, laid out like the pyramid (image stride = affnet_pyramid_image_stride, level offsets as the pyramid's).
-static int detect_candidates(affnet_ctx* ctx, const float* d_responses, AffZeroSegs z, hipStream_t st) {
+static int detect_candidates(affnet_ctx* ctx, const float* d_responses, AffZeroSegs z, hipStream_t st, bool fold_hist) {
     const affnet_config& c = ctx->cfg;
     const int NLv = c.levels_per_octave;
     if (NLv < 3 || NLv > 8) return aff_fail(ctx, AFFNET_ERR_INVALID, "detect: levels_per_octave = %d (3..8 supported)", NLv);
     const int B = ctx->B;
+    const bool two_pass = NLv - 2 <= 3;          // <= 3 detection levels: resolve_count / resolve_apply, no octaveMap in memory
     z.add(ctx->cnt, (size_t)B * CNT_TOTAL * sizeof(int32_t));
-    z.add(ctx->omap, (size_t)B * ctx->map_stride);
+    if (!two_pass) z.add(ctx->omap, (size_t)B * ctx->map_stride);
     z.add(ctx->sel_hist, (size_t)B * SEL_HIST_BINS * sizeof(uint32_t));
     { int zrc = aff_zero_multi_async(ctx, z, st); if (zrc) return zrc; }          // counters, octaveMap, histogram + the caller's areas: one launch
     ResolveParams rp;
@@ -949,9 +1078,14 @@ static int detect_candidates(affnet_ctx* ctx, const float* d_responses, AffZeroS
         // leave at once).  (A cap of 32 left octave 0 of a 4K batch to 8 x 32 workgroups: 42 us per image for the five passes.)
         const int rb = aff_cdiv(max_cap, 256);
         const dim3 rgrid(rb < 128 ? rb : 128, c.n_octaves, B);
-        for (int l = 1; l <= rp.n_detect_levels; ++l) {
-            if (l > 1) hipLaunchKernelGGL(level_resolve_kernel, rgrid, dim3(256), 0, st, rp, l, 0);   // level 1 was counted by hessian_nms_kernel
-            hipLaunchKernelGGL(level_resolve_kernel, rgrid, dim3(256), 0, st, rp, l, 1);
+        if (two_pass) {
+            hipLaunchKernelGGL(resolve_count_kernel, rgrid, dim3(256), 0, st, rp);
+            hipLaunchKernelGGL(resolve_apply_kernel, rgrid, dim3(256), 0, st, rp, fold_hist ? ctx->sel_hist : (uint32_t*)nullptr);
+        } else {
+            for (int l = 1; l <= rp.n_detect_levels; ++l) {
+                hipLaunchKernelGGL(level_resolve_kernel, rgrid, dim3(256), 0, st, rp, l, 0);
+                hipLaunchKernelGGL(level_resolve_kernel, rgrid, dim3(256), 0, st, rp, l, 1);
+            }
         }
     }
     AFF_LAUNCH_CHECK(ctx);
@@ -959,10 +1093,10 @@ static int detect_candidates(affnet_ctx* ctx, const float* d_responses, AffZeroS
 }
 
 // Stage 3: global top-C of a candidate list (CNT_CAND rows of resp / syx / ids) -> ranked rows in ctx->sel_* (CNT_SEL, st_rank).
-static int select_top(affnet_ctx* ctx, const float* resp, const float* syx, const int32_t* ids, hipStream_t st) {
+static int select_top(affnet_ctx* ctx, const float* resp, const float* syx, const int32_t* ids, hipStream_t st, bool have_hist) {
     const affnet_config& c = ctx->cfg;
     const int B = ctx->B;
-    {
+    if (!have_hist) {        // (the two-launch resolve fills the first-digit histogram while it emits the candidates)
         int hb = aff_cdiv((int)ctx->cand_cap, 1024);
         hb = hb < 1 ? 1 : (hb > 128 ? 128 : hb);
         hipLaunchKernelGGL(select_hist_kernel, dim3(hb, B), dim3(256), 0, st, resp, ctx->cnt, (int)ctx->cand_cap, c.num_prefilter, ctx->sel_hist);
@@ -996,9 +1130,10 @@ static AffZeroSegs clear_outputs(affnet_ctx* ctx, float* d_resp, float* d_lafs, 
 int aff_detect_impl(affnet_ctx* ctx, const float* d_responses, float* d_resp, float* d_lafs, int32_t* d_ids, int32_t* d_count, void* stream) {
     if (!ctx || !ctx->ws || !d_resp || !d_lafs || !d_ids) return aff_fail(ctx, AFFNET_ERR_INVALID, "detect: context not bound or null output");
     hipStream_t st = (hipStream_t)stream;
-    int rc = detect_candidates(ctx, d_responses, clear_outputs(ctx, d_resp, d_lafs, d_ids), st);
+    const bool fold = ctx->cfg.levels_per_octave - 2 <= 3;
+    int rc = detect_candidates(ctx, d_responses, clear_outputs(ctx, d_resp, d_lafs, d_ids), st, fold);
     if (rc) return rc;
-    rc = select_top(ctx, ctx->cand_resp, ctx->cand_syx, ctx->cand_ids, st);
+    rc = select_top(ctx, ctx->cand_resp, ctx->cand_syx, ctx->cand_ids, st, fold);
     if (rc) return rc;
     const int nb = aff_cdiv(ctx->cap_pre, 256);
     hipLaunchKernelGGL(select_emit_kernel, dim3(nb, ctx->B), dim3(256), 0, st, ctx->sel_resp, ctx->sel_syx, ctx->sel_ids, ctx->cnt, ctx->cap_pre,
@@ -1032,7 +1167,7 @@ int aff_detect_onepass_impl(affnet_ctx* ctx, const float* d_packed_fullconv, con
             if (rc) return rc;
         }
     }
-    int rc = detect_candidates(ctx, d_responses, clear_outputs(ctx, ctx->st_det_resp, ctx->st_det_lafs, ctx->st_det_ids), st);
+    int rc = detect_candidates(ctx, d_responses, clear_outputs(ctx, ctx->st_det_resp, ctx->st_det_lafs, ctx->st_det_ids), st, false);
     if (rc) return rc;
     const int n_detect = c.levels_per_octave - 2;
     hipLaunchKernelGGL(onepass_level_select_kernel, dim3(c.n_octaves * n_detect, B), dim3(1024), 0, st, ctx->cand_resp, ctx->cand_ids, ctx->cnt,
@@ -1043,7 +1178,7 @@ int aff_detect_onepass_impl(affnet_ctx* ctx, const float* d_packed_fullconv, con
     AFF_LAUNCH_CHECK(ctx);
     hipLaunchKernelGGL(onepass_adopt_count_kernel, dim3(B), dim3(1), 0, st, ctx->cnt);
     AFF_LAUNCH_CHECK(ctx);
-    rc = select_top(ctx, ctx->cand2_resp, ctx->cand2_syx, ctx->cand2_ids, st);
+    rc = select_top(ctx, ctx->cand2_resp, ctx->cand2_syx, ctx->cand2_ids, st, false);
     if (rc) return rc;
     const int nb = aff_cdiv(ctx->cap_pre, 256);
     hipLaunchKernelGGL(select_emit_onepass_kernel, dim3(nb, B), dim3(256), 0, st, ctx->sel_resp, ctx->sel_syx, ctx->sel_ids, ctx->cnt, ctx->cap_pre,

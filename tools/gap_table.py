@@ -7,7 +7,7 @@ import re
 import sys
 
 STAGE = [("pyramid", r"blur2d|aff_copy|decimate"), ("shape", r"shape_"), ("levelsel", r"scale_lafs|level_select"),
-         ("detector", r"hessian_nms|level_resolve|select_|aff_zero|onepass"),
+         ("detector", r"hessian_nms|level_resolve|resolve_|select_|aff_zero|onepass"),
          ("affnet", r"cnn32_trunk_kernel<0|cnn16_finish_kernel<0|affnet_finish"),
          ("orinet", r"cnn32_trunk_kernel<1|cnn16_finish_kernel<1|orinet_finish|apply_rotation"),
          ("hardnet", r"cnn32_trunk_kernel<2|hardnet_")]
