@@ -107,6 +107,7 @@ DEBUG_SYMBOLS = {
     "affnet_cnn32_debug_layer": (_I, [_P, _I, _P, _P, _I, _P, _P]),
     "affnet_cnn32_probe": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "affnet_selftest_mfma": (_I, [_P, _P, _P, _P]),
+    "affnet_debug_split3": (_I, [_P, _I]),
     "affnet_split3_gemm": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "affnet_split3_rate": (_I, [_I, _I, _I, _P, _P]),
     "affnet_debug_stream": (_I, [_P, _P, _SZ, _I, _I, _I, _P]),

@@ -53,6 +53,28 @@ extern "C" int affnet_cnn32_pack_weights(int kind, const float* const* conv_w, c
                 }
         }
     }
+    // EXPLORATORY split copies (HardNet, layers of S3_LAYER_MASK): the same BN-folded fp32 weight as three bf16 terms (nearest even,
+    // exact remainders), [tap][cin / 32][term][kq][cout][8]: lane (cout, kq) of the bf16 MFMA's A operand = 8 consecutive input channels
+    for (int i = 1; i < 6; ++i) {
+        if (!L.w_s3[i]) continue;
+        const int ci = L.cin[i], co = L.cout[i];
+        uint16_t* dst = reinterpret_cast<uint16_t*>(out + L.w_s3[i]);
+        auto bf16_rne = [](float x) -> uint32_t { uint32_t u; memcpy(&u, &x, 4); return (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u; };
+        for (int n = 0; n < co; ++n) {
+            const float sc = 1.0f / sqrtf(bn_var[i][n] + 1e-5f);
+            for (int c = 0; c < ci; ++c)
+                for (int t9 = 0; t9 < 9; ++t9) {
+                    float r = conv_w[i][((size_t)n * ci + c) * 9 + t9] * sc;          // the value the fp32 path uses
+                    for (int term = 0; term < 3; ++term) {
+                        const uint32_t hb = bf16_rne(r);
+                        float hf; memcpy(&hf, &hb, 4);
+                        r -= hf;                                                       // exact
+                        const int G = c / 32, kq = (c % 32) / 8, j = c % 8;
+                        dst[(((((size_t)t9 * (ci / 32) + G) * 3 + term) * 4 + kq) * co + n) * 8 + j] = (uint16_t)(hb >> 16);
+                    }
+                }
+        }
+    }
     if (kind == AFFNET_NET_HARDNET) {
         if (!head_bn_mean || !head_bn_var) return AFFNET_ERR_INVALID;
         for (int n = 0; n < 128; ++n) {
@@ -195,6 +217,7 @@ struct CnnArgs {
     int32_t* shape_cnt;
     int shape_op;
 };
+// (the split-operand variant is a template instantiation: cnn32_trunk_kernel<KIND, NW, STAMPS, S3>)
 
 __device__ __forceinline__ bool lazy_skip(const int32_t* skip_cnt, int skip_n, int image, int which = CNT_SURVIVED1) {
     if (!skip_cnt) return false;
@@ -229,7 +252,7 @@ __device__ __forceinline__ void dump_planes(const float* act, float* dst) {
 // CU (2 waves / SIMD, 256 VGPRs).
 // STAMPS = debug instantiation: the s_memtime phase stamps of tools/cnn_phase_timing.py and the per-layer activation dumps
 // of affnet_cnn32_debug_layer exist only there (26 stamp sites = 26 predicated stores + branches in every wave otherwise).
-template <int KIND, int NW, bool STAMPS>
+template <int KIND, int NW, bool STAMPS, bool S3 = false>
 __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4) void cnn32_trunk_kernel(CnnArgs a, PyrSrc ps) {
     constexpr int CB = (KIND == AFFNET_NET_HARDNET) ? 32 : 16;
     constexpr int NTHR = NW * 64;
@@ -340,6 +363,39 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
     __syncthreads();
     if (STAMPS && a.dbg_layer == 0) { dump_planes<CB, LayC0, NTHR>(act, a.dbg_out); return; }
     CNN_STAMP(2);
+
+    if constexpr (S3 && KIND == AFFNET_NET_HARDNET) {
+        // EXPLORATORY (affnet_debug_split3): conv1 .. conv5 on split operands - fp32 = three bf16 terms, six v_mfma_f32_16x16x32_bf16 per
+        // 32-channel block (conv3x3_mfma_s3).  Activations stay fp32 in LDS in the layouts of the exact path, so the epilogues are shared; the
+        // tilings are chosen so that one split activation fragment (44 VALU instructions) feeds >= 12 MFMAs.
+#define S3_LAYER(CIN_, COUT_, LI_, LO_, STRIDE_, HOUT_, TM_, TN_, IDX_)                                                                  \
+        {                                                                                                                                \
+            f32x4 acc_[TM_][TN_], bias_[TN_];                                                                                            \
+            prefetch_bias<NW, HOUT_, TM_, TN_>(a.packed + a.off.b[IDX_], bias_, wave, lane);                                             \
+            if (PRIO) __builtin_amdgcn_s_setprio(0);                                                                                     \
+            conv3x3_mfma_s3<NW, CIN_, COUT_, LI_, STRIDE_, TM_, TN_>(act, a.packed + a.off.w_s3[IDX_], acc_, wave, lane);               \
+            if (PRIO) __builtin_amdgcn_s_setprio(3);                                                                                     \
+            __syncthreads();                                                                                                             \
+            zero_halo<LO_, NTHR>(act, COUT_);                                                                                            \
+            store_tiles_lds<COUT_, LO_, TM_, TN_>(act, bias_, acc_, wave, lane);                                                         \
+            __syncthreads();                                                                                                             \
+        }
+        S3_LAYER(CB, CB, LayC0, LayC1, 1, 32, 8, 2, 1)                   // conv1: 32 -> 32 @32x32
+        S3_LAYER(CB, 2 * CB, LayC1, LayC2, 2, 16, 4, 2, 2)               // conv2: 32 -> 64, stride 2 -> 16x16
+        S3_LAYER(2 * CB, 2 * CB, LayC2, LayC3, 1, 16, 4, 2, 3)           // conv3: 64 -> 64 @16x16
+        S3_LAYER(2 * CB, 4 * CB, LayC3, LayC4, 2, 8, 2, 2, 4)            // conv4: 64 -> 128, stride 2 -> 8x8
+#undef S3_LAYER
+        {
+            constexpr int T5M = 2, T5N = 2;                              // conv5: 128 -> 128 @8x8, conv5 tensor -> HBM for the head GEMM
+            f32x4 acc5[T5M][T5N], bias5s[T5N];
+            prefetch_bias<NW, 8, T5M, T5N>(a.packed + a.off.b[5], bias5s, wave, lane);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            conv3x3_mfma_s3<NW, 4 * CB, 4 * CB, LayC4, 1, T5M, T5N>(act, a.packed + a.off.w_s3[5], acc5, wave, lane);
+            if (PRIO) __builtin_amdgcn_s_setprio(3);
+            store_tiles_global<4 * CB, T5M, T5N>(a.out + pidx * (64 * 4 * CB), bias5s, acc5, wave, lane);
+        }
+        return;
+    }
 
     // Every layer: MFMA loop -> request the next layer's first weight chunk and bias -> barrier (all waves done reading
     // the input) -> zero the halo of the OUTPUT layout, bias + ReLU + store in place -> barrier.
@@ -688,6 +744,8 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
                              else hipLaunchKernelGGL((cnn32_trunk_kernel<K, 8, false>), grid, dim3(512), 0, st, a, ps); } while (0)
     if (kind == AFFNET_NET_AFFNET) TRUNK_LAUNCH(AFFNET_NET_AFFNET);
     else if (kind == AFFNET_NET_ORINET) TRUNK_LAUNCH(AFFNET_NET_ORINET);
+    else if (ctx->split3 && !a.dbg_time && dbg_layer < 0)         // EXPLORATORY (affnet_debug_split3): split-operand layers
+        hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_HARDNET, 8, false, true>), grid, dim3(512), 0, st, a, ps);
     else TRUNK_LAUNCH(AFFNET_NET_HARDNET);
 #undef TRUNK_LAUNCH
     AFF_LAUNCH_CHECK(ctx);
@@ -764,6 +822,12 @@ int aff_orinet_rotate(affnet_ctx* ctx, const float* packed, float* lafs, const i
 int aff_hardnet_forward_pyr_marked(affnet_ctx* ctx, const float* packed, const float* lafs, const int32_t* ids, const int32_t* count,
                                    int n_max, float* out, float* scratch, hipStream_t st) {
     return cnn_launch(ctx, AFFNET_NET_HARDNET, packed, nullptr, lafs, ids, count, n_max, out, scratch, -1, nullptr, st, true);
+}
+
+extern "C" int affnet_debug_split3(affnet_ctx* ctx, int on) {
+    if (!ctx) return AFFNET_ERR_INVALID;
+    ctx->split3 = on != 0;      // EXPLORATORY: HardNet layers of S3_LAYER_MASK on split operands (fp32 = 3 x bf16) for this context's launches
+    return AFFNET_OK;
 }
 
 extern "C" int affnet_cnn32_debug_timing(affnet_ctx* ctx, unsigned long long* d_stamps) {

@@ -69,8 +69,13 @@ struct NetLayout {
     int cin[6], cout[6];
     size_t w_off[6], b_off[6];
     size_t head_w, head_b;  // head weights / bias (HardNet: BN-folded [8192][128] + bias[128])
+    size_t w_s3[6];         // EXPLORATORY (HardNet only, 0 = none): conv weights once more as three bf16 terms, [tap][cin/32][term][kq][cout][8]
     size_t total;
 };
+
+// floats occupied by the split copy of a cin x cout 3x3 layer: 9 taps x (cin / 32) groups x 3 terms x 4 lane groups x cout x 8 bf16 (= 4 floats)
+constexpr size_t s3_floats(int cin, int cout) { return (size_t)9 * (cin / 32) * 3 * 4 * cout * 4; }
+#define S3_LAYER_MASK 0x3E      // which layers have a split copy / run on split operands (bit i = conv i): conv1 .. conv5 of HardNet
 
 static inline NetLayout net_layout(int kind) {
     NetLayout L;
@@ -88,18 +93,24 @@ static inline NetLayout net_layout(int kind) {
     else if (kind == AFFNET_NET_AFFNET_FULLCONV) { off += 8 * 64 * 32; L.head_b = off; off += 4; }   // [ky][c / 16][(c / 4) % 4][n = o * 8 + kx (32)][c % 4]
     else if (kind == AFFNET_NET_ORINET) { off += 2 * 4096; L.head_b = off; off += 4; }
     else { off += (size_t)HEAD_K * 128; L.head_b = off; off += 128; }
+    for (int i = 0; i < 6; ++i) {
+        L.w_s3[i] = 0;
+        if (kind == AFFNET_NET_HARDNET && ((S3_LAYER_MASK >> i) & 1)) { L.w_s3[i] = off; off += s3_floats(L.cin[i], L.cout[i]); }
+    }
     L.total = off;
     return L;
 }
 
 struct NetOffsets {        // device-side copy of the offsets (by-value kernel argument)
     int w[6], b[6], head_w, head_b;
+    int w_s3[6];
 };
 
 static inline NetOffsets to_offsets(const NetLayout& L) {
     NetOffsets o;
     for (int i = 0; i < 6; ++i) { o.w[i] = (int)L.w_off[i]; o.b[i] = (int)L.b_off[i]; }
     o.head_w = (int)L.head_w; o.head_b = (int)L.head_b;
+    for (int i = 0; i < 6; ++i) o.w_s3[i] = (int)L.w_s3[i];
     return o;
 }
 
@@ -304,6 +315,100 @@ __device__ __forceinline__ void conv3x3_mfma(const float* act, const float* __re
 #pragma unroll
         for (int u = 0; u < GRP; ++u) mfma_group(f0, u);
     }
+}
+
+// ---- EXPLORATORY: the same contraction on split operands (fp32 = three bf16 terms) ---------------------------------------------
+// x = x0 + x1 + x2 with every term rounded to bf16 is exact for a 24-bit significand, every bf16 x bf16 product is exact in the fp32
+// accumulator of v_mfma_f32_16x16x32_bf16, and the six products with i + j <= 2 carry an fp32 product to 2^-25 relative - at 16x the
+// rate of the fp32 MFMA.  Activations stay fp32 in LDS (layout LI unchanged): a lane reads the 8 consecutive input channels of its pixel
+// that one k = 32 step needs (two ds_read_b128 from neighbouring plane groups) and splits them in registers (v_cvt_pk_bf16_f32 + the
+// remainders); weights were split at pack time: Ws [tap][CIN/32][term][kq][COUT][8 bf16].  Accumulator layout = conv3x3_mfma's, so the
+// epilogues are shared.  Selected per context (affnet_debug_split3); never the default.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct Split3 { bf16x8 t[3]; };
+
+__device__ __forceinline__ Split3 split3_rne(const f32x4 lo, const f32x4 hi) {
+    const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    u32x4 p[3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x2 v = {x[2 * q], x[2 * q + 1]};
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));      // v_cvt_pk_bf16_f32 (nearest even)
+            p[t][q] = u;
+            if (t < 2) { v.x -= __uint_as_float(u << 16); v.y -= __uint_as_float(u & 0xffff0000u); }   // exact remainders
+        }
+    }
+    Split3 s;
+#pragma unroll
+    for (int t = 0; t < 3; ++t) s.t[t] = __builtin_bit_cast(bf16x8, p[t]);
+    return s;
+}
+
+template <int NW, int CIN, int COUT, typename LI, int STRIDE, int TM, int TN>
+__device__ __forceinline__ void conv3x3_mfma_s3(const float* act, const float* __restrict__ Ws, f32x4 (&acc)[TM][TN], int wave, int lane) {
+    constexpr int HOUT = LI::H / STRIDE;
+    constexpr int MT = HOUT * HOUT / 16, NT = COUT / 16;
+    constexpr int MG = MT / TM, NG = NT / TN;
+    constexpr int NG32 = CIN / 32, NS = 9 * NG32;
+    static_assert(MG * NG == NW && CIN % 32 == 0, "bad tiling for the split-operand loop");
+    const int mg = wave % MG, ng = wave / MG;
+    const int m = lane & 15, kq = lane >> 4;
+    int a_lane;
+    {
+        const int p = mg * TM * 16 + m;
+        const int oy = p / HOUT, ox = p - oy * HOUT;
+        a_lane = 2 * kq * LI::PSG + ((oy * STRIDE) * LI::WP + ox * STRIDE) * 4;       // channels 8 kq .. 8 kq + 7 = plane groups 2 kq, 2 kq + 1
+    }
+    const unsigned a_addr0 = lds_byte_addr(act) + a_lane * 4;
+    auto a_imm = [](int i) { return 4 * (HOUT == 8 ? i * 2 * STRIDE * LI::WP * 4 : (((i * 16) / HOUT) * STRIDE * LI::WP + ((i * 16) % HOUT) * STRIDE) * 4); };
+    constexpr int WS_FLOATS = 9 * (CIN / 32) * 3 * 4 * COUT * 4;
+    const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(Ws, WS_FLOATS);
+    const int w_lane = (kq * COUT + ng * TN * 16 + m) * 16;                            // bytes; + j * 256 per N-tile
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 w[2][3][TN];
+    auto load_w = [&](bf16x8 (&dst)[3][TN], int s) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                dst[t][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_lane + j * 256, ((s * 3 + t) * 4 * COUT) * 16, 0));
+    };
+    auto step = [&](const bf16x8 (&wc)[3][TN], int s) {
+        const int tap = s / NG32, G = s - tap * NG32;
+        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+        const unsigned ab = a_addr0 + (8 * G * LI::PSG + (ky * LI::WP + kx) * 4) * 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const f32x4 lo = lds_read4(ab + a_imm(i)), hi = lds_read4(ab + a_imm(i) + LI::PSG * 4);
+            const Split3 a = split3_rne(lo, hi);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                // smallest terms first: (0,2) (1,1) (2,0), then (0,1) (1,0), then (0,0)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[0][j], a.t[2], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[1][j], a.t[1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[2][j], a.t[0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[0][j], a.t[1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[1][j], a.t[0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[0][j], a.t[0], acc[i][j], 0, 0, 0);
+            }
+        }
+    };
+    load_w(w[0], 0);
+#pragma unroll 1
+    for (int s = 0; s + 1 < NS; s += 2) {
+        load_w(w[1], s + 1);
+        step(w[0], s);
+        load_w(w[0], (s + 2 < NS) ? s + 2 : s + 1);
+        step(w[1], s + 1);
+    }
+    if (NS & 1) step(w[0], NS - 1);
 }
 
 // Same contraction with ONE A register set that is reloaded in place (for TM = 8 under a 128-VGPR budget, where two

@@ -321,6 +321,9 @@ def main():
                          "seeds) and compares them bit for bit with what arrived through the exchange: right content, count and global order. "
                          "Default for N > 1: 'sample' (first and last image of every rank); 'all' checks every record; N = 1 with "
                          "AFFNET_BENCH_SELF_GATHER=1 checks the 1-rank RCCL path")
+    ap.add_argument("--split3", action="store_true",
+                    help="EXPLORATORY, separately labelled, never the headline: HardNet trunk layers of S3_LAYER_MASK on split operands "
+                         "(fp32 = 3 x bf16 terms on the bf16 matrix cores, fp32 accumulate)")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)        # child process of cpu_node_throughput()
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: ranks rendezvous (backend from AFFNET_BENCH_BACKEND, default gloo here), exchange fake records and "
@@ -508,6 +511,8 @@ def run(args, world):
             if args.all_candidates:
                 dets[k].lazy_shape_rows = 0
             dets[k]._context(c, allow_batch=True)  # create contexts / workspaces before anything is timed
+        if args.split3:
+            _lib.check(_lib.lib.affnet_debug_split3(dets[k]._ctx.handle, 1), dets[k]._ctx.handle, "debug_split3")
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     det_stream = torch.cuda.Stream(device=dev) if PIPE else None
 
@@ -688,13 +693,15 @@ def run(args, world):
         metric = "keypoints/sec (detect+AffNet+OriNet+HardNet) per image, %d kp @%dx%d" % (NKP, W, H)
         if H2D:
             metric += " [PCIe-inclusive: images uploaded from pinned host memory every step]"
+        if args.split3:
+            metric += " [EXPLORATORY: HardNet conv5 on 3 x bf16 split operands]"
         if ONEPASS:
             metric = "keypoints/sec (OnePassSIR: detect + dense AffNetFastFullConv per octave + OriNet + HardNet) per image, %d kp @%dx%d" % (NKP, W, H)
         out = {
             "metric": metric,
             "value": kps / tmax, "unit": "keypoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": tmax / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32 (3xbf16 split operands, fp32 accumulate) in HardNet conv5; f32 elsewhere" if args.split3 else "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[%d]: batch of %d synthetic %dx%d grayscale images per GPU per step, "
                                    "%d kp each, full path detect+AffNet+OriNet+HardNet; AffNet/OriNet shipped weights, "
                                    "HardNet seeded synthetic weights (HardNet++.pth is a missing blob)%s"

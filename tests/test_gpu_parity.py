@@ -1039,6 +1039,35 @@ def test_many_exact_ties_stay_cheap_and_deterministic(amd):
         assert c.max() >= 8 and dt < 0.5, (int(c.max()), dt)       # groups of equal responses inside the selection; the cut falls inside one
 
 
+def test_exploratory_split3_layers_keep_descriptor_parity(amd, nets, weights):
+    """EXPLORATORY (never the default): HardNet trunk layers of S3_LAYER_MASK on split operands - fp32 = three bf16 terms, six
+    v_mfma_f32_16x16x32_bf16 per fp32 product block (affnet_debug_split3).  Keypoints and frames are untouched (AffNet / OriNet stay on
+    the fp32 MFMA), descriptors must agree with the exact-fp32 path far inside the 1e-3 bar and hold the same bars against the oracle."""
+    from affnet_amd._lib import lib
+    A, O, H = nets
+    x = orc.synthetic_image(240, 320, 1)
+    det = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=1, AffNet=A, OriNet=O).to(DEV)
+    exact = det.run(x.to(DEV), do_ori=True, desc=H)
+    assert lib.affnet_debug_split3(det._ctx.handle, 1) == 0
+    try:
+        split = det.run(x.to(DEV), do_ori=True, desc=H)
+    finally:
+        lib.affnet_debug_split3(det._ctx.handle, 0)
+    for k in ("LAFs", "responses", "ids"):
+        assert torch.equal(exact[k], split[k]), k
+    d = (exact["descriptors"] - split["descriptors"]).abs().max().item()
+    ex = _oracle(x, 300, weights)
+    Lw, rw, Pw, Dw = orc.describe(x, ex, weights["HardNet"], do_ori=True, ps=32)
+    gi, wi = _match(split["ids"].cpu().numpy(), ex.keys.numpy())
+    dw_split = np.abs(split["descriptors"].cpu().numpy()[gi] - Dw.numpy()[wi]).max()
+    dw_exact = np.abs(exact["descriptors"].cpu().numpy()[gi] - Dw.numpy()[wi]).max()
+    record_parity("EXPLORATORY split3 (HardNet conv5 on 3 x bf16 split operands) 320x240, 300 kp", split_vs_exact_fp32_desc_max=float(d),
+                  split_vs_oracle_desc_max=float(dw_split), exact_vs_oracle_desc_max=float(dw_exact), rows=int(len(gi)))
+    print("split3: descriptors vs exact fp32 path %.3g; vs oracle %.3g (exact path: %.3g)" % (d, dw_split, dw_exact))
+    assert d > 0.0, "the split-operand path did not run"
+    assert d < 2e-5 and dw_split < 1e-3
+
+
 @pytest.mark.parametrize("ranks,gather", [(2, "all"), (3, "rank0")])
 def test_bench_n_rank_gather_with_real_kernels(ranks, gather):
     """The N-rank path of bench.py with REAL kernels: N self-spawned ranks share this one device (gloo for the
