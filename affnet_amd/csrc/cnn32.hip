@@ -53,7 +53,7 @@ extern "C" int affnet_cnn32_pack_weights(int kind, const float* const* conv_w, c
                 }
         }
     }
-    // EXPLORATORY split copies (HardNet, layers of S3_LAYER_MASK): the same BN-folded fp32 weight as three bf16 terms (nearest even,
+    // EXPLORATORY split copies (HardNet: layers of S3_LAYER_MASK; AffNet / OriNet: conv3..5): the same BN-folded fp32 weight as three bf16 terms (nearest even,
     // exact remainders), [tap][cin / 32][term][kq][cout][8]: lane (cout, kq) of the bf16 MFMA's A operand = 8 consecutive input channels
     for (int i = 1; i < 6; ++i) {
         if (!L.w_s3[i]) continue;
@@ -440,6 +440,33 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
     }
     if (STAMPS && a.dbg_layer == 2) { dump_planes<2 * CB, LayC2, NTHR>(act, a.dbg_out); return; }
 
+    if constexpr (S3 && CB == 16) {
+        // EXPLORATORY (affnet_debug_split3): AffNet / OriNet conv3 .. conv5 (the layers with >= 32 input channels, 62 % of the trunk's
+        // multiply-adds) on split operands; conv1 / conv2 (16 input channels: half a k = 32 step per tap) stay on the fp32 MFMA.
+#define S3_LAYER16(CIN_, COUT_, LI_, LO_, STRIDE_, HOUT_, TM_, TN_, IDX_)                                                                \
+        {                                                                                                                                \
+            f32x4 acc_[TM_][TN_], bias_[TN_];                                                                                            \
+            prefetch_bias<NW, HOUT_, TM_, TN_>(a.packed + a.off.b[IDX_], bias_, wave, lane);                                             \
+            conv3x3_mfma_s3<NW, CIN_, COUT_, LI_, STRIDE_, TM_, TN_>(act, a.packed + a.off.w_s3[IDX_], acc_, wave, lane);               \
+            __syncthreads();                                                                                                             \
+            zero_halo<LO_, NTHR>(act, COUT_);                                                                                            \
+            store_tiles_lds<COUT_, LO_, TM_, TN_>(act, bias_, acc_, wave, lane);                                                         \
+            __syncthreads();                                                                                                             \
+        }
+        S3_LAYER16(2 * CB, 2 * CB, LayC2, LayC3, 1, 16, 2, 2, 3)         // conv3: 32 -> 32 @16x16
+        S3_LAYER16(2 * CB, 4 * CB, LayC3, LayC4, 2, 8, 1, 2, 4)          // conv4: 32 -> 64, stride 2 -> 8x8
+#undef S3_LAYER16
+        {
+            f32x4 acc5[T4M][T4N], bias5s[T4N];                           // conv5: 64 -> 64 @8x8 in the exact path's tiling (the heads read it)
+            prefetch_bias<NW, 8, T4M, T4N>(a.packed + a.off.b[5], bias5s, wave, lane);
+            conv3x3_mfma_s3<NW, 4 * CB, 4 * CB, LayC4, 1, T4M, T4N>(act, a.packed + a.off.w_s3[5], acc5, wave, lane);
+            if constexpr (KIND != AFFNET_NET_HARDNET)
+                head_partials<KIND, T4M>(a.packed + a.off.head_w, bias5s, acc5,
+                                         a.out + pidx * (KIND == AFFNET_NET_AFFNET ? HEAD_PART_AFF : HEAD_PART_ORI), wave, lane);
+        }
+        return;
+    }
+
     // ---- conv3: 2CB -> 2CB @16x16 --------------------------------------------------------------------
     f32x4 b4[G4][T4N];
     f32x4 bias4[T4N];
@@ -742,10 +769,12 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
     // small-tile loops reach 85-90 % of the pipe rate with two waves per SIMD; 16-wave HardNet workgroups - slower too.)
 #define TRUNK_LAUNCH(K) do { if (a.dbg_time || dbg_layer >= 0) hipLaunchKernelGGL((cnn32_trunk_kernel<K, 8, true>), grid, dim3(512), 0, st, a, ps); \
                              else hipLaunchKernelGGL((cnn32_trunk_kernel<K, 8, false>), grid, dim3(512), 0, st, a, ps); } while (0)
-    if (kind == AFFNET_NET_AFFNET) TRUNK_LAUNCH(AFFNET_NET_AFFNET);
+    const bool s3 = ctx->split3 && !a.dbg_time && dbg_layer < 0;      // EXPLORATORY (affnet_debug_split3): split-operand layers
+    if (s3 && kind == AFFNET_NET_AFFNET) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_AFFNET, 8, false, true>), grid, dim3(512), 0, st, a, ps);
+    else if (s3 && kind == AFFNET_NET_ORINET) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_ORINET, 8, false, true>), grid, dim3(512), 0, st, a, ps);
+    else if (s3) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_HARDNET, 8, false, true>), grid, dim3(512), 0, st, a, ps);
+    else if (kind == AFFNET_NET_AFFNET) TRUNK_LAUNCH(AFFNET_NET_AFFNET);
     else if (kind == AFFNET_NET_ORINET) TRUNK_LAUNCH(AFFNET_NET_ORINET);
-    else if (ctx->split3 && !a.dbg_time && dbg_layer < 0)         // EXPLORATORY (affnet_debug_split3): split-operand layers
-        hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_HARDNET, 8, false, true>), grid, dim3(512), 0, st, a, ps);
     else TRUNK_LAUNCH(AFFNET_NET_HARDNET);
 #undef TRUNK_LAUNCH
     AFF_LAUNCH_CHECK(ctx);

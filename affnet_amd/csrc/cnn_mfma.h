@@ -69,7 +69,7 @@ struct NetLayout {
     int cin[6], cout[6];
     size_t w_off[6], b_off[6];
     size_t head_w, head_b;  // head weights / bias (HardNet: BN-folded [8192][128] + bias[128])
-    size_t w_s3[6];         // EXPLORATORY (HardNet only, 0 = none): conv weights once more as three bf16 terms, [tap][cin/32][term][kq][cout][8]
+    size_t w_s3[6];         // EXPLORATORY (0 = none): conv weights once more as three bf16 terms, [tap][cin/32][term][kq][cout][8]
     size_t total;
 };
 
@@ -95,7 +95,9 @@ static inline NetLayout net_layout(int kind) {
     else { off += (size_t)HEAD_K * 128; L.head_b = off; off += 128; }
     for (int i = 0; i < 6; ++i) {
         L.w_s3[i] = 0;
-        if (kind == AFFNET_NET_HARDNET && ((S3_LAYER_MASK >> i) & 1)) { L.w_s3[i] = off; off += s3_floats(L.cin[i], L.cout[i]); }
+        const bool has = (kind == AFFNET_NET_HARDNET && ((S3_LAYER_MASK >> i) & 1)) ||
+                         ((kind == AFFNET_NET_AFFNET || kind == AFFNET_NET_ORINET) && i >= 3);     // 16-channel trunks: the layers with >= 32 input channels
+        if (has) { L.w_s3[i] = off; off += s3_floats(L.cin[i], L.cout[i]); }
     }
     L.total = off;
     return L;

@@ -694,14 +694,14 @@ def run(args, world):
         if H2D:
             metric += " [PCIe-inclusive: images uploaded from pinned host memory every step]"
         if args.split3:
-            metric += " [EXPLORATORY: HardNet conv5 on 3 x bf16 split operands]"
+            metric += " [EXPLORATORY: CNN layers with >= 32 input channels on 3 x bf16 split operands]"
         if ONEPASS:
             metric = "keypoints/sec (OnePassSIR: detect + dense AffNetFastFullConv per octave + OriNet + HardNet) per image, %d kp @%dx%d" % (NKP, W, H)
         out = {
             "metric": metric,
             "value": kps / tmax, "unit": "keypoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": tmax / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (3xbf16 split operands, fp32 accumulate) in HardNet conv5; f32 elsewhere" if args.split3 else "f32", "data": "synthetic",
+            "dtype": "f32 (3xbf16 split operands, fp32 accumulate: HardNet conv1-5, AffNet / OriNet conv3-5; f32 MFMA elsewhere)" if args.split3 else "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[%d]: batch of %d synthetic %dx%d grayscale images per GPU per step, "
                                    "%d kp each, full path detect+AffNet+OriNet+HardNet; AffNet/OriNet shipped weights, "
                                    "HardNet seeded synthetic weights (HardNet++.pth is a missing blob)%s"
