@@ -69,8 +69,13 @@ extern "C" int affnet_cnn32_pack_weights(int kind, const float* const* conv_w, c
                         const uint32_t hb = bf16_rne(r);
                         float hf; memcpy(&hf, &hb, 4);
                         r -= hf;                                                       // exact
-                        const int G = c / 32, kq = (c % 32) / 8, j = c % 8;
-                        dst[(((((size_t)t9 * (ci / 32) + G) * 3 + term) * 4 + kq) * co + n) * 8 + j] = (uint16_t)(hb >> 16);
+                        if (ci == 16) {                                                // two taps per k = 32 step: [step][term][kq][cout][8]
+                            const int st = t9 / 2, kq = (t9 % 2) * 2 + c / 8, j = c % 8;
+                            dst[((((size_t)st * 3 + term) * 4 + kq) * co + n) * 8 + j] = (uint16_t)(hb >> 16);
+                        } else {
+                            const int G = c / 32, kq = (c % 32) / 8, j = c % 8;
+                            dst[(((((size_t)t9 * (ci / 32) + G) * 3 + term) * 4 + kq) * co + n) * 8 + j] = (uint16_t)(hb >> 16);
+                        }
                     }
                 }
         }
@@ -397,6 +402,51 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         return;
     }
 
+    if constexpr (S3 && CB == 16) {
+        // EXPLORATORY (affnet_debug_split3): AffNet / OriNet conv1 .. conv5 on split operands; conv1 / conv2 (16 input channels) take two
+        // taps per k = 32 step (conv3x3_mfma_s3_c16).
+        {
+            f32x4 acc_[8][1], bias_[1];                                  // conv1: 16 -> 16 @32x32
+            prefetch_bias<NW, 32, 8, 1>(a.packed + a.off.b[1], bias_, wave, lane);
+            conv3x3_mfma_s3_c16<NW, CB, LayC0, 1, 8, 1>(act, a.packed + a.off.w_s3[1], acc_, wave, lane);
+            __syncthreads();
+            zero_halo<LayC1, NTHR>(act, CB);
+            store_tiles_lds<CB, LayC1, 8, 1>(act, bias_, acc_, wave, lane);
+            __syncthreads();
+        }
+        {
+            f32x4 acc_[2][2], bias_[2];                                  // conv2: 16 -> 32, stride 2 -> 16x16
+            prefetch_bias<NW, 16, 2, 2>(a.packed + a.off.b[2], bias_, wave, lane);
+            conv3x3_mfma_s3_c16<NW, 2 * CB, LayC1, 2, 2, 2>(act, a.packed + a.off.w_s3[2], acc_, wave, lane);
+            __syncthreads();
+            zero_halo<LayC2, NTHR>(act, 2 * CB);
+            store_tiles_lds<2 * CB, LayC2, 2, 2>(act, bias_, acc_, wave, lane);
+            __syncthreads();
+        }
+#define S3_LAYER16(CIN_, COUT_, LI_, LO_, STRIDE_, HOUT_, TM_, TN_, IDX_)                                                                \
+        {                                                                                                                                \
+            f32x4 acc_[TM_][TN_], bias_[TN_];                                                                                            \
+            prefetch_bias<NW, HOUT_, TM_, TN_>(a.packed + a.off.b[IDX_], bias_, wave, lane);                                             \
+            conv3x3_mfma_s3<NW, CIN_, COUT_, LI_, STRIDE_, TM_, TN_>(act, a.packed + a.off.w_s3[IDX_], acc_, wave, lane);               \
+            __syncthreads();                                                                                                             \
+            zero_halo<LO_, NTHR>(act, COUT_);                                                                                            \
+            store_tiles_lds<COUT_, LO_, TM_, TN_>(act, bias_, acc_, wave, lane);                                                         \
+            __syncthreads();                                                                                                             \
+        }
+        S3_LAYER16(2 * CB, 2 * CB, LayC2, LayC3, 1, 16, 2, 2, 3)         // conv3: 32 -> 32 @16x16
+        S3_LAYER16(2 * CB, 4 * CB, LayC3, LayC4, 2, 8, 1, 2, 4)          // conv4: 32 -> 64, stride 2 -> 8x8
+#undef S3_LAYER16
+        {
+            f32x4 acc5[T4M][T4N], bias5s[T4N];                           // conv5: 64 -> 64 @8x8 in the exact path's tiling (the heads read it)
+            prefetch_bias<NW, 8, T4M, T4N>(a.packed + a.off.b[5], bias5s, wave, lane);
+            conv3x3_mfma_s3<NW, 4 * CB, 4 * CB, LayC4, 1, T4M, T4N>(act, a.packed + a.off.w_s3[5], acc5, wave, lane);
+            if constexpr (KIND != AFFNET_NET_HARDNET)
+                head_partials<KIND, T4M>(a.packed + a.off.head_w, bias5s, acc5,
+                                         a.out + pidx * (KIND == AFFNET_NET_AFFNET ? HEAD_PART_AFF : HEAD_PART_ORI), wave, lane);
+        }
+        return;
+    }
+
     // Every layer: MFMA loop -> request the next layer's first weight chunk and bias -> barrier (all waves done reading
     // the input) -> zero the halo of the OUTPUT layout, bias + ReLU + store in place -> barrier.
     // ---- conv1: CB -> CB @32x32 --------------------------------------------------------------------
@@ -439,33 +489,6 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         CNN_STAMP(6);
     }
     if (STAMPS && a.dbg_layer == 2) { dump_planes<2 * CB, LayC2, NTHR>(act, a.dbg_out); return; }
-
-    if constexpr (S3 && CB == 16) {
-        // EXPLORATORY (affnet_debug_split3): AffNet / OriNet conv3 .. conv5 (the layers with >= 32 input channels, 62 % of the trunk's
-        // multiply-adds) on split operands; conv1 / conv2 (16 input channels: half a k = 32 step per tap) stay on the fp32 MFMA.
-#define S3_LAYER16(CIN_, COUT_, LI_, LO_, STRIDE_, HOUT_, TM_, TN_, IDX_)                                                                \
-        {                                                                                                                                \
-            f32x4 acc_[TM_][TN_], bias_[TN_];                                                                                            \
-            prefetch_bias<NW, HOUT_, TM_, TN_>(a.packed + a.off.b[IDX_], bias_, wave, lane);                                             \
-            conv3x3_mfma_s3<NW, CIN_, COUT_, LI_, STRIDE_, TM_, TN_>(act, a.packed + a.off.w_s3[IDX_], acc_, wave, lane);               \
-            __syncthreads();                                                                                                             \
-            zero_halo<LO_, NTHR>(act, COUT_);                                                                                            \
-            store_tiles_lds<COUT_, LO_, TM_, TN_>(act, bias_, acc_, wave, lane);                                                         \
-            __syncthreads();                                                                                                             \
-        }
-        S3_LAYER16(2 * CB, 2 * CB, LayC2, LayC3, 1, 16, 2, 2, 3)         // conv3: 32 -> 32 @16x16
-        S3_LAYER16(2 * CB, 4 * CB, LayC3, LayC4, 2, 8, 1, 2, 4)          // conv4: 32 -> 64, stride 2 -> 8x8
-#undef S3_LAYER16
-        {
-            f32x4 acc5[T4M][T4N], bias5s[T4N];                           // conv5: 64 -> 64 @8x8 in the exact path's tiling (the heads read it)
-            prefetch_bias<NW, 8, T4M, T4N>(a.packed + a.off.b[5], bias5s, wave, lane);
-            conv3x3_mfma_s3<NW, 4 * CB, 4 * CB, LayC4, 1, T4M, T4N>(act, a.packed + a.off.w_s3[5], acc5, wave, lane);
-            if constexpr (KIND != AFFNET_NET_HARDNET)
-                head_partials<KIND, T4M>(a.packed + a.off.head_w, bias5s, acc5,
-                                         a.out + pidx * (KIND == AFFNET_NET_AFFNET ? HEAD_PART_AFF : HEAD_PART_ORI), wave, lane);
-        }
-        return;
-    }
 
     // ---- conv3: 2CB -> 2CB @16x16 --------------------------------------------------------------------
     f32x4 b4[G4][T4N];

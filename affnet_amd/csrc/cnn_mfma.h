@@ -74,7 +74,8 @@ struct NetLayout {
 };
 
 // floats occupied by the split copy of a cin x cout 3x3 layer: 9 taps x (cin / 32) groups x 3 terms x 4 lane groups x cout x 8 bf16 (= 4 floats)
-constexpr size_t s3_floats(int cin, int cout) { return (size_t)9 * (cin / 32) * 3 * 4 * cout * 4; }
+constexpr size_t s3_floats(int cin, int cout) { return cin == 16 ? (size_t)5 * 3 * 4 * cout * 4      // 16 input channels: two taps per k = 32 step, 9 taps in 5 steps
+                                                                  : (size_t)9 * (cin / 32) * 3 * 4 * cout * 4; }
 #define S3_LAYER_MASK 0x3E      // which layers have a split copy / run on split operands (bit i = conv i): conv1 .. conv5 of HardNet
 
 static inline NetLayout net_layout(int kind) {
@@ -96,7 +97,7 @@ static inline NetLayout net_layout(int kind) {
     for (int i = 0; i < 6; ++i) {
         L.w_s3[i] = 0;
         const bool has = (kind == AFFNET_NET_HARDNET && ((S3_LAYER_MASK >> i) & 1)) ||
-                         ((kind == AFFNET_NET_AFFNET || kind == AFFNET_NET_ORINET) && i >= 3);     // 16-channel trunks: the layers with >= 32 input channels
+                         ((kind == AFFNET_NET_AFFNET || kind == AFFNET_NET_ORINET) && i >= 1);     // 16-channel trunks: conv1 .. conv5
         if (has) { L.w_s3[i] = off; off += s3_floats(L.cin[i], L.cout[i]); }
     }
     L.total = off;
@@ -411,6 +412,59 @@ __device__ __forceinline__ void conv3x3_mfma_s3(const float* act, const float* _
         step(w[1], s + 1);
     }
     if (NS & 1) step(w[0], NS - 1);
+}
+
+// 16 input channels: one k = 32 step = TWO taps x 16 channels (lane group kq: tap 2 s + (kq >> 1), channels 8 (kq & 1) .. + 7); the nine taps
+// take five steps, the tenth half-step multiplies zero weights.  Ws [step][term][kq][COUT][8 bf16].
+template <int NW, int COUT, typename LI, int STRIDE, int TM, int TN>
+__device__ __forceinline__ void conv3x3_mfma_s3_c16(const float* act, const float* __restrict__ Ws, f32x4 (&acc)[TM][TN], int wave, int lane) {
+    constexpr int HOUT = LI::H / STRIDE;
+    constexpr int MT = HOUT * HOUT / 16, NT = COUT / 16;
+    constexpr int MG = MT / TM, NG = NT / TN;
+    static_assert(MG * NG == NW, "bad tiling for the split-operand loop");
+    const int mg = wave % MG, ng = wave / MG;
+    const int m = lane & 15, kq = lane >> 4;
+    int a_lane;
+    {
+        const int p = mg * TM * 16 + m;
+        const int oy = p / HOUT, ox = p - oy * HOUT;
+        a_lane = 2 * (kq & 1) * LI::PSG + ((oy * STRIDE) * LI::WP + ox * STRIDE) * 4;
+    }
+    const unsigned a_addr0 = lds_byte_addr(act) + a_lane * 4;
+    auto a_imm = [](int i) { return 4 * (HOUT == 8 ? i * 2 * STRIDE * LI::WP * 4 : (((i * 16) / HOUT) * STRIDE * LI::WP + ((i * 16) % HOUT) * STRIDE) * 4); };
+    constexpr int WS_FLOATS = 5 * 3 * 4 * COUT * 4;
+    const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(Ws, WS_FLOATS);
+    const int w_lane = (kq * COUT + ng * TN * 16 + m) * 16;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        bf16x8 w[3][TN];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                w[t][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_lane + j * 256, ((s * 3 + t) * 4 * COUT) * 16, 0));
+        const int ta = 2 * s, tb = (2 * s + 1 < 9) ? 2 * s + 1 : 8;                   // the pad half-step re-reads tap 8 (times zero weights)
+        const int off_a = ((ta / 3) * LI::WP + ta % 3) * 16, off_b = ((tb / 3) * LI::WP + tb % 3) * 16;      // bytes
+        const unsigned ab = a_addr0 + ((kq >> 1) ? off_b : off_a);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const f32x4 lo = lds_read4(ab + a_imm(i)), hi = lds_read4(ab + a_imm(i) + LI::PSG * 4);
+            const Split3 a = split3_rne(lo, hi);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0][j], a.t[2], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1][j], a.t[1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2][j], a.t[0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0][j], a.t[1], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1][j], a.t[0], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0][j], a.t[0], acc[i][j], 0, 0, 0);
+            }
+        }
+    }
 }
 
 // Same contraction with ONE A register set that is reloaded in place (for TM = 8 under a 128-VGPR budget, where two
