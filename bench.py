@@ -324,6 +324,7 @@ def main():
     ap.add_argument("--split3", action="store_true",
                     help="EXPLORATORY, separately labelled, never the headline: HardNet trunk layers of S3_LAYER_MASK on split operands "
                          "(fp32 = 3 x bf16 terms on the bf16 matrix cores, fp32 accumulate)")
+    ap.add_argument("--no-split3", action="store_true", help="skip the exploratory split-operand steps behind `split3_exploratory`")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)        # child process of cpu_node_throughput()
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU work: ranks rendezvous (backend from AFFNET_BENCH_BACKEND, default gloo here), exchange fake records and "
@@ -367,6 +368,9 @@ def config2_latency(args):
     A, O, Hn = A.to(dev), O.to(dev), Hn.to(dev)
     det = affnet_amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=2000, border=5, num_Baum_iters=1, AffNet=A, OriNet=O).to(dev)
     x = host.to(dev, non_blocking=True)
+    if args.split3:             # EXPLORATORY: CNN conv layers on split operands (see run())
+        from affnet_amd import _lib
+        _lib.check(_lib.lib.affnet_debug_split3(det._context(x).handle, 1), det._ctx.handle, "debug_split3")
     r = det.run(x, do_ori=True, desc=Hn)
     torch.cuda.synchronize()
     cold = time.perf_counter() - t0
@@ -397,9 +401,12 @@ def config2_latency(args):
         glat.sort()
     except Exception as e:                                      # noqa: BLE001  (reported in the line, the eager figures stand)
         gerr, same = repr(e), False
-    out = {"metric": "latency per image (hesaffnet.py test-graf/img1.png, 2000 kp, detect+AffNet+OriNet+HardNet, B=1, H2D included)",
+    out = {"metric": "latency per image (hesaffnet.py test-graf/img1.png, 2000 kp, detect+AffNet+OriNet+HardNet, B=1, H2D included)" +
+                     (" [EXPLORATORY: CNN conv layers on 3 x bf16 split operands]" if args.split3 else ""),
            "value": warm * 1e3, "unit": "ms", "n_gpus": 1, "steps": len(lat), "warmup": 1, "ms_per_step": warm * 1e3,
-           "higher_is_better": False, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "tests/golden/graf_img1.png (byte copy of test-graf/img1.png)",
+           "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32 (3xbf16 split operands, fp32 accumulate, in every 3x3 conv layer but conv0)" if args.split3 else "f32",
+           "data": "tests/golden/graf_img1.png (byte copy of test-graf/img1.png)",
            "config": {"workload": "BASELINE.json configs[1]: hesaffnet.py test-graf/img1.png 2000 kp, full path on 1 MI355X, single-image API "
                                   "(ScaleSpaceAffinePatchExtractor.run), %dx%d, pinned host image uploaded inside the timed call" % (img.shape[1], img.shape[0]),
                       "keypoints": n},
@@ -694,14 +701,14 @@ def run(args, world):
         if H2D:
             metric += " [PCIe-inclusive: images uploaded from pinned host memory every step]"
         if args.split3:
-            metric += " [EXPLORATORY: CNN layers with >= 32 input channels on 3 x bf16 split operands]"
+            metric += " [EXPLORATORY: CNN conv layers on 3 x bf16 split operands]"
         if ONEPASS:
             metric = "keypoints/sec (OnePassSIR: detect + dense AffNetFastFullConv per octave + OriNet + HardNet) per image, %d kp @%dx%d" % (NKP, W, H)
         out = {
             "metric": metric,
             "value": kps / tmax, "unit": "keypoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": tmax / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32 (3xbf16 split operands, fp32 accumulate: HardNet conv1-5, AffNet / OriNet conv3-5; f32 MFMA elsewhere)" if args.split3 else "f32", "data": "synthetic",
+            "dtype": "f32 (3xbf16 split operands, fp32 accumulate, in every 3x3 conv layer but conv0; f32 MFMA elsewhere)" if args.split3 else "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[%d]: batch of %d synthetic %dx%d grayscale images per GPU per step, "
                                    "%d kp each, full path detect+AffNet+OriNet+HardNet; AffNet/OriNet shipped weights, "
                                    "HardNet seeded synthetic weights (HardNet++.pth is a missing blob)%s"
@@ -741,19 +748,50 @@ def run(args, world):
                                          "border 15; the detector stage includes the dense AffNetFastFullConv of every octave" % (args.batch, W, H, NKP))
         if not args.no_secondary and not ONEPASS and world == 1:
             out["secondary_rooflines"] = secondary_rooflines(dets, chunks, stage_ms, dev)
+        # EXPLORATORY, separately labelled, NOT `value`: the same step with the CNN layers on split operands (fp32 = three bf16 terms on the
+        # bf16 matrix cores, fp32 accumulate) - a few steps on the same contexts after the timed region
+        last_s3 = None
+        if world == 1 and not ONEPASS and not args.split3 and not args.no_split3:
+            try:
+                for d in dets.values():
+                    _lib.check(_lib.lib.affnet_debug_split3(d._ctx.handle, 1), d._ctx.handle, "debug_split3")
+                step(); drain()
+                kp_dev.zero_()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(3):
+                    last_s3 = step()
+                drain()
+                dt3 = time.perf_counter() - t1
+                out["split3_exploratory"] = {
+                    "value": int(kp_dev.item()) / dt3, "unit": "keypoints/s", "steps": 3, "ms_per_image": dt3 / (3 * args.batch) * 1e3,
+                    "dtype": "f32 (3xbf16 split operands, fp32 accumulate) in every 3x3 conv layer of AffNet / OriNet / HardNet but conv0; f32 MFMA elsewhere",
+                    "vs_value": int(kp_dev.item()) / dt3 / (kps / tmax),
+                    "note": "EXPLORATORY, never the headline: exact fp32 operands split into three bf16 terms, six v_mfma_f32_16x16x32_bf16 per "
+                            "32-channel block; differs from the exact path like one summation order from another (tests: same parity bars)"}
+            except Exception as e:                                   # noqa: BLE001  (never at the expense of the main line)
+                out["split3_exploratory"] = {"error": repr(e)[:300]}
+                last_s3 = None
+            finally:
+                for d in dets.values():
+                    _lib.lib.affnet_debug_split3(d._ctx.handle, 0)
         if world == 1 and not args.no_cpu_baseline and not args.config5 and not ONEPASS:
             base, kept = cpu_baseline()
             out["cpu_baseline"] = base
 
-            def fetch(seed):                                         # image `seed` of the last timed step (rank 0, world 1: seed == index)
-                r = last[seed // CH]
-                b = seed % CH
-                n = int(r["count"].view(-1)[b].item())
-                g = lambda k: (r[k] if r["count"].numel() > 1 else r[k].unsqueeze(0))[b, :n].cpu().numpy()
-                return {"ids": g("ids"), "LAFs": g("LAFs"), "resp": g("responses"), "desc": g("descriptors")}
+            def fetcher(results):
+                def fetch(seed):                                     # image `seed` of a step (rank 0, world 1: seed == index)
+                    r = results[seed // CH]
+                    b = seed % CH
+                    n = int(r["count"].view(-1)[b].item())
+                    g = lambda k: (r[k] if r["count"].numel() > 1 else r[k].unsqueeze(0))[b, :n].cpu().numpy()
+                    return {"ids": g("ids"), "LAFs": g("LAFs"), "resp": g("responses"), "desc": g("descriptors")}
+                return fetch
             kept = [(s, w) for s, w in kept if s < args.batch]
             if kept:
-                out["parity_check"] = parity_check(kept, fetch)
+                out["parity_check"] = parity_check(kept, fetcher(last))
+                if last_s3 is not None and "split3_exploratory" in out and "value" in out["split3_exploratory"]:
+                    out["split3_exploratory"]["parity_check"] = parity_check(kept, fetcher(last_s3))
         print(json.dumps(out), flush=True)
     if DIST:
         dist.destroy_process_group()
