@@ -380,23 +380,65 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
             if (PRIO) __builtin_amdgcn_s_setprio(0);                                                                                     \
             conv3x3_mfma_s3<NW, CIN_, COUT_, LI_, STRIDE_, TM_, TN_>(act, a.packed + a.off.w_s3[IDX_], acc_, wave, lane);               \
             if (PRIO) __builtin_amdgcn_s_setprio(3);                                                                                     \
+            CNN_STAMP(2 * IDX_ + 1);                                                                                                     \
             __syncthreads();                                                                                                             \
             zero_halo<LO_, NTHR>(act, COUT_);                                                                                            \
             store_tiles_lds<COUT_, LO_, TM_, TN_>(act, bias_, acc_, wave, lane);                                                         \
             __syncthreads();                                                                                                             \
+            CNN_STAMP(2 * IDX_ + 2);                                                                                                     \
         }
         S3_LAYER(CB, CB, LayC0, LayC1, 1, 32, 8, 2, 1)                   // conv1: 32 -> 32 @32x32
-        S3_LAYER(CB, 2 * CB, LayC1, LayC2, 2, 16, 4, 2, 2)               // conv2: 32 -> 64, stride 2 -> 16x16
-        S3_LAYER(2 * CB, 2 * CB, LayC2, LayC3, 1, 16, 4, 2, 3)           // conv3: 64 -> 64 @16x16
-        S3_LAYER(2 * CB, 4 * CB, LayC3, LayC4, 2, 8, 2, 2, 4)            // conv4: 64 -> 128, stride 2 -> 8x8
 #undef S3_LAYER
+        // conv2 .. conv4 write their outputs PRE-SPLIT (three bf16 planes, LayB): conv3 .. conv5 read ready fragments
+        typedef LayB<16, 18, 2 * CB> LB2;                                // conv2 / conv3 outputs: 64 channels @16x16 (124 KB)
+        typedef LayB<8, 10, 4 * CB> LB4;                                 // conv4 output: 128 channels @8x8 (77 KB)
+        static_assert(LB2::BYTES <= TrunkLds<CB>::ACT * 4 && LB4::BYTES <= TrunkLds<CB>::ACT * 4, "pre-split layouts must fit the activation buffer");
+        {
+            f32x4 acc_[4][2], bias_[2];                                  // conv2: 32 -> 64, stride 2 -> 16x16 (input fp32, split in the loop)
+            prefetch_bias<NW, 16, 4, 2>(a.packed + a.off.b[2], bias_, wave, lane);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            conv3x3_mfma_s3<NW, CB, 2 * CB, LayC1, 2, 4, 2>(act, a.packed + a.off.w_s3[2], acc_, wave, lane);
+            if (PRIO) __builtin_amdgcn_s_setprio(3);
+            CNN_STAMP(5);
+            __syncthreads();
+            zero_halo_b<LB2, NTHR>(act);
+            store_tiles_split<2 * CB, LB2, 4, 2>(act, bias_, acc_, wave, lane);
+            __syncthreads();
+            CNN_STAMP(6);
+        }
+        {
+            f32x4 acc_[4][2], bias_[2];                                  // conv3: 64 -> 64 @16x16
+            prefetch_bias<NW, 16, 4, 2>(a.packed + a.off.b[3], bias_, wave, lane);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            conv3x3_mfma_s3p<NW, 2 * CB, 2 * CB, LB2, 1, 4, 2>(act, a.packed + a.off.w_s3[3], acc_, wave, lane);
+            if (PRIO) __builtin_amdgcn_s_setprio(3);
+            CNN_STAMP(7);
+            __syncthreads();
+            store_tiles_split<2 * CB, LB2, 4, 2>(act, bias_, acc_, wave, lane);      // same layout in place: the halo is still zero
+            __syncthreads();
+            CNN_STAMP(8);
+        }
+        {
+            f32x4 acc_[2][2], bias_[2];                                  // conv4: 64 -> 128, stride 2 -> 8x8
+            prefetch_bias<NW, 8, 2, 2>(a.packed + a.off.b[4], bias_, wave, lane);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            conv3x3_mfma_s3p<NW, 2 * CB, 4 * CB, LB2, 2, 2, 2>(act, a.packed + a.off.w_s3[4], acc_, wave, lane);
+            if (PRIO) __builtin_amdgcn_s_setprio(3);
+            CNN_STAMP(9);
+            __syncthreads();
+            zero_halo_b<LB4, NTHR>(act);
+            store_tiles_split<4 * CB, LB4, 2, 2>(act, bias_, acc_, wave, lane);
+            __syncthreads();
+            CNN_STAMP(10);
+        }
         {
             constexpr int T5M = 2, T5N = 2;                              // conv5: 128 -> 128 @8x8, conv5 tensor -> HBM for the head GEMM
             f32x4 acc5[T5M][T5N], bias5s[T5N];
             prefetch_bias<NW, 8, T5M, T5N>(a.packed + a.off.b[5], bias5s, wave, lane);
             if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3<NW, 4 * CB, 4 * CB, LayC4, 1, T5M, T5N>(act, a.packed + a.off.w_s3[5], acc5, wave, lane);
+            conv3x3_mfma_s3p<NW, 4 * CB, 4 * CB, LB4, 1, T5M, T5N>(act, a.packed + a.off.w_s3[5], acc5, wave, lane);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
+            CNN_STAMP(11);
             store_tiles_global<4 * CB, T5M, T5N>(a.out + pidx * (64 * 4 * CB), bias5s, acc5, wave, lane);
         }
         return;
@@ -414,32 +456,40 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
             store_tiles_lds<CB, LayC1, 8, 1>(act, bias_, acc_, wave, lane);
             __syncthreads();
         }
+        // conv2 .. conv4 write their outputs PRE-SPLIT (three bf16 planes, LayB - see the HardNet branch): no more LDS than the fp32 layouts
+        typedef LayB<16, 18, 2 * CB> LB2;                                // conv2 / conv3 outputs: 32 channels @16x16 (61 KB)
+        typedef LayB<8, 10, 4 * CB> LB4;                                 // conv4 output: 64 channels @8x8 (38 KB)
+        static_assert(LB2::BYTES <= TrunkLds<CB>::ACT * 4 && LB4::BYTES <= TrunkLds<CB>::ACT * 4, "pre-split layouts must fit the activation buffer");
         {
             f32x4 acc_[2][2], bias_[2];                                  // conv2: 16 -> 32, stride 2 -> 16x16
             prefetch_bias<NW, 16, 2, 2>(a.packed + a.off.b[2], bias_, wave, lane);
             conv3x3_mfma_s3_c16<NW, 2 * CB, LayC1, 2, 2, 2>(act, a.packed + a.off.w_s3[2], acc_, wave, lane);
             __syncthreads();
-            zero_halo<LayC2, NTHR>(act, 2 * CB);
-            store_tiles_lds<2 * CB, LayC2, 2, 2>(act, bias_, acc_, wave, lane);
+            zero_halo_b<LB2, NTHR>(act);
+            store_tiles_split<2 * CB, LB2, 2, 2>(act, bias_, acc_, wave, lane);
             __syncthreads();
         }
-#define S3_LAYER16(CIN_, COUT_, LI_, LO_, STRIDE_, HOUT_, TM_, TN_, IDX_)                                                                \
-        {                                                                                                                                \
-            f32x4 acc_[TM_][TN_], bias_[TN_];                                                                                            \
-            prefetch_bias<NW, HOUT_, TM_, TN_>(a.packed + a.off.b[IDX_], bias_, wave, lane);                                             \
-            conv3x3_mfma_s3<NW, CIN_, COUT_, LI_, STRIDE_, TM_, TN_>(act, a.packed + a.off.w_s3[IDX_], acc_, wave, lane);               \
-            __syncthreads();                                                                                                             \
-            zero_halo<LO_, NTHR>(act, COUT_);                                                                                            \
-            store_tiles_lds<COUT_, LO_, TM_, TN_>(act, bias_, acc_, wave, lane);                                                         \
-            __syncthreads();                                                                                                             \
+        {
+            f32x4 acc_[2][2], bias_[2];                                  // conv3: 32 -> 32 @16x16
+            prefetch_bias<NW, 16, 2, 2>(a.packed + a.off.b[3], bias_, wave, lane);
+            conv3x3_mfma_s3p<NW, 2 * CB, 2 * CB, LB2, 1, 2, 2>(act, a.packed + a.off.w_s3[3], acc_, wave, lane);
+            __syncthreads();
+            store_tiles_split<2 * CB, LB2, 2, 2>(act, bias_, acc_, wave, lane);      // in place: the halo is still zero
+            __syncthreads();
         }
-        S3_LAYER16(2 * CB, 2 * CB, LayC2, LayC3, 1, 16, 2, 2, 3)         // conv3: 32 -> 32 @16x16
-        S3_LAYER16(2 * CB, 4 * CB, LayC3, LayC4, 2, 8, 1, 2, 4)          // conv4: 32 -> 64, stride 2 -> 8x8
-#undef S3_LAYER16
+        {
+            f32x4 acc_[1][2], bias_[2];                                  // conv4: 32 -> 64, stride 2 -> 8x8
+            prefetch_bias<NW, 8, 1, 2>(a.packed + a.off.b[4], bias_, wave, lane);
+            conv3x3_mfma_s3p<NW, 2 * CB, 4 * CB, LB2, 2, 1, 2>(act, a.packed + a.off.w_s3[4], acc_, wave, lane);
+            __syncthreads();
+            zero_halo_b<LB4, NTHR>(act);
+            store_tiles_split<4 * CB, LB4, 1, 2>(act, bias_, acc_, wave, lane);
+            __syncthreads();
+        }
         {
             f32x4 acc5[T4M][T4N], bias5s[T4N];                           // conv5: 64 -> 64 @8x8 in the exact path's tiling (the heads read it)
             prefetch_bias<NW, 8, T4M, T4N>(a.packed + a.off.b[5], bias5s, wave, lane);
-            conv3x3_mfma_s3<NW, 4 * CB, 4 * CB, LayC4, 1, T4M, T4N>(act, a.packed + a.off.w_s3[5], acc5, wave, lane);
+            conv3x3_mfma_s3p<NW, 4 * CB, 4 * CB, LB4, 1, T4M, T4N>(act, a.packed + a.off.w_s3[5], acc5, wave, lane);
             if constexpr (KIND != AFFNET_NET_HARDNET)
                 head_partials<KIND, T4M>(a.packed + a.off.head_w, bias5s, acc5,
                                          a.out + pidx * (KIND == AFFNET_NET_AFFNET ? HEAD_PART_AFF : HEAD_PART_ORI), wave, lane);
@@ -793,7 +843,9 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
 #define TRUNK_LAUNCH(K) do { if (a.dbg_time || dbg_layer >= 0) hipLaunchKernelGGL((cnn32_trunk_kernel<K, 8, true>), grid, dim3(512), 0, st, a, ps); \
                              else hipLaunchKernelGGL((cnn32_trunk_kernel<K, 8, false>), grid, dim3(512), 0, st, a, ps); } while (0)
     const bool s3 = ctx->split3 && !a.dbg_time && dbg_layer < 0;      // EXPLORATORY (affnet_debug_split3): split-operand layers
-    if (s3 && kind == AFFNET_NET_AFFNET) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_AFFNET, 8, false, true>), grid, dim3(512), 0, st, a, ps);
+    if (ctx->split3 && a.dbg_time && dbg_layer < 0 && kind == AFFNET_NET_HARDNET)      // phase stamps of the split-operand HardNet (tuning aid)
+        hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_HARDNET, 8, true, true>), grid, dim3(512), 0, st, a, ps);
+    else if (s3 && kind == AFFNET_NET_AFFNET) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_AFFNET, 8, false, true>), grid, dim3(512), 0, st, a, ps);
     else if (s3 && kind == AFFNET_NET_ORINET) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_ORINET, 8, false, true>), grid, dim3(512), 0, st, a, ps);
     else if (s3) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_HARDNET, 8, false, true>), grid, dim3(512), 0, st, a, ps);
     else if (kind == AFFNET_NET_AFFNET) TRUNK_LAUNCH(AFFNET_NET_AFFNET);

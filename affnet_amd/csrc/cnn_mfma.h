@@ -332,6 +332,21 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct Split3 { bf16x8 t[3]; };
 
+// Exact remainder of a pair after its bf16 roundings u = (bf16(v.x), bf16(v.y)): v_dot2c_f32_bf16 with the constant pair (-1, 0) /
+// (0, -1) is  v.x - float(u.lo) + 0 * float(u.hi)  in one full-rate instruction (vs shift / mask + packed subtract, 8 issue cycles
+// per pair): the difference is representable, so the rounding mode does not matter; checked bit-for-bit against the shift / subtract
+// form on 2^24 random bit patterns incl. denormals (tools/_tmp probe, round 3) - they differ only where bf16(v) overflows to inf.
+// The constants come from s_mov through an asm so that the compiler cannot fold them into an inline operand: it encodes the packed
+// bf16 (-1, 0) as the inline constant -1.0, which the hardware does not read as bf16 (the low-half remainders came out unchanged).
+__device__ __forceinline__ void split_remainder(f32x2& v, unsigned u) {
+    unsigned c0, c1;
+    asm("s_mov_b32 %0, 0xbf80" : "=s"(c0));
+    asm("s_mov_b32 %0, 0xbf800000" : "=s"(c1));
+    const bf16x2 b = __builtin_bit_cast(bf16x2, u);
+    v.x = __builtin_amdgcn_fdot2_f32_bf16(b, __builtin_bit_cast(bf16x2, c0), v.x, false);
+    v.y = __builtin_amdgcn_fdot2_f32_bf16(b, __builtin_bit_cast(bf16x2, c1), v.y, false);
+}
+
 __device__ __forceinline__ Split3 split3_rne(const f32x4 lo, const f32x4 hi) {
     const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     u32x4 p[3];
@@ -342,7 +357,7 @@ __device__ __forceinline__ Split3 split3_rne(const f32x4 lo, const f32x4 hi) {
         for (int t = 0; t < 3; ++t) {
             const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));      // v_cvt_pk_bf16_f32 (nearest even)
             p[t][q] = u;
-            if (t < 2) { v.x -= __uint_as_float(u << 16); v.y -= __uint_as_float(u & 0xffff0000u); }   // exact remainders
+            if (t < 2) split_remainder(v, u);                                                          // exact remainders
         }
     }
     Split3 s;
@@ -391,16 +406,14 @@ __device__ __forceinline__ void conv3x3_mfma_s3(const float* act, const float* _
         for (int i = 0; i < TM; ++i) {
             const f32x4 lo = lds_read4(ab + a_imm(i)), hi = lds_read4(ab + a_imm(i) + LI::PSG * 4);
             const Split3 a = split3_rne(lo, hi);
+            // smallest terms first: (0,2) (1,1) (2,0), then (0,1) (1,0), then (0,0); the channel tiles alternate inside a term so that
+            // consecutive MFMAs do not wait on one accumulator
+            constexpr int TW[6] = {0, 1, 2, 0, 1, 0}, TA[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                // smallest terms first: (0,2) (1,1) (2,0), then (0,1) (1,0), then (0,0)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[0][j], a.t[2], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[1][j], a.t[1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[2][j], a.t[0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[0][j], a.t[1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[1][j], a.t[0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[0][j], a.t[0], acc[i][j], 0, 0, 0);
-            }
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[TW[t]][j], a.t[TA[t]], acc[i][j], 0, 0, 0);
         }
     };
     load_w(w[0], 0);
@@ -410,6 +423,141 @@ __device__ __forceinline__ void conv3x3_mfma_s3(const float* act, const float* _
         step(w[0], s);
         load_w(w[0], (s + 2 < NS) ? s + 2 : s + 1);
         step(w[1], s + 1);
+    }
+    if (NS & 1) step(w[0], NS - 1);
+}
+
+// ---- pre-split activations: a layer's output stored as three bf16 planes -------------------------------------------------------
+// Splitting in the reading loop is redundant: the NG waves that share a pixel tile (different output channels) each split the same
+// fragment - 4.5 VALU instructions per MFMA in the first version (PMC: 8.0e9 VALU vs 1.8e9 MFMA instructions per 32-image HardNet
+// launch, VALU and matrix pipe each ~50 % busy, one after the other).  Where the buffer allows (1.5x the fp32 size), the EPILOGUE
+// splits every output element once and the next layer reads ready bf16 fragments: element (term t, channel c, y, x) of an H x H layer
+// sits at  t * TS + (c / 8) * GS + ((y + 1) * WP + x + 1) * 16 + (c % 8) * 2  bytes - one ds_read_b128 = the 8 channels of one term
+// of one pixel = a lane's B fragment of a k = 32 step.
+template <int H_, int WP_, int C_>
+struct LayB {
+    static constexpr int H = H_, WP = WP_, C = C_;
+    static constexpr int GS = (H_ + 2) * WP_ * 16;        // bytes per 8-channel group
+    static constexpr int TS = (C_ / 8) * GS;              // bytes per term
+    static constexpr int BYTES = 3 * TS;
+};
+
+template <typename L, int NTHR>
+__device__ __forceinline__ void zero_halo_b(float* act, int tid = threadIdx.x) {
+    constexpr int H = L::H, CELLS = 4 * (H + 1), PLANES = 3 * (L::C / 8);
+    char* base = reinterpret_cast<char*>(act);
+    for (int i = tid; i < PLANES * CELLS; i += NTHR) {
+        const int g = i / CELLS, e = i - g * CELLS;      // g = term * (C / 8) + group: planes are contiguous (TS = groups * GS)
+        int y, x;
+        if (e < H + 2) { y = 0; x = e; }
+        else if (e < 2 * (H + 2)) { y = H + 1; x = e - (H + 2); }
+        else { const int r = e - 2 * (H + 2); y = 1 + (r >> 1); x = (r & 1) ? H + 1 : 0; }
+        *reinterpret_cast<f32x4*>(base + (size_t)g * L::GS + (y * L::WP + x) * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// Epilogue: + bias, ReLU, split into three bf16 terms, store into layout LO (lane: pixel n of the tile, channels 4 g .. 4 g + 3 of N-tile)
+template <int COUT, typename LO, int TM, int TN>
+__device__ __forceinline__ void store_tiles_split(float* act, const f32x4 (&bias)[TN], const f32x4 (&acc)[TM][TN], int wave, int lane) {
+    constexpr int HOUT = LO::H;
+    constexpr int MT = HOUT * HOUT / 16, MG = MT / TM;
+    const int mg = wave % MG, ng = wave / MG;
+    const int n = lane & 15, g = lane >> 4;
+    char* base = reinterpret_cast<char*>(act);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int p = (mg * TM + i) * 16 + n;
+        const int oy = p / HOUT, ox = p - oy * HOUT;
+        const int cell = ((oy + 1) * LO::WP + ox + 1) * 16;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            f32x4 v = acc[i][j] + bias[j];
+            v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+            const int c0 = (ng * TN + j) * 16 + 4 * g;                   // first of this lane's 4 channels
+            char* dst = base + (c0 >> 3) * LO::GS + cell + (c0 & 4) * 2;
+            f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const unsigned u0 = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
+                const unsigned u1 = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
+                *reinterpret_cast<uint2*>(dst + t * LO::TS) = make_uint2(u0, u1);
+                if (t < 2) { split_remainder(lo, u0); split_remainder(hi, u1); }
+            }
+        }
+    }
+}
+
+// The contraction on a PRE-SPLIT input (layout LI = LayB): no VALU in the loop - three ds_read_b128 per pixel tile and k = 32 step.
+template <int NW, int CIN, int COUT, typename LI, int STRIDE, int TM, int TN>
+__device__ __forceinline__ void conv3x3_mfma_s3p(const float* act, const float* __restrict__ Ws, f32x4 (&acc)[TM][TN], int wave, int lane) {
+    constexpr int HOUT = LI::H / STRIDE;
+    constexpr int MT = HOUT * HOUT / 16, NT = COUT / 16;
+    constexpr int MG = MT / TM, NG = NT / TN;
+    constexpr int NG32 = CIN / 32, NS = 9 * NG32;
+    static_assert(MG * NG == NW && CIN % 32 == 0 && LI::C == CIN, "bad tiling for the split-operand loop");
+    const int mg = wave % MG, ng = wave / MG;
+    const int m = lane & 15, kq = lane >> 4;
+    int a_lane;                                                            // bytes
+    {
+        const int p = mg * TM * 16 + m;
+        const int oy = p / HOUT, ox = p - oy * HOUT;
+        a_lane = kq * LI::GS + ((oy * STRIDE) * LI::WP + ox * STRIDE) * 16;
+    }
+    const unsigned a_addr0 = lds_byte_addr(act) + a_lane;
+    auto a_imm = [](int i) { return 16 * (HOUT == 8 ? i * 2 * STRIDE * LI::WP : (((i * 16) / HOUT) * STRIDE * LI::WP + ((i * 16) % HOUT) * STRIDE)); };
+    constexpr int WS_FLOATS = 9 * (CIN / 32) * 3 * 4 * COUT * 4;
+    const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(Ws, WS_FLOATS);
+    const int w_lane = (kq * COUT + ng * TN * 16 + m) * 16;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 w[2][3][TN];
+    auto load_w = [&](bf16x8 (&dst)[3][TN], int s) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                dst[t][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_lane + j * 256, ((s * 3 + t) * 4 * COUT) * 16, 0));
+    };
+    // Rotating schedule: the fragments of pixel tile i for step s + 1 are requested right after tile i's MFMAs of step s were issued
+    // (same registers - the matrix pipe has read them by then), so every ds_read has the other tiles' MFMAs (>= 100 issue cycles) to
+    // complete.  The first version read a step's 3 TM fragments at its top and waited: a wave stalled once per step and the two waves
+    // of a SIMD drifted apart (conv3: faster wave 30 k cycles, slower 35 k; matrix-pipe floor 27.6 k).
+    auto frag_addr = [&](int s) {
+        const int tap = s / NG32, G = s - tap * NG32;
+        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+        return a_addr0 + 4 * G * LI::GS + (ky * LI::WP + kx) * 16;
+    };
+    bf16x8 a[TM][3];
+    auto read_tile = [&](unsigned ab, int i) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) a[i][t] = __builtin_bit_cast(bf16x8, lds_read4(ab + a_imm(i) + t * LI::TS));
+    };
+    auto step = [&](const bf16x8 (&wc)[3][TN], int s_next) {
+        const unsigned ab = frag_addr(s_next);
+        constexpr int TW[6] = {0, 1, 2, 0, 1, 0}, TA[6] = {2, 1, 0, 1, 0, 0};      // smallest terms first
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[TW[t]][j], a[i][TA[t]], acc[i][j], 0, 0, 0);
+            read_tile(ab, i);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6 * TN, 0);      // this tile's MFMAs ...
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);           // ... then its three reads for the next step
+        }
+    };
+    load_w(w[0], 0);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) read_tile(frag_addr(0), i);
+#pragma unroll 1
+    for (int s = 0; s + 1 < NS; s += 2) {
+        load_w(w[1], s + 1);
+        step(w[0], s + 1);
+        load_w(w[0], (s + 2 < NS) ? s + 2 : s + 1);
+        step(w[1], (s + 2 < NS) ? s + 2 : s + 1);                        // the last step re-reads its own fragments (never used)
     }
     if (NS & 1) step(w[0], NS - 1);
 }

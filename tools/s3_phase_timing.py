@@ -1,0 +1,37 @@
+#!/usr/bin/env python
+"""Phase breakdown (s_memtime stamps) of the EXPLORATORY split-operand HardNet trunk next to the exact fp32 one (tuning aid)."""
+import os, sys
+import numpy as np
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import affnet_amd
+from affnet_amd._lib import lib, ptr
+from affnet_amd import engine
+
+dev = torch.device("cuda:0")
+n, nw = int(os.environ.get("PHASE_PATCHES", "2048")), 8
+p = (torch.rand(n, 1, 32, 32) * 255).to(dev)
+H = affnet_amd.HardNet(); H.load_state_dict(affnet_amd.synthetic_hardnet_state(0)); H.to(dev)
+names = ["input+norm", "conv0", "conv1 mfma", "conv1 store", "conv2 mfma", "conv2 store", "conv3 mfma", "conv3 store",
+         "conv4 mfma", "conv4 store", "conv5 mfma"]
+ctx = engine.utility_ctx(dev)
+for split in (0, 1):
+    lib.affnet_debug_split3(ctx, split)
+    H(p); torch.cuda.synchronize()
+    st = torch.zeros(n * nw * 32, dtype=torch.int64, device=dev)
+    lib.affnet_cnn32_debug_timing(ctx, ptr(st))
+    H(p); torch.cuda.synchronize()
+    lib.affnet_cnn32_debug_timing(ctx, None)
+    t = st.cpu().numpy().reshape(n, nw, 32).astype(np.float64)
+    d = np.diff(t[:, :, :12], axis=2)
+    print("== HardNet %s: mean ticks per phase per wave (100 MHz)" % ("split operands" if split else "exact fp32"))
+    for i in range(11):
+        print("  %-12s mean %8.0f  max-over-waves %8.0f" % (names[i], d[:, :, i].mean(), d[:, :, i].max(axis=1).mean()))
+    print("  total per patch %.0f ticks" % (t[:, :, 11].max(axis=1) - t[:, :, 0].min(axis=1)).mean())
+    big = (torch.rand(48000, 1, 32, 32) * 255).to(dev)
+    H(big); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); H(big); e1.record(); torch.cuda.synchronize()
+    print("  48000 patches: %.3f ms" % e0.elapsed_time(e1))
+lib.affnet_debug_split3(ctx, 0)
