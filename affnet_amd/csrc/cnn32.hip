@@ -338,7 +338,10 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         const int y = e < 34 ? 0 : (e < 68 ? 33 : 1 + ((e - 68) >> 1)), x = e < 34 ? e : (e < 68 ? e - 34 : ((e - 68) & 1) * 33);
         patch[y * WP32 + x] = 0.0f;
     }
-    zero_halo<LayC0, NTHR>(act, CB);
+    constexpr bool HALF = S3;                                     // EXPLORATORY split path: conv0 .. conv2 in two half-patch passes
+    typedef LayB<16, 32, 34, CB> LBH;                            // conv0 output of half a patch, pre-split (HALF only)
+    if constexpr (HALF) zero_halo_b<LBH, NTHR>(act);
+    else zero_halo<LayC0, NTHR>(act, CB);
     float sum = 0.f;
 #pragma unroll
     for (int q = 0; q < PPT; ++q) sum += v[q];
@@ -357,52 +360,80 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
 
     // ---- conv0: 1 -> CB, K = 9 (padded to 12), MFMA; reads `patch`, writes `act`: no barrier in between ----
     f32x4 bias1[T1N];
-    {
+    if constexpr (!HALF) {
         f32x4 acc[T1M][T1N];
         conv0_mfma<NW, CB, T1M, T1N>(patch, w0, bias0, acc, wave, lane);
         CNN_STAMP(19);
         prefetch_bias<NW, 32, T1M, T1N>(a.packed + a.off.b[1], bias1, wave, lane);
         store_tiles_lds<CB, LayC0, T1M, T1N, false>(act, bias0, acc, wave, lane);
         CNN_STAMP(20);
+        __syncthreads();
     }
-    __syncthreads();
     if (STAMPS && a.dbg_layer == 0) { dump_planes<CB, LayC0, NTHR>(act, a.dbg_out); return; }
-    CNN_STAMP(2);
+    if (!HALF) CNN_STAMP(2);
 
     if constexpr (S3 && KIND == AFFNET_NET_HARDNET) {
         // EXPLORATORY (affnet_debug_split3): conv1 .. conv5 on split operands - fp32 = three bf16 terms, six v_mfma_f32_16x16x32_bf16 per
         // 32-channel block (conv3x3_mfma_s3).  Activations stay fp32 in LDS in the layouts of the exact path, so the epilogues are shared; the
         // tilings are chosen so that one split activation fragment (44 VALU instructions) feeds >= 12 MFMAs.
-#define S3_LAYER(CIN_, COUT_, LI_, LO_, STRIDE_, HOUT_, TM_, TN_, IDX_)                                                                  \
-        {                                                                                                                                \
-            f32x4 acc_[TM_][TN_], bias_[TN_];                                                                                            \
-            prefetch_bias<NW, HOUT_, TM_, TN_>(a.packed + a.off.b[IDX_], bias_, wave, lane);                                             \
-            if (PRIO) __builtin_amdgcn_s_setprio(0);                                                                                     \
-            conv3x3_mfma_s3<NW, CIN_, COUT_, LI_, STRIDE_, TM_, TN_>(act, a.packed + a.off.w_s3[IDX_], acc_, wave, lane);               \
-            if (PRIO) __builtin_amdgcn_s_setprio(3);                                                                                     \
-            CNN_STAMP(2 * IDX_ + 1);                                                                                                     \
-            __syncthreads();                                                                                                             \
-            zero_halo<LO_, NTHR>(act, COUT_);                                                                                            \
-            store_tiles_lds<COUT_, LO_, TM_, TN_>(act, bias_, acc_, wave, lane);                                                         \
-            __syncthreads();                                                                                                             \
-            CNN_STAMP(2 * IDX_ + 2);                                                                                                     \
-        }
-        S3_LAYER(CB, CB, LayC0, LayC1, 1, 32, 8, 2, 1)                   // conv1: 32 -> 32 @32x32
-#undef S3_LAYER
-        // conv2 .. conv4 write their outputs PRE-SPLIT (three bf16 planes, LayB): conv3 .. conv5 read ready fragments
-        typedef LayB<16, 18, 2 * CB> LB2;                                // conv2 / conv3 outputs: 64 channels @16x16 (124 KB)
-        typedef LayB<8, 10, 4 * CB> LB4;                                 // conv4 output: 128 channels @8x8 (77 KB)
+        // conv1 .. conv4 write their outputs PRE-SPLIT (three bf16 planes, LayB): conv2 .. conv5 read ready fragments
+        typedef LayB<16, 16, 18, 2 * CB> LB2;                            // conv2 / conv3 outputs: 64 channels @16x16 (124 KB)
+        typedef LayB<8, 8, 10, 4 * CB> LB4;                              // conv4 output: 128 channels @8x8 (77 KB)
         static_assert(LB2::BYTES <= TrunkLds<CB>::ACT * 4 && LB4::BYTES <= TrunkLds<CB>::ACT * 4, "pre-split layouts must fit the activation buffer");
-        {
-            f32x4 acc_[4][2], bias_[2];                                  // conv2: 32 -> 64, stride 2 -> 16x16 (input fp32, split in the loop)
-            prefetch_bias<NW, 16, 4, 2>(a.packed + a.off.b[2], bias_, wave, lane);
+        if constexpr (CB == 32) {
+            // conv0 + conv1 in two half-patch passes: the pre-split conv0 output of 32 channels @32x32 would be 222 KB, half of it (16 rows +
+            // a halo row either side) is 115 KB.  conv1 splits nothing in its loop (the on-the-fly version split every pixel once per tap: 9x).
+            static_assert(LBH::BYTES <= TrunkLds<CB>::ACT * 4, "the half-patch layout must fit the activation buffer");
+            f32x4 acc_a[4][2], acc_b[4][2];
+            prefetch_bias<NW, 32, 8, 2>(a.packed + a.off.b[1], bias1, wave, lane);
+            conv0_half_split<NW, LBH, 2>(patch, w0, bias0, act, 0, wave, lane);
+            __syncthreads();
+            CNN_STAMP(2);
             if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3<NW, CB, 2 * CB, LayC1, 2, 4, 2>(act, a.packed + a.off.w_s3[2], acc_, wave, lane);
+            conv3x3_mfma_s3p<NW, CB, CB, LBH, 1, 4, 2>(act, a.packed + a.off.w_s3[1], acc_a, wave, lane);
+            if (PRIO) __builtin_amdgcn_s_setprio(3);
+            __syncthreads();
+            if (tid < 12 * 32) {                                         // pass 0 left conv0 row 16 in the bottom halo row: zero again
+                char* base = reinterpret_cast<char*>(act);
+                *reinterpret_cast<f32x4*>(base + (tid >> 5) * LBH::GS + (17 * LBH::WP + (tid & 31) + 1) * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            conv0_half_split<NW, LBH, 2>(patch, w0, bias0, act, 1, wave, lane);
+            __syncthreads();
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            conv3x3_mfma_s3p<NW, CB, CB, LBH, 1, 4, 2>(act, a.packed + a.off.w_s3[1], acc_b, wave, lane);
+            if (PRIO) __builtin_amdgcn_s_setprio(3);
+            CNN_STAMP(3);
+            __syncthreads();
+            // conv1's output goes back into the same half layout, pre-split, and conv2 (stride 2: output rows 0 .. 7 read input rows
+            // -1 .. 15, rows 8 .. 15 read 15 .. 31) runs in two passes as well
+            char* base = reinterpret_cast<char*>(act);
+            if (tid < 12 * 32)                                           // pass 1 of conv0 left its row 15 in the top halo row
+                *reinterpret_cast<f32x4*>(base + (tid >> 5) * LBH::GS + ((tid & 31) + 1) * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            store_tiles_split<CB, LBH, 4, 2>(act, bias1, acc_a, wave, lane);
+            f32x4 acc2_a[2][2], acc2_b[2][2], bias2[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bias2[j] = *reinterpret_cast<const f32x4*>(&a.packed[a.off.b[2] + ((wave >> 2) * 2 + j) * 16 + 4 * (lane >> 4)]);
+            __syncthreads();
+            CNN_STAMP(4);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            conv3x3_mfma_s3p<NW, CB, 2 * CB, LBH, 2, 2, 2>(act, a.packed + a.off.w_s3[2], acc2_a, wave, lane);
+            if (PRIO) __builtin_amdgcn_s_setprio(3);
+            __syncthreads();
+            store_tiles_split<CB, LBH, 4, 2>(act, bias1, acc_b, wave, lane);
+            if (wave == 7) {                                             // conv1 row 15 (tiles 2, 3 of wave 7 in pass 0) = the top halo row of pass 1
+                const int n = lane & 15;
+#pragma unroll
+                for (int i = 2; i < 4; ++i) split_store_tile<LBH, 2>(base, ((i - 2) * 16 + n + 1) * 16, 0, bias1, acc_a[i], lane >> 4);
+            }
+            __syncthreads();
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            conv3x3_mfma_s3p<NW, CB, 2 * CB, LBH, 2, 2, 2>(act, a.packed + a.off.w_s3[2], acc2_b, wave, lane);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
             CNN_STAMP(5);
             __syncthreads();
             zero_halo_b<LB2, NTHR>(act);
-            store_tiles_split<2 * CB, LB2, 4, 2>(act, bias_, acc_, wave, lane);
+            store_tiles_split<2 * CB, LB2, 2, 2, 8>(act, bias2, acc2_a, wave, lane, 0);
+            store_tiles_split<2 * CB, LB2, 2, 2, 8>(act, bias2, acc2_b, wave, lane, 8);
             __syncthreads();
             CNN_STAMP(6);
         }
@@ -445,28 +476,46 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
     }
 
     if constexpr (S3 && CB == 16) {
-        // EXPLORATORY (affnet_debug_split3): AffNet / OriNet conv1 .. conv5 on split operands; conv1 / conv2 (16 input channels) take two
-        // taps per k = 32 step (conv3x3_mfma_s3_c16).
+        // EXPLORATORY (affnet_debug_split3): AffNet / OriNet on split operands, same structure as the HardNet branch: conv0 .. conv2 in two
+        // half-patch passes on pre-split layouts (conv1 / conv2 have 16 input channels: two taps per k = 32 step), conv3 .. conv5 whole.
+        typedef LayB<16, 16, 18, 2 * CB> LB2;                            // conv2 / conv3 outputs: 32 channels @16x16 (61 KB)
+        typedef LayB<8, 8, 10, 4 * CB> LB4;                              // conv4 output: 64 channels @8x8 (38 KB)
+        static_assert(LBH::BYTES <= TrunkLds<CB>::ACT * 4 && LB2::BYTES <= TrunkLds<CB>::ACT * 4 && LB4::BYTES <= TrunkLds<CB>::ACT * 4,
+                      "pre-split layouts must fit the activation buffer");
         {
-            f32x4 acc_[8][1], bias_[1];                                  // conv1: 16 -> 16 @32x32
-            prefetch_bias<NW, 32, 8, 1>(a.packed + a.off.b[1], bias_, wave, lane);
-            conv3x3_mfma_s3_c16<NW, CB, LayC0, 1, 8, 1>(act, a.packed + a.off.w_s3[1], acc_, wave, lane);
+            char* base = reinterpret_cast<char*>(act);
+            f32x4 acc_a[4][1], acc_b[4][1];
+            prefetch_bias<NW, 32, 8, 1>(a.packed + a.off.b[1], bias1, wave, lane);
+            conv0_half_split<NW, LBH, 1>(patch, w0, bias0, act, 0, wave, lane);
             __syncthreads();
-            zero_halo<LayC1, NTHR>(act, CB);
-            store_tiles_lds<CB, LayC1, 8, 1>(act, bias_, acc_, wave, lane);
+            conv3x3_mfma_s3p_c16<NW, CB, LBH, 1, 4, 1>(act, a.packed + a.off.w_s3[1], acc_a, wave, lane);
             __syncthreads();
-        }
-        // conv2 .. conv4 write their outputs PRE-SPLIT (three bf16 planes, LayB - see the HardNet branch): no more LDS than the fp32 layouts
-        typedef LayB<16, 18, 2 * CB> LB2;                                // conv2 / conv3 outputs: 32 channels @16x16 (61 KB)
-        typedef LayB<8, 10, 4 * CB> LB4;                                 // conv4 output: 64 channels @8x8 (38 KB)
-        static_assert(LB2::BYTES <= TrunkLds<CB>::ACT * 4 && LB4::BYTES <= TrunkLds<CB>::ACT * 4, "pre-split layouts must fit the activation buffer");
-        {
-            f32x4 acc_[2][2], bias_[2];                                  // conv2: 16 -> 32, stride 2 -> 16x16
-            prefetch_bias<NW, 16, 2, 2>(a.packed + a.off.b[2], bias_, wave, lane);
-            conv3x3_mfma_s3_c16<NW, 2 * CB, LayC1, 2, 2, 2>(act, a.packed + a.off.w_s3[2], acc_, wave, lane);
+            if (tid < 6 * 32)                                            // pass 0 left conv0 row 16 in the bottom halo row: zero again
+                *reinterpret_cast<f32x4*>(base + (tid >> 5) * LBH::GS + (17 * LBH::WP + (tid & 31) + 1) * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            conv0_half_split<NW, LBH, 1>(patch, w0, bias0, act, 1, wave, lane);
+            __syncthreads();
+            conv3x3_mfma_s3p_c16<NW, CB, LBH, 1, 4, 1>(act, a.packed + a.off.w_s3[1], acc_b, wave, lane);
+            __syncthreads();
+            if (tid < 6 * 32)                                            // pass 1 of conv0 left its row 15 in the top halo row
+                *reinterpret_cast<f32x4*>(base + (tid >> 5) * LBH::GS + ((tid & 31) + 1) * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            store_tiles_split<CB, LBH, 4, 1>(act, bias1, acc_a, wave, lane);
+            f32x4 acc2_a[2][1], acc2_b[2][1], bias2[1];
+            bias2[0] = *reinterpret_cast<const f32x4*>(&a.packed[a.off.b[2] + (wave >> 2) * 16 + 4 * (lane >> 4)]);
+            __syncthreads();
+            conv3x3_mfma_s3p_c16<NW, 2 * CB, LBH, 2, 2, 1>(act, a.packed + a.off.w_s3[2], acc2_a, wave, lane);
+            __syncthreads();
+            store_tiles_split<CB, LBH, 4, 1>(act, bias1, acc_b, wave, lane);
+            if (wave == 7) {                                             // conv1 row 15 (tiles 2, 3 of wave 7 in pass 0) = the top halo row of pass 1
+                const int n = lane & 15;
+#pragma unroll
+                for (int i = 2; i < 4; ++i) split_store_tile<LBH, 1>(base, ((i - 2) * 16 + n + 1) * 16, 0, bias1, acc_a[i], lane >> 4);
+            }
+            __syncthreads();
+            conv3x3_mfma_s3p_c16<NW, 2 * CB, LBH, 2, 2, 1>(act, a.packed + a.off.w_s3[2], acc2_b, wave, lane);
             __syncthreads();
             zero_halo_b<LB2, NTHR>(act);
-            store_tiles_split<2 * CB, LB2, 2, 2>(act, bias_, acc_, wave, lane);
+            store_tiles_split<2 * CB, LB2, 2, 1, 8>(act, bias2, acc2_a, wave, lane, 0);
+            store_tiles_split<2 * CB, LB2, 2, 1, 8>(act, bias2, acc2_b, wave, lane, 8);
             __syncthreads();
         }
         {

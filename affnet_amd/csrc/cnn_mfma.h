@@ -333,11 +333,16 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct Split3 { bf16x8 t[3]; };
 
 // Exact remainder of a pair after its bf16 roundings u = (bf16(v.x), bf16(v.y)): v_dot2c_f32_bf16 with the constant pair (-1, 0) /
-// (0, -1) is  v.x - float(u.lo) + 0 * float(u.hi)  in one full-rate instruction (vs shift / mask + packed subtract, 8 issue cycles
-// per pair): the difference is representable, so the rounding mode does not matter; checked bit-for-bit against the shift / subtract
-// form on 2^24 random bit patterns incl. denormals (tools/_tmp probe, round 3) - they differ only where bf16(v) overflows to inf.
-// The constants come from s_mov through an asm so that the compiler cannot fold them into an inline operand: it encodes the packed
-// bf16 (-1, 0) as the inline constant -1.0, which the hardware does not read as bf16 (the low-half remainders came out unchanged).
+// (0, -1) is  v.x - float(u.lo) + 0 * float(u.hi)  in one instruction; the difference is representable, so the rounding mode does not
+// matter.  Checked bit-for-bit against the shift / subtract form on 2^24 random bit patterns incl. denormals - they differ only where
+// bf16(v) overflows to inf.  The constants come from s_mov through an asm so that the compiler cannot fold them into an inline
+// operand: it encodes the packed bf16 (-1, 0) as the inline constant -1.0, which the hardware does not read as bf16 (the low-half
+// remainders came out unchanged).
+// Measured alternatives inside the MFMA loops (HardNet conv1, cycles of the slower wave of a SIMD): shift / mask + v_pk_add_f32 54.9 k,
+// this form 48.8 k, shift / mask + two unpacked v_sub_f32 50.2 k.  tools/probes/mfma_valu_overlap.hip shows why none of them hides
+// under the matrix pipe: with two waves per SIMD, 12 bf16 MFMAs + 36 VALU instructions take 528-553 cycles for v_fmac / v_cvt_pk /
+// v_lshlrev (MFMAs alone 428, the VALU alone 190-330) and ~1000 cycles for v_dot2c / v_pk_add_f32 - VALU work next to bf16 MFMAs is at
+// best half hidden, so the remedy is not to have it in the loop (pre-split layouts below).
 __device__ __forceinline__ void split_remainder(f32x2& v, unsigned u) {
     unsigned c0, c1;
     asm("s_mov_b32 %0, 0xbf80" : "=s"(c0));
@@ -398,22 +403,40 @@ __device__ __forceinline__ void conv3x3_mfma_s3(const float* act, const float* _
             for (int j = 0; j < TN; ++j)
                 dst[t][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_lane + j * 256, ((s * 3 + t) * 4 * COUT) * 16, 0));
     };
-    auto step = [&](const bf16x8 (&wc)[3][TN], int s) {
+    // Software pipeline over the flat tile sequence (step s, tile i): while tile q's 6 TN MFMAs issue, the VALU splits tile q + 1
+    // (its raw fp32 fragment arrived one tile earlier) and the LDS reads for tile q + 2 are in flight.  One MFMA occupies the matrix
+    // pipe for 16 cycles and its issue takes 4, so up to three VALU instructions fit under each - the ~30 of a split hide under 12
+    // MFMAs.  The first version ran read -> wait -> split -> MFMAs per tile, i.e. the wave's own matrix pipe idled during every split.
+    static_assert(TM >= 2, "the pipeline looks two tiles ahead");
+    auto frag_addr = [&](int s) {
         const int tap = s / NG32, G = s - tap * NG32;
         const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
-        const unsigned ab = a_addr0 + (8 * G * LI::PSG + (ky * LI::WP + kx) * 4) * 4;
+        return a_addr0 + (8 * G * LI::PSG + (ky * LI::WP + kx) * 4) * 4;
+    };
+    Split3 cur;
+    f32x4 rlo, rhi;
+    {
+        const unsigned ab = frag_addr(0);
+        cur = split3_rne(lds_read4(ab + a_imm(0)), lds_read4(ab + a_imm(0) + LI::PSG * 4));
+        rlo = lds_read4(ab + a_imm(1)); rhi = lds_read4(ab + a_imm(1) + LI::PSG * 4);
+    }
+    auto step = [&](const bf16x8 (&wc)[3][TN], int s) {
+        const unsigned ab0 = frag_addr(s), ab1 = frag_addr(s + 1 < NS ? s + 1 : s);      // past the end: harmless re-reads
+        constexpr int TW[6] = {0, 1, 2, 0, 1, 0}, TA[6] = {2, 1, 0, 1, 0, 0};            // smallest terms first
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const f32x4 lo = lds_read4(ab + a_imm(i)), hi = lds_read4(ab + a_imm(i) + LI::PSG * 4);
-            const Split3 a = split3_rne(lo, hi);
-            // smallest terms first: (0,2) (1,1) (2,0), then (0,1) (1,0), then (0,0); the channel tiles alternate inside a term so that
-            // consecutive MFMAs do not wait on one accumulator
-            constexpr int TW[6] = {0, 1, 2, 0, 1, 0}, TA[6] = {2, 1, 0, 1, 0, 0};
+            const unsigned ad2 = (i + 2 < TM) ? ab0 + a_imm(i + 2) : ab1 + a_imm(i + 2 - TM);
+            const f32x4 lo2 = lds_read4(ad2), hi2 = lds_read4(ad2 + LI::PSG * 4);
+            const Split3 nxt = split3_rne(rlo, rhi);
 #pragma unroll
             for (int t = 0; t < 6; ++t)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[TW[t]][j], a.t[TA[t]], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[TW[t]][j], cur.t[TA[t]], acc[i][j], 0, 0, 0);
+            cur = nxt; rlo = lo2; rhi = hi2;
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // reads of tile q + 2
+            __builtin_amdgcn_sched_group_barrier(0x002, 48, 0);     // split of tile q + 1 as one VALU burst ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 6 * TN, 0); // ... then the MFMA burst of tile q (the SIMD's other wave fills the gaps)
         }
     };
     load_w(w[0], 0);
@@ -434,9 +457,9 @@ __device__ __forceinline__ void conv3x3_mfma_s3(const float* act, const float* _
 // splits every output element once and the next layer reads ready bf16 fragments: element (term t, channel c, y, x) of an H x H layer
 // sits at  t * TS + (c / 8) * GS + ((y + 1) * WP + x + 1) * 16 + (c % 8) * 2  bytes - one ds_read_b128 = the 8 channels of one term
 // of one pixel = a lane's B fragment of a k = 32 step.
-template <int H_, int WP_, int C_>
+template <int H_, int W_, int WP_, int C_>
 struct LayB {
-    static constexpr int H = H_, WP = WP_, C = C_;
+    static constexpr int H = H_, W = W_, WP = WP_, C = C_;      // H rows x W columns (+ a one-cell halo), row stride WP cells
     static constexpr int GS = (H_ + 2) * WP_ * 16;        // bytes per 8-channel group
     static constexpr int TS = (C_ / 8) * GS;              // bytes per term
     static constexpr int BYTES = 3 * TS;
@@ -444,54 +467,61 @@ struct LayB {
 
 template <typename L, int NTHR>
 __device__ __forceinline__ void zero_halo_b(float* act, int tid = threadIdx.x) {
-    constexpr int H = L::H, CELLS = 4 * (H + 1), PLANES = 3 * (L::C / 8);
+    constexpr int H = L::H, W = L::W, CELLS = 2 * (W + 2) + 2 * H, PLANES = 3 * (L::C / 8);
     char* base = reinterpret_cast<char*>(act);
     for (int i = tid; i < PLANES * CELLS; i += NTHR) {
         const int g = i / CELLS, e = i - g * CELLS;      // g = term * (C / 8) + group: planes are contiguous (TS = groups * GS)
         int y, x;
-        if (e < H + 2) { y = 0; x = e; }
-        else if (e < 2 * (H + 2)) { y = H + 1; x = e - (H + 2); }
-        else { const int r = e - 2 * (H + 2); y = 1 + (r >> 1); x = (r & 1) ? H + 1 : 0; }
+        if (e < W + 2) { y = 0; x = e; }
+        else if (e < 2 * (W + 2)) { y = H + 1; x = e - (W + 2); }
+        else { const int r = e - 2 * (W + 2); y = 1 + (r >> 1); x = (r & 1) ? W + 1 : 0; }
         *reinterpret_cast<f32x4*>(base + (size_t)g * L::GS + (y * L::WP + x) * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 }
 
-// Epilogue: + bias, ReLU, split into three bf16 terms, store into layout LO (lane: pixel n of the tile, channels 4 g .. 4 g + 3 of N-tile)
-template <int COUT, typename LO, int TM, int TN>
-__device__ __forceinline__ void store_tiles_split(float* act, const f32x4 (&bias)[TN], const f32x4 (&acc)[TM][TN], int wave, int lane) {
-    constexpr int HOUT = LO::H;
-    constexpr int MT = HOUT * HOUT / 16, MG = MT / TM;
+// (+ bias,) ReLU, split into three bf16 terms and store ONE pixel tile: the lane's pixel sits at byte offset `cell` of a plane, its
+// four channels are 4 g .. 4 g + 3 of channel tiles nt0 .. nt0 + TN - 1
+template <typename LO, int TN, bool ADD_BIAS = true>
+__device__ __forceinline__ void split_store_tile(char* base, int cell, int nt0, const f32x4 (&bias)[TN], const f32x4 (&acc)[TN], int g) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        f32x4 v = acc[j];
+        if (ADD_BIAS) v += bias[j];
+        v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+        const int c0 = (nt0 + j) * 16 + 4 * g;                           // first of this lane's 4 channels
+        char* dst = base + (c0 >> 3) * LO::GS + cell + (c0 & 4) * 2;
+        f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const unsigned u0 = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
+            const unsigned u1 = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
+            *reinterpret_cast<uint2*>(dst + t * LO::TS) = make_uint2(u0, u1);
+            if (t < 2) { split_remainder(lo, u0); split_remainder(hi, u1); }
+        }
+    }
+}
+
+// Epilogue of a layer whose output goes to a pre-split layout LO: the waves' tiles cover HT rows (default: all of LO) starting at row_off
+template <int COUT, typename LO, int TM, int TN, int HT = LO::H>
+__device__ __forceinline__ void store_tiles_split(float* act, const f32x4 (&bias)[TN], const f32x4 (&acc)[TM][TN], int wave, int lane, int row_off = 0) {
+    constexpr int W = LO::W;
+    constexpr int MT = HT * W / 16, MG = MT / TM;
     const int mg = wave % MG, ng = wave / MG;
     const int n = lane & 15, g = lane >> 4;
     char* base = reinterpret_cast<char*>(act);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int p = (mg * TM + i) * 16 + n;
-        const int oy = p / HOUT, ox = p - oy * HOUT;
-        const int cell = ((oy + 1) * LO::WP + ox + 1) * 16;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            f32x4 v = acc[i][j] + bias[j];
-            v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
-            const int c0 = (ng * TN + j) * 16 + 4 * g;                   // first of this lane's 4 channels
-            char* dst = base + (c0 >> 3) * LO::GS + cell + (c0 & 4) * 2;
-            f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const unsigned u0 = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
-                const unsigned u1 = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
-                *reinterpret_cast<uint2*>(dst + t * LO::TS) = make_uint2(u0, u1);
-                if (t < 2) { split_remainder(lo, u0); split_remainder(hi, u1); }
-            }
-        }
+        const int oy = p / W, ox = p - oy * W;
+        split_store_tile<LO, TN>(base, ((oy + row_off + 1) * LO::WP + ox + 1) * 16, ng * TN, bias, acc[i], g);
     }
 }
 
 // The contraction on a PRE-SPLIT input (layout LI = LayB): no VALU in the loop - three ds_read_b128 per pixel tile and k = 32 step.
 template <int NW, int CIN, int COUT, typename LI, int STRIDE, int TM, int TN>
 __device__ __forceinline__ void conv3x3_mfma_s3p(const float* act, const float* __restrict__ Ws, f32x4 (&acc)[TM][TN], int wave, int lane) {
-    constexpr int HOUT = LI::H / STRIDE;
-    constexpr int MT = HOUT * HOUT / 16, NT = COUT / 16;
+    constexpr int HOUT = LI::H / STRIDE, WOUT = LI::W / STRIDE;
+    constexpr int MT = HOUT * WOUT / 16, NT = COUT / 16;
     constexpr int MG = MT / TM, NG = NT / TN;
     constexpr int NG32 = CIN / 32, NS = 9 * NG32;
     static_assert(MG * NG == NW && CIN % 32 == 0 && LI::C == CIN, "bad tiling for the split-operand loop");
@@ -500,11 +530,11 @@ __device__ __forceinline__ void conv3x3_mfma_s3p(const float* act, const float* 
     int a_lane;                                                            // bytes
     {
         const int p = mg * TM * 16 + m;
-        const int oy = p / HOUT, ox = p - oy * HOUT;
+        const int oy = p / WOUT, ox = p - oy * WOUT;
         a_lane = kq * LI::GS + ((oy * STRIDE) * LI::WP + ox * STRIDE) * 16;
     }
     const unsigned a_addr0 = lds_byte_addr(act) + a_lane;
-    auto a_imm = [](int i) { return 16 * (HOUT == 8 ? i * 2 * STRIDE * LI::WP : (((i * 16) / HOUT) * STRIDE * LI::WP + ((i * 16) % HOUT) * STRIDE)); };
+    auto a_imm = [](int i) { return 16 * (WOUT == 8 ? i * 2 * STRIDE * LI::WP : (((i * 16) / WOUT) * STRIDE * LI::WP + ((i * 16) % WOUT) * STRIDE)); };
     constexpr int WS_FLOATS = 9 * (CIN / 32) * 3 * 4 * COUT * 4;
     const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(Ws, WS_FLOATS);
     const int w_lane = (kq * COUT + ng * TN * 16 + m) * 16;
@@ -562,6 +592,69 @@ __device__ __forceinline__ void conv3x3_mfma_s3p(const float* act, const float* 
     if (NS & 1) step(w[0], NS - 1);
 }
 
+// Pre-split input with 16 channels (AffNet / OriNet conv1, conv2): one k = 32 step = two taps x 16 channels as in conv3x3_mfma_s3_c16
+// (lane group kq: tap 2 s + (kq >> 1), channel group kq & 1), fragments read ready from a LayB layout with the rotating schedule.
+template <int NW, int COUT, typename LI, int STRIDE, int TM, int TN>
+__device__ __forceinline__ void conv3x3_mfma_s3p_c16(const float* act, const float* __restrict__ Ws, f32x4 (&acc)[TM][TN], int wave, int lane) {
+    constexpr int HOUT = LI::H / STRIDE, WOUT = LI::W / STRIDE;
+    constexpr int MT = HOUT * WOUT / 16, NT = COUT / 16;
+    constexpr int MG = MT / TM, NG = NT / TN;
+    static_assert(MG * NG == NW && LI::C == 16, "bad tiling for the split-operand loop");
+    const int mg = wave % MG, ng = wave / MG;
+    const int m = lane & 15, kq = lane >> 4;
+    int a_lane;                                                            // bytes
+    {
+        const int p = mg * TM * 16 + m;
+        const int oy = p / WOUT, ox = p - oy * WOUT;
+        a_lane = (kq & 1) * LI::GS + ((oy * STRIDE) * LI::WP + ox * STRIDE) * 16;
+    }
+    const unsigned a_addr0 = lds_byte_addr(act) + a_lane;
+    auto a_imm = [](int i) { return 16 * (WOUT == 8 ? i * 2 * STRIDE * LI::WP : (((i * 16) / WOUT) * STRIDE * LI::WP + ((i * 16) % WOUT) * STRIDE)); };
+    constexpr int WS_FLOATS = 5 * 3 * 4 * COUT * 4;
+    const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(Ws, WS_FLOATS);
+    const int w_lane = (kq * COUT + ng * TN * 16 + m) * 16;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto frag_addr = [&](int s) {
+        const int ta = 2 * s, tb = (2 * s + 1 < 9) ? 2 * s + 1 : 8;                   // the pad half-step re-reads tap 8 (times zero weights)
+        const int off_a = ((ta / 3) * LI::WP + ta % 3) * 16, off_b = ((tb / 3) * LI::WP + tb % 3) * 16;
+        return a_addr0 + ((kq >> 1) ? off_b : off_a);
+    };
+    bf16x8 a[TM][3];
+    auto read_tile = [&](unsigned ab, int i) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) a[i][t] = __builtin_bit_cast(bf16x8, lds_read4(ab + a_imm(i) + t * LI::TS));
+    };
+#pragma unroll
+    for (int i = 0; i < TM; ++i) read_tile(frag_addr(0), i);
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        bf16x8 w[3][TN];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                w[t][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_lane + j * 256, ((s * 3 + t) * 4 * COUT) * 16, 0));
+        const unsigned abn = frag_addr(s + 1 < 5 ? s + 1 : s);
+        constexpr int TW[6] = {0, 1, 2, 0, 1, 0}, TA[6] = {2, 1, 0, 1, 0, 0};
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[TW[t]][j], a[i][TA[t]], acc[i][j], 0, 0, 0);
+            if (s + 1 < 5) {
+                read_tile(abn, i);
+                __builtin_amdgcn_sched_group_barrier(0x008, 6 * TN, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            }
+        }
+    }
+}
+
 // 16 input channels: one k = 32 step = TWO taps x 16 channels (lane group kq: tap 2 s + (kq >> 1), channels 8 (kq & 1) .. + 7); the nine taps
 // take five steps, the tenth half-step multiplies zero weights.  Ws [step][term][kq][COUT][8 bf16].
 template <int NW, int COUT, typename LI, int STRIDE, int TM, int TN>
@@ -587,6 +680,20 @@ __device__ __forceinline__ void conv3x3_mfma_s3_c16(const float* act, const floa
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // same software pipeline as conv3x3_mfma_s3: MFMAs of tile q | split of tile q + 1 | LDS reads of tile q + 2
+    static_assert(TM >= 2, "the pipeline looks two tiles ahead");
+    auto frag_addr = [&](int s) {
+        const int ta = 2 * s, tb = (2 * s + 1 < 9) ? 2 * s + 1 : 8;                   // the pad half-step re-reads tap 8 (times zero weights)
+        const int off_a = ((ta / 3) * LI::WP + ta % 3) * 16, off_b = ((tb / 3) * LI::WP + tb % 3) * 16;      // bytes
+        return a_addr0 + ((kq >> 1) ? off_b : off_a);
+    };
+    Split3 cur;
+    f32x4 rlo, rhi;
+    {
+        const unsigned ab = frag_addr(0);
+        cur = split3_rne(lds_read4(ab + a_imm(0)), lds_read4(ab + a_imm(0) + LI::PSG * 4));
+        rlo = lds_read4(ab + a_imm(1)); rhi = lds_read4(ab + a_imm(1) + LI::PSG * 4);
+    }
 #pragma unroll
     for (int s = 0; s < 5; ++s) {
         bf16x8 w[3][TN];
@@ -595,22 +702,22 @@ __device__ __forceinline__ void conv3x3_mfma_s3_c16(const float* act, const floa
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 w[t][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_lane + j * 256, ((s * 3 + t) * 4 * COUT) * 16, 0));
-        const int ta = 2 * s, tb = (2 * s + 1 < 9) ? 2 * s + 1 : 8;                   // the pad half-step re-reads tap 8 (times zero weights)
-        const int off_a = ((ta / 3) * LI::WP + ta % 3) * 16, off_b = ((tb / 3) * LI::WP + tb % 3) * 16;      // bytes
-        const unsigned ab = a_addr0 + ((kq >> 1) ? off_b : off_a);
+        const unsigned ab0 = frag_addr(s), ab1 = frag_addr(s + 1 < 5 ? s + 1 : s);
+        constexpr int TW[6] = {0, 1, 2, 0, 1, 0}, TA[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const f32x4 lo = lds_read4(ab + a_imm(i)), hi = lds_read4(ab + a_imm(i) + LI::PSG * 4);
-            const Split3 a = split3_rne(lo, hi);
+            const unsigned ad2 = (i + 2 < TM) ? ab0 + a_imm(i + 2) : ab1 + a_imm(i + 2 - TM);
+            const f32x4 lo2 = lds_read4(ad2), hi2 = lds_read4(ad2 + LI::PSG * 4);
+            const Split3 nxt = split3_rne(rlo, rhi);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0][j], a.t[2], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1][j], a.t[1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[2][j], a.t[0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0][j], a.t[1], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[1][j], a.t[0], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[0][j], a.t[0], acc[i][j], 0, 0, 0);
-            }
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[TW[t]][j], cur.t[TA[t]], acc[i][j], 0, 0, 0);
+            cur = nxt; rlo = lo2; rhi = hi2;
+            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // reads of tile q + 2
+            __builtin_amdgcn_sched_group_barrier(0x002, 48, 0);     // split of tile q + 1 as one VALU burst ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 6 * TN, 0); // ... then the MFMA burst of tile q (the SIMD's other wave fills the gaps)
         }
     }
 }
@@ -741,6 +848,59 @@ __device__ __forceinline__ void conv0_mfma(const float* patch, const float (&b)[
         for (int s3 = 0; s3 < 3; ++s3)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s3][j], av[s3], acc[i][j], 0, 0, 0);
+    }
+}
+
+// conv0 of HALF a 32 x 32 patch straight into a pre-split layout LBH (16 rows + halo rows, 32 columns): pass 0 = rows 0 .. 15 plus row
+// 16 into the bottom halo row, pass 1 = rows 16 .. 31 plus row 15 into the top halo row.  34 tiles of 16 pixels over 8 waves: four each
+// and one of the two extra-row tiles (computed by four waves each, identical values).
+template <int NW, typename LBH, int TN>
+__device__ __forceinline__ void conv0_half_split(const float* patch, const float (&b)[3][TN], const f32x4 (&bv)[TN], float* act, int pass,
+                                                 int wave, int lane) {
+    static_assert(NW == 8 && LBH::H == 16 && LBH::W == 32 && LBH::C == 16 * TN, "half-patch conv0: 8 waves, all channel tiles in every wave");
+    const int m = lane & 15, kq = lane >> 4;
+    int toff[3];
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+        const int t = 4 * s3 + kq;
+        toff[s3] = t < 9 ? (t / 3) * WP32 + (t % 3) : 0;
+    }
+    char* base = reinterpret_cast<char*>(act);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        int row_l, x0;
+        if (k < 4) { const int T = 4 * wave + k; row_l = T >> 1; x0 = (T & 1) * 16; }
+        else { row_l = pass ? -1 : 16; x0 = (wave & 1) * 16; }
+        const int pb = (row_l + 16 * pass) * WP32 + x0 + m;
+        float av[3];
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) av[s3] = patch[pb + toff[s3]];
+        f32x4 acc[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[j] = bv[j];
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s3][j], av[s3], acc[j], 0, 0, 0);
+        split_store_tile<LBH, TN, false>(base, ((row_l + 1) * LBH::WP + x0 + m + 1) * 16, 0, bv, acc, kq);
+    }
+}
+
+// fp32 epilogue of a half-patch layer (tiles cover 16 rows x 32 columns, all channel tiles in one wave): + bias, ReLU, rows row_off ..
+template <typename LO, int TM, int TN>
+__device__ __forceinline__ void store_half_lds(float* act, const f32x4 (&bias)[TN], const f32x4 (&acc)[TM][TN], int wave, int lane, int row_off) {
+    const int n = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int p = (wave * TM + i) * 16 + n;
+        const int oy = (p >> 5) + row_off, ox = p & 31;
+        const int pbase = ((oy + 1) * LO::WP + ox + 1) * 4;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            f32x4 v = acc[i][j] + bias[j];
+            v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+            *reinterpret_cast<f32x4*>(&act[(j * 4 + g) * LO::PSG + pbase]) = v;
+        }
     }
 }
 

@@ -1,0 +1,29 @@
+#!/usr/bin/env python
+"""Wall time of each trunk alone on 48000 patches, exact fp32 vs the EXPLORATORY split-operand path (min of 5 launches each)."""
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import affnet_amd
+from affnet_amd._lib import lib
+from affnet_amd import engine
+
+dev = torch.device("cuda:0")
+A = affnet_amd.AffNetFast(); A.load_state_dict(torch.load(os.path.join(ROOT, "pretrained/AffNet.pth"), map_location="cpu", weights_only=False)["state_dict"]); A.to(dev)
+O = affnet_amd.OriNetFast(PS=32); O.load_state_dict(torch.load(os.path.join(ROOT, "pretrained/OriNet.pth"), map_location="cpu", weights_only=False)["state_dict"]); O.to(dev)
+H = affnet_amd.HardNet(); H.load_state_dict(affnet_amd.synthetic_hardnet_state(0)); H.to(dev)
+big = (torch.rand(48000, 1, 32, 32) * 255).to(dev)
+ctx = engine.utility_ctx(dev)
+for split in (0, 1, 0, 1):
+    lib.affnet_debug_split3(ctx, split)
+    row = []
+    for nm, net in (("AffNet", A), ("OriNet", O), ("HardNet", H)):
+        net(big); torch.cuda.synchronize()
+        best = 1e9
+        for _ in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); net(big); e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1))
+        row.append("%s %.3f ms" % (nm, best))
+    print("split3" if split else "exact ", " | ".join(row))
+lib.affnet_debug_split3(ctx, 0)
