@@ -44,6 +44,7 @@ H, W, NKP, BATCH = 768, 1024, 2000, 64
 FLOP_AFF, FLOP_ORI, FLOP_HARD = 19193856.0, 19316736.0, 78184448.0
 FLOP_HARD_HEAD = 2.0 * 8192 * 128
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
+PEAK_BF16_MFMA_TFLOPS = 16 * 157.3  # MI355X_MICROARCH.md: bf16 MFMA = 16x the fp32 matrix rate (~2.5 PF dense); EXPLORATORY --split3 line only
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; ~6.3 TB/s achievable)
 GRAF = os.path.join(ROOT, "tests", "golden", "graf_img1.png")
 
@@ -738,6 +739,15 @@ def run(args, world):
                          "affnet_tflops": aff_eval_per_img * FLOP_AFF / (max(stage_ms[2], 1e-9) * 1e-3) / 1e12,
                          "orinet_tflops": kp_per_img * FLOP_ORI / (max(stage_ms[4], 1e-9) * 1e-3) / 1e12},
         }
+        if args.split3:
+            # the split-operand trunk executes SIX bf16 MFMA products per fp32 product (conv0 stays fp32): priced against the bf16 peak
+            f_conv0 = kp_per_img * img_per_launch * 2.0 * 1024 * 9 * 32
+            bf16_tf = 6.0 * (flops_launch - f_conv0) / (trunk_ms * 1e-3) / 1e12 if trunk_ms > 0 else 0.0
+            out["roofline"].update({
+                "kernel": "cnn32_trunk_kernel<HardNet, split operands> (conv1..conv5: 6 x v_mfma_f32_16x16x32_bf16 per fp32 product, fp32 accumulate; conv0 fp32 MFMA)",
+                "achieved": bf16_tf, "peak": PEAK_BF16_MFMA_TFLOPS, "frac": bf16_tf / PEAK_BF16_MFMA_TFLOPS,
+                "fp32_equivalent_tflops": achieved, "fp32_equivalent_vs_fp32_mfma_peak": achieved / PEAK_FP32_MFMA_TFLOPS,
+                "note": "EXPLORATORY line: executed bf16 matrix FLOPs (6 per algorithmic fp32 FLOP) against the dense bf16 MFMA peak"})
         if exchange is not None:
             out["exchange"] = exchange
         if gather_check is not None:
@@ -755,16 +765,17 @@ def run(args, world):
             try:
                 for d in dets.values():
                     _lib.check(_lib.lib.affnet_debug_split3(d._ctx.handle, 1), d._ctx.handle, "debug_split3")
-                step(); drain()
+                n3 = 8
+                step(); step(); drain()
                 kp_dev.zero_()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                for _ in range(3):
+                for _ in range(n3):
                     last_s3 = step()
                 drain()
                 dt3 = time.perf_counter() - t1
                 out["split3_exploratory"] = {
-                    "value": int(kp_dev.item()) / dt3, "unit": "keypoints/s", "steps": 3, "ms_per_image": dt3 / (3 * args.batch) * 1e3,
+                    "value": int(kp_dev.item()) / dt3, "unit": "keypoints/s", "steps": n3, "ms_per_image": dt3 / (n3 * args.batch) * 1e3,
                     "dtype": "f32 (3xbf16 split operands, fp32 accumulate) in every 3x3 conv layer of AffNet / OriNet / HardNet but conv0; f32 MFMA elsewhere",
                     "vs_value": int(kp_dev.item()) / dt3 / (kps / tmax),
                     "note": "EXPLORATORY, never the headline: exact fp32 operands split into three bf16 terms, six v_mfma_f32_16x16x32_bf16 per "

@@ -1043,9 +1043,9 @@ def test_many_exact_ties_stay_cheap_and_deterministic(amd):
 
 
 def test_exploratory_split3_same_bars_as_the_exact_path(amd, nets, weights, golden_dir):
-    """EXPLORATORY (never the default; affnet_debug_split3 / bench.py --split3): every CNN layer with >= 32 input channels (HardNet conv1..5,
-    AffNet / OriNet conv3..5) on split operands - fp32 = three bf16 terms, six v_mfma_f32_16x16x32_bf16 per 32-channel block, fp32
-    accumulate.  The SAME bars as the exact-fp32 path, against the oracle and the reference's golden output: the metric's configuration
+    """EXPLORATORY (never the default; affnet_debug_split3 / bench.py --split3): every 3x3 conv layer of the three trunks but conv0 on split
+    operands - fp32 = three bf16 terms, six v_mfma_f32_16x16x32_bf16 per 32-channel block, fp32 accumulate, activations pre-split into bf16
+    planes in LDS (conv0 .. conv2 in two half-patch passes).  The SAME bars as the exact-fp32 path, against the oracle and the reference's golden output: the metric's configuration
     (1024 x 768, 2000 kp), graf img1 and the small synthetic case; and the distance to the exact path's own output."""
     from affnet_amd._lib import lib
     A, O, H = nets
@@ -1070,6 +1070,33 @@ def test_exploratory_split3_same_bars_as_the_exact_path(amd, nets, weights, gold
     record_parity("EXPLORATORY split3 vs the exact-fp32 path, 320x240, 300 kp", matched=int(len(gi)), rows=int(exact["LAFs"].shape[0]), laf_max_px=dl, desc_max=dd)
     print("split3 vs exact fp32 path: %d / %d rows, LAF max %.3g px, descriptor max %.3g" % (len(gi), exact["LAFs"].shape[0], dl, dd))
     assert len(gi) >= 299 and dd > 0.0 and dd < 1e-4 and dl < 1e-3
+
+
+def test_exploratory_split3_trunks_vs_exact_trunks(amd, nets):
+    """EXPLORATORY: each trunk alone on random patches (incl. a ragged count), split operands vs the exact fp32 MFMA path: the two differ
+    like one fp32 summation order from another.  Catches layout slips of the pre-split / half-patch layers (halo rows, the conv1 row kept
+    for the second conv2 pass) that a loose end-to-end bar could hide."""
+    from affnet_amd._lib import lib
+    from affnet_amd import engine
+    A, O, H = nets
+    ctx = engine.utility_ctx(torch.device(DEV))
+    g = torch.Generator().manual_seed(7)
+    for n in (1, 257, 3000):
+        p = (torch.rand(n, 1, 32, 32, generator=g) * 255).to(DEV)
+        p[0, 0, :16] = 0.0                                            # a half-constant patch: exact zeros through ReLU in one half
+        exact = [net(p).clone() for net in (A, O, H)]
+        assert lib.affnet_debug_split3(ctx, 1) == 0
+        try:
+            split = [net(p).clone() for net in (A, O, H)]
+        finally:
+            lib.affnet_debug_split3(ctx, 0)
+        again = [net(p) for net in (A, O, H)]
+        # OriNet returns the rotation of atan2(o): a short output vector o amplifies a 1e-7 difference (same effect as in the parity report)
+        for nm, e, s_, a2, bar in zip(("AffNet", "OriNet", "HardNet"), exact, split, again, (2e-5, 5e-3, 1e-5)):
+            d = float((e - s_).abs().max())
+            record_parity("EXPLORATORY split3 trunk vs exact trunk: %s, %d random patches" % (nm, n), max_abs=d)
+            assert torch.equal(e, a2), "switching the exploratory path off must restore the exact path bit for bit"
+            assert 0.0 < d < bar or (n == 1 and d < bar), (nm, n, d)
 
 
 @pytest.mark.parametrize("ranks,gather", [(2, "all"), (3, "rank0")])
