@@ -41,4 +41,12 @@ json.dump(out, open("profiles/%s_sampler_traffic.json" % t, "w"), indent=1)
 print(json.dumps(out["launches"], indent=1)[:600])
 PY
 fi
+# EXPLORATORY split-operand path
+grep '^{' gpurun_out/bench_split3.log > profiles/${T}_split3_bench.json
+grep '^{' gpurun_out/bench_config2_split3.log > profiles/${T}_split3_bench_config2_latency.json
+cp gpurun_out/prof_split3/run_kernel_stats.csv profiles/${T}_split3_kernel_stats.csv
+(cat gpurun_out/split3_phase_timing.txt; echo; cat gpurun_out/split3_net_timing.txt) | grep -v amdgpu.ids > profiles/${T}_split3_phase_and_net_timing.txt
+[ -f gpurun_out/pmc_split3_summary.txt ] && cp gpurun_out/pmc_split3_summary.txt profiles/${T}_split3_pmc_summary.txt
+cp gpurun_out/mfma_valu_overlap.txt profiles/${T}_mfma_valu_overlap_probe.txt
+grep -v "^ *value" gpurun_out/clock_watch.txt > profiles/${T}_clock_power_exact_vs_split3.txt; grep "value" gpurun_out/clock_watch.txt >> profiles/${T}_clock_power_exact_vs_split3.txt
 ls -la profiles/${T}_*

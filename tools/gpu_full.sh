@@ -25,6 +25,19 @@ CMD="python bench.py --steps 1 --warmup 1 --batch 64 --chunk 32 --no-cpu-baselin
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o run -- $CMD > gpurun_out/prof.log 2>&1; echo "prof exit: $?"
 f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -n 12 "$f" | cut -c1-200
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_onepass -o run -- python bench.py --onepass --steps 1 --warmup 1 > gpurun_out/prof_onepass.log 2>&1; echo "prof onepass exit: $?"
+# EXPLORATORY split-operand path (never `value`): its own bench lines, kernel stats, matrix-pipe PMC pass, phase / per-net timings, the
+# MFMA / VALU overlap probe and the clock / power watch
+timeout 300 python bench.py --split3 --no-cpu-baseline --no-secondary > gpurun_out/bench_split3.log 2>&1; echo "split3 exit: $?"; grep '^{' gpurun_out/bench_split3.log | cut -c1-300
+timeout 300 python bench.py --config2 --split3 > gpurun_out/bench_config2_split3.log 2>&1; echo "config2 split3 exit: $?"; grep '^{' gpurun_out/bench_config2_split3.log | cut -c1-300
+timeout 200 python tools/s3_phase_timing.py > gpurun_out/split3_phase_timing.txt 2>&1; tail -n 14 gpurun_out/split3_phase_timing.txt
+timeout 200 python tools/s3_net_timing.py > gpurun_out/split3_net_timing.txt 2>&1; tail -n 4 gpurun_out/split3_net_timing.txt
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_split3 -o run -- python bench.py --split3 --steps 1 --warmup 1 --batch 64 --chunk 32 --no-cpu-baseline --no-secondary > gpurun_out/prof_split3.log 2>&1; echo "prof split3 exit: $?"
+if [ "$SKIP_PMC" != "1" ]; then
+  timeout 300 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT --output-format csv -d gpurun_out/pmc_split3 -o run -- python bench.py --split3 --steps 1 --warmup 1 --batch 64 --chunk 32 --no-cpu-baseline --no-secondary > gpurun_out/pmc_split3.log 2>&1; echo "pmc split3 exit $?"
+  python tools/pmc_biggest.py $(dirname $(find gpurun_out/pmc_split3 -name run_counter_collection.csv | head -1)) 'cnn32_trunk' > gpurun_out/pmc_split3_summary.txt 2>&1; head -n 12 gpurun_out/pmc_split3_summary.txt
+fi
+(/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_valu_overlap tools/probes/mfma_valu_overlap.hip 2>/dev/null && timeout 120 /tmp/mfma_valu_overlap) > gpurun_out/mfma_valu_overlap.txt 2>&1; tail -n 4 gpurun_out/mfma_valu_overlap.txt
+bash tools/clock_watch.sh > gpurun_out/clock_watch.txt 2>&1; cat gpurun_out/clock_watch.txt
 if [ "$SKIP_PMC" != "1" ]; then
   timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/calib_f -o run -- python tools/fetch_calib.py run > gpurun_out/calib_f.log 2>&1; echo "calib fetch exit $?"
   timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/calib_w -o run -- python tools/fetch_calib.py run > gpurun_out/calib_w.log 2>&1; echo "calib write exit $?"
