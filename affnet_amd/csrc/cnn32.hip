@@ -53,7 +53,7 @@ extern "C" int affnet_cnn32_pack_weights(int kind, const float* const* conv_w, c
                 }
         }
     }
-    // EXPLORATORY split copies (HardNet: layers of S3_LAYER_MASK; AffNet / OriNet: conv3..5): the same BN-folded fp32 weight as three bf16 terms (nearest even,
+    // EXPLORATORY split copies (conv1 .. conv5 = S3_LAYER_MASK, all three nets): the same BN-folded fp32 weight as three bf16 terms (nearest even,
     // exact remainders), [tap][cin / 32][term][kq][cout][8]: lane (cout, kq) of the bf16 MFMA's A operand = 8 consecutive input channels
     for (int i = 1; i < 6; ++i) {
         if (!L.w_s3[i]) continue;
@@ -339,7 +339,8 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         patch[y * WP32 + x] = 0.0f;
     }
     constexpr bool HALF = S3;                                     // EXPLORATORY split path: conv0 .. conv2 in two half-patch passes
-    typedef LayB<16, 32, 34, CB> LBH;                            // conv0 output of half a patch, pre-split (HALF only)
+    typedef LayB<16, 32, 34, CB> LBH;                            // conv0 output of half a patch, pre-split (HALF only); read by conv1 (stride 1)
+    typedef LayB<16, 32, 34, CB, 16> LBH2;                       // conv1 output of half a patch; read by conv2 at stride 2
     if constexpr (HALF) zero_halo_b<LBH, NTHR>(act);
     else zero_halo<LayC0, NTHR>(act, CB);
     float sum = 0.f;
@@ -374,16 +375,15 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
 
     if constexpr (S3 && KIND == AFFNET_NET_HARDNET) {
         // EXPLORATORY (affnet_debug_split3): conv1 .. conv5 on split operands - fp32 = three bf16 terms, six v_mfma_f32_16x16x32_bf16 per
-        // 32-channel block (conv3x3_mfma_s3).  Activations stay fp32 in LDS in the layouts of the exact path, so the epilogues are shared; the
-        // tilings are chosen so that one split activation fragment (44 VALU instructions) feeds >= 12 MFMAs.
-        // conv1 .. conv4 write their outputs PRE-SPLIT (three bf16 planes, LayB): conv2 .. conv5 read ready fragments
-        typedef LayB<16, 16, 18, 2 * CB> LB2;                            // conv2 / conv3 outputs: 64 channels @16x16 (124 KB)
-        typedef LayB<8, 8, 10, 4 * CB> LB4;                              // conv4 output: 128 channels @8x8 (77 KB)
+        // 32-channel block.  conv0 .. conv4 write their outputs PRE-SPLIT (three bf16 planes, LayB), conv1 .. conv5 read ready fragments
+        // (conv3x3_mfma_s3p): no VALU work inside the MFMA loops ("Split-operand trunks").
+        typedef LayB<16, 16, 18, 2 * CB> LB2;                            // conv2 / conv3 outputs: 64 channels @16x16 (126 KB)
+        typedef LayB<8, 8, 16, 4 * CB, 128> LB4;                         // conv4 output: 128 channels @8x8, row stride 256 B (126 KB)
         static_assert(LB2::BYTES <= TrunkLds<CB>::ACT * 4 && LB4::BYTES <= TrunkLds<CB>::ACT * 4, "pre-split layouts must fit the activation buffer");
         if constexpr (CB == 32) {
             // conv0 + conv1 in two half-patch passes: the pre-split conv0 output of 32 channels @32x32 would be 222 KB, half of it (16 rows +
-            // a halo row either side) is 115 KB.  conv1 splits nothing in its loop (the on-the-fly version split every pixel once per tap: 9x).
-            static_assert(LBH::BYTES <= TrunkLds<CB>::ACT * 4, "the half-patch layout must fit the activation buffer");
+            // a halo row either side) is 117 KB.  conv1 splits nothing in its loop (the on-the-fly version split every pixel once per tap: 9x).
+            static_assert(LBH::BYTES <= TrunkLds<CB>::ACT * 4 && LBH2::BYTES <= TrunkLds<CB>::ACT * 4, "the half-patch layouts must fit the activation buffer");
             f32x4 acc_a[4][2], acc_b[4][2];
             prefetch_bias<NW, 32, 8, 2>(a.packed + a.off.b[1], bias1, wave, lane);
             conv0_half_split<NW, LBH, 2>(patch, w0, bias0, act, 0, wave, lane);
@@ -407,27 +407,26 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
             // conv1's output goes back into the same half layout, pre-split, and conv2 (stride 2: output rows 0 .. 7 read input rows
             // -1 .. 15, rows 8 .. 15 read 15 .. 31) runs in two passes as well
             char* base = reinterpret_cast<char*>(act);
-            if (tid < 12 * 32)                                           // pass 1 of conv0 left its row 15 in the top halo row
-                *reinterpret_cast<f32x4*>(base + (tid >> 5) * LBH::GS + ((tid & 31) + 1) * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
-            store_tiles_split<CB, LBH, 4, 2>(act, bias1, acc_a, wave, lane);
+            zero_halo_b<LBH2, NTHR>(act);                                // another group stride than LBH (bank conflicts of the stride-2 reader)
+            store_tiles_split<CB, LBH2, 4, 2>(act, bias1, acc_a, wave, lane);
             f32x4 acc2_a[2][2], acc2_b[2][2], bias2[2];
 #pragma unroll
             for (int j = 0; j < 2; ++j) bias2[j] = *reinterpret_cast<const f32x4*>(&a.packed[a.off.b[2] + ((wave >> 2) * 2 + j) * 16 + 4 * (lane >> 4)]);
             __syncthreads();
             CNN_STAMP(4);
             if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3p<NW, CB, 2 * CB, LBH, 2, 2, 2>(act, a.packed + a.off.w_s3[2], acc2_a, wave, lane);
+            conv3x3_mfma_s3p<NW, CB, 2 * CB, LBH2, 2, 2, 2>(act, a.packed + a.off.w_s3[2], acc2_a, wave, lane);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
             __syncthreads();
-            store_tiles_split<CB, LBH, 4, 2>(act, bias1, acc_b, wave, lane);
+            store_tiles_split<CB, LBH2, 4, 2>(act, bias1, acc_b, wave, lane);
             if (wave == 7) {                                             // conv1 row 15 (tiles 2, 3 of wave 7 in pass 0) = the top halo row of pass 1
                 const int n = lane & 15;
 #pragma unroll
-                for (int i = 2; i < 4; ++i) split_store_tile<LBH, 2>(base, ((i - 2) * 16 + n + 1) * 16, 0, bias1, acc_a[i], lane >> 4);
+                for (int i = 2; i < 4; ++i) split_store_tile<LBH2, 2>(base, ((i - 2) * 16 + n + 1) * 16, 0, bias1, acc_a[i], lane >> 4);
             }
             __syncthreads();
             if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3p<NW, CB, 2 * CB, LBH, 2, 2, 2>(act, a.packed + a.off.w_s3[2], acc2_b, wave, lane);
+            conv3x3_mfma_s3p<NW, CB, 2 * CB, LBH2, 2, 2, 2>(act, a.packed + a.off.w_s3[2], acc2_b, wave, lane);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
             CNN_STAMP(5);
             __syncthreads();
@@ -478,9 +477,9 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
     if constexpr (S3 && CB == 16) {
         // EXPLORATORY (affnet_debug_split3): AffNet / OriNet on split operands, same structure as the HardNet branch: conv0 .. conv2 in two
         // half-patch passes on pre-split layouts (conv1 / conv2 have 16 input channels: two taps per k = 32 step), conv3 .. conv5 whole.
-        typedef LayB<16, 16, 18, 2 * CB> LB2;                            // conv2 / conv3 outputs: 32 channels @16x16 (61 KB)
-        typedef LayB<8, 8, 10, 4 * CB> LB4;                              // conv4 output: 64 channels @8x8 (38 KB)
-        static_assert(LBH::BYTES <= TrunkLds<CB>::ACT * 4 && LB2::BYTES <= TrunkLds<CB>::ACT * 4 && LB4::BYTES <= TrunkLds<CB>::ACT * 4,
+        typedef LayB<16, 16, 18, 2 * CB> LB2;                            // conv2 / conv3 outputs: 32 channels @16x16 (63 KB)
+        typedef LayB<8, 8, 16, 4 * CB, 128> LB4;                         // conv4 output: 64 channels @8x8, row stride 256 B (63 KB)
+        static_assert(LBH::BYTES <= TrunkLds<CB>::ACT * 4 && LBH2::BYTES <= TrunkLds<CB>::ACT * 4 && LB2::BYTES <= TrunkLds<CB>::ACT * 4 && LB4::BYTES <= TrunkLds<CB>::ACT * 4,
                       "pre-split layouts must fit the activation buffer");
         {
             char* base = reinterpret_cast<char*>(act);
@@ -496,22 +495,21 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
             __syncthreads();
             conv3x3_mfma_s3p_c16<NW, CB, LBH, 1, 4, 1>(act, a.packed + a.off.w_s3[1], acc_b, wave, lane);
             __syncthreads();
-            if (tid < 6 * 32)                                            // pass 1 of conv0 left its row 15 in the top halo row
-                *reinterpret_cast<f32x4*>(base + (tid >> 5) * LBH::GS + ((tid & 31) + 1) * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
-            store_tiles_split<CB, LBH, 4, 1>(act, bias1, acc_a, wave, lane);
+            zero_halo_b<LBH2, NTHR>(act);                                // another group stride than LBH (bank conflicts of the stride-2 reader)
+            store_tiles_split<CB, LBH2, 4, 1>(act, bias1, acc_a, wave, lane);
             f32x4 acc2_a[2][1], acc2_b[2][1], bias2[1];
             bias2[0] = *reinterpret_cast<const f32x4*>(&a.packed[a.off.b[2] + (wave >> 2) * 16 + 4 * (lane >> 4)]);
             __syncthreads();
-            conv3x3_mfma_s3p_c16<NW, 2 * CB, LBH, 2, 2, 1>(act, a.packed + a.off.w_s3[2], acc2_a, wave, lane);
+            conv3x3_mfma_s3p_c16<NW, 2 * CB, LBH2, 2, 2, 1>(act, a.packed + a.off.w_s3[2], acc2_a, wave, lane);
             __syncthreads();
-            store_tiles_split<CB, LBH, 4, 1>(act, bias1, acc_b, wave, lane);
+            store_tiles_split<CB, LBH2, 4, 1>(act, bias1, acc_b, wave, lane);
             if (wave == 7) {                                             // conv1 row 15 (tiles 2, 3 of wave 7 in pass 0) = the top halo row of pass 1
                 const int n = lane & 15;
 #pragma unroll
-                for (int i = 2; i < 4; ++i) split_store_tile<LBH, 1>(base, ((i - 2) * 16 + n + 1) * 16, 0, bias1, acc_a[i], lane >> 4);
+                for (int i = 2; i < 4; ++i) split_store_tile<LBH2, 1>(base, ((i - 2) * 16 + n + 1) * 16, 0, bias1, acc_a[i], lane >> 4);
             }
             __syncthreads();
-            conv3x3_mfma_s3p_c16<NW, 2 * CB, LBH, 2, 2, 1>(act, a.packed + a.off.w_s3[2], acc2_b, wave, lane);
+            conv3x3_mfma_s3p_c16<NW, 2 * CB, LBH2, 2, 2, 1>(act, a.packed + a.off.w_s3[2], acc2_b, wave, lane);
             __syncthreads();
             zero_halo_b<LB2, NTHR>(act);
             store_tiles_split<2 * CB, LB2, 2, 1, 8>(act, bias2, acc2_a, wave, lane, 0);
@@ -979,7 +977,7 @@ int aff_hardnet_forward_pyr_marked(affnet_ctx* ctx, const float* packed, const f
 
 extern "C" int affnet_debug_split3(affnet_ctx* ctx, int on) {
     if (!ctx) return AFFNET_ERR_INVALID;
-    ctx->split3 = on != 0;      // EXPLORATORY: HardNet layers of S3_LAYER_MASK on split operands (fp32 = 3 x bf16) for this context's launches
+    ctx->split3 = on != 0;      // EXPLORATORY: conv1 .. conv5 of the three trunks on split operands (fp32 = 3 x bf16) for this context's launches
     return AFFNET_OK;
 }
 

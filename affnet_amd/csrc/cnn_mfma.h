@@ -323,14 +323,13 @@ __device__ __forceinline__ void conv3x3_mfma(const float* act, const float* __re
 // ---- EXPLORATORY: the same contraction on split operands (fp32 = three bf16 terms) ---------------------------------------------
 // x = x0 + x1 + x2 with every term rounded to bf16 is exact for a 24-bit significand, every bf16 x bf16 product is exact in the fp32
 // accumulator of v_mfma_f32_16x16x32_bf16, and the six products with i + j <= 2 carry an fp32 product to 2^-25 relative - at 16x the
-// rate of the fp32 MFMA.  Activations stay fp32 in LDS (layout LI unchanged): a lane reads the 8 consecutive input channels of its pixel
-// that one k = 32 step needs (two ds_read_b128 from neighbouring plane groups) and splits them in registers (v_cvt_pk_bf16_f32 + the
-// remainders); weights were split at pack time: Ws [tap][CIN/32][term][kq][COUT][8 bf16].  Accumulator layout = conv3x3_mfma's, so the
-// epilogues are shared.  Selected per context (affnet_debug_split3); never the default.
+// rate of the fp32 MFMA.  Weights are split at pack time: Ws [tap][CIN/32][term][kq][COUT][8 bf16]; activations are split ONCE, by the
+// epilogue of the layer that produces them, into three bf16 planes (LayB) - the first version kept them fp32 in LDS and split each
+// fragment in registers when it was read (9 taps x NG channel groups times per element): 4.5 VALU instructions per MFMA, matrix pipe
+// 49 % busy (round 3, removed).  Accumulator layout = conv3x3_mfma's.  Selected per context (affnet_debug_split3); never the default.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-struct Split3 { bf16x8 t[3]; };
 
 // Exact remainder of a pair after its bf16 roundings u = (bf16(v.x), bf16(v.y)): v_dot2c_f32_bf16 with the constant pair (-1, 0) /
 // (0, -1) is  v.x - float(u.lo) + 0 * float(u.hi)  in one instruction; the difference is representable, so the rounding mode does not
@@ -338,9 +337,9 @@ struct Split3 { bf16x8 t[3]; };
 // bf16(v) overflows to inf.  The constants come from s_mov through an asm so that the compiler cannot fold them into an inline
 // operand: it encodes the packed bf16 (-1, 0) as the inline constant -1.0, which the hardware does not read as bf16 (the low-half
 // remainders came out unchanged).
-// Measured alternatives inside the MFMA loops (HardNet conv1, cycles of the slower wave of a SIMD): shift / mask + v_pk_add_f32 54.9 k,
-// this form 48.8 k, shift / mask + two unpacked v_sub_f32 50.2 k.  tools/probes/mfma_valu_overlap.hip shows why none of them hides
-// under the matrix pipe: with two waves per SIMD, 12 bf16 MFMAs + 36 VALU instructions take 528-553 cycles for v_fmac / v_cvt_pk /
+// Measured alternatives when the split still sat inside the MFMA loops (HardNet conv1, cycles of the slower wave of a SIMD): shift /
+// mask + v_pk_add_f32 54.9 k, this form 48.8 k, shift / mask + two unpacked v_sub_f32 50.2 k (pre-split: 38.3 k incl. a second conv0
+// pass).  tools/probes/mfma_valu_overlap.hip shows why none of them hides under the matrix pipe: with two waves per SIMD, 12 bf16 MFMAs + 36 VALU instructions take 528-553 cycles for v_fmac / v_cvt_pk /
 // v_lshlrev (MFMAs alone 428, the VALU alone 190-330) and ~1000 cycles for v_dot2c / v_pk_add_f32 - VALU work next to bf16 MFMAs is at
 // best half hidden, so the remedy is not to have it in the loop (pre-split layouts below).
 __device__ __forceinline__ void split_remainder(f32x2& v, unsigned u) {
@@ -352,104 +351,6 @@ __device__ __forceinline__ void split_remainder(f32x2& v, unsigned u) {
     v.y = __builtin_amdgcn_fdot2_f32_bf16(b, __builtin_bit_cast(bf16x2, c1), v.y, false);
 }
 
-__device__ __forceinline__ Split3 split3_rne(const f32x4 lo, const f32x4 hi) {
-    const float x[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
-    u32x4 p[3];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        f32x2 v = {x[2 * q], x[2 * q + 1]};
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const unsigned u = __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));      // v_cvt_pk_bf16_f32 (nearest even)
-            p[t][q] = u;
-            if (t < 2) split_remainder(v, u);                                                          // exact remainders
-        }
-    }
-    Split3 s;
-#pragma unroll
-    for (int t = 0; t < 3; ++t) s.t[t] = __builtin_bit_cast(bf16x8, p[t]);
-    return s;
-}
-
-template <int NW, int CIN, int COUT, typename LI, int STRIDE, int TM, int TN>
-__device__ __forceinline__ void conv3x3_mfma_s3(const float* act, const float* __restrict__ Ws, f32x4 (&acc)[TM][TN], int wave, int lane) {
-    constexpr int HOUT = LI::H / STRIDE;
-    constexpr int MT = HOUT * HOUT / 16, NT = COUT / 16;
-    constexpr int MG = MT / TM, NG = NT / TN;
-    constexpr int NG32 = CIN / 32, NS = 9 * NG32;
-    static_assert(MG * NG == NW && CIN % 32 == 0, "bad tiling for the split-operand loop");
-    const int mg = wave % MG, ng = wave / MG;
-    const int m = lane & 15, kq = lane >> 4;
-    int a_lane;
-    {
-        const int p = mg * TM * 16 + m;
-        const int oy = p / HOUT, ox = p - oy * HOUT;
-        a_lane = 2 * kq * LI::PSG + ((oy * STRIDE) * LI::WP + ox * STRIDE) * 4;       // channels 8 kq .. 8 kq + 7 = plane groups 2 kq, 2 kq + 1
-    }
-    const unsigned a_addr0 = lds_byte_addr(act) + a_lane * 4;
-    auto a_imm = [](int i) { return 4 * (HOUT == 8 ? i * 2 * STRIDE * LI::WP * 4 : (((i * 16) / HOUT) * STRIDE * LI::WP + ((i * 16) % HOUT) * STRIDE) * 4); };
-    constexpr int WS_FLOATS = 9 * (CIN / 32) * 3 * 4 * COUT * 4;
-    const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(Ws, WS_FLOATS);
-    const int w_lane = (kq * COUT + ng * TN * 16 + m) * 16;                            // bytes; + j * 256 per N-tile
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    bf16x8 w[2][3][TN];
-    auto load_w = [&](bf16x8 (&dst)[3][TN], int s) {
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                dst[t][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_lane + j * 256, ((s * 3 + t) * 4 * COUT) * 16, 0));
-    };
-    // Software pipeline over the flat tile sequence (step s, tile i): while tile q's 6 TN MFMAs issue, the VALU splits tile q + 1
-    // (its raw fp32 fragment arrived one tile earlier) and the LDS reads for tile q + 2 are in flight.  One MFMA occupies the matrix
-    // pipe for 16 cycles and its issue takes 4, so up to three VALU instructions fit under each - the ~30 of a split hide under 12
-    // MFMAs.  The first version ran read -> wait -> split -> MFMAs per tile, i.e. the wave's own matrix pipe idled during every split.
-    static_assert(TM >= 2, "the pipeline looks two tiles ahead");
-    auto frag_addr = [&](int s) {
-        const int tap = s / NG32, G = s - tap * NG32;
-        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
-        return a_addr0 + (8 * G * LI::PSG + (ky * LI::WP + kx) * 4) * 4;
-    };
-    Split3 cur;
-    f32x4 rlo, rhi;
-    {
-        const unsigned ab = frag_addr(0);
-        cur = split3_rne(lds_read4(ab + a_imm(0)), lds_read4(ab + a_imm(0) + LI::PSG * 4));
-        rlo = lds_read4(ab + a_imm(1)); rhi = lds_read4(ab + a_imm(1) + LI::PSG * 4);
-    }
-    auto step = [&](const bf16x8 (&wc)[3][TN], int s) {
-        const unsigned ab0 = frag_addr(s), ab1 = frag_addr(s + 1 < NS ? s + 1 : s);      // past the end: harmless re-reads
-        constexpr int TW[6] = {0, 1, 2, 0, 1, 0}, TA[6] = {2, 1, 0, 1, 0, 0};            // smallest terms first
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const unsigned ad2 = (i + 2 < TM) ? ab0 + a_imm(i + 2) : ab1 + a_imm(i + 2 - TM);
-            const f32x4 lo2 = lds_read4(ad2), hi2 = lds_read4(ad2 + LI::PSG * 4);
-            const Split3 nxt = split3_rne(rlo, rhi);
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc[TW[t]][j], cur.t[TA[t]], acc[i][j], 0, 0, 0);
-            cur = nxt; rlo = lo2; rhi = hi2;
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // reads of tile q + 2
-            __builtin_amdgcn_sched_group_barrier(0x002, 48, 0);     // split of tile q + 1 as one VALU burst ...
-            __builtin_amdgcn_sched_group_barrier(0x008, 6 * TN, 0); // ... then the MFMA burst of tile q (the SIMD's other wave fills the gaps)
-        }
-    };
-    load_w(w[0], 0);
-#pragma unroll 1
-    for (int s = 0; s + 1 < NS; s += 2) {
-        load_w(w[1], s + 1);
-        step(w[0], s);
-        load_w(w[0], (s + 2 < NS) ? s + 2 : s + 1);
-        step(w[1], s + 1);
-    }
-    if (NS & 1) step(w[0], NS - 1);
-}
-
 // ---- pre-split activations: a layer's output stored as three bf16 planes -------------------------------------------------------
 // Splitting in the reading loop is redundant: the NG waves that share a pixel tile (different output channels) each split the same
 // fragment - 4.5 VALU instructions per MFMA in the first version (PMC: 8.0e9 VALU vs 1.8e9 MFMA instructions per 32-image HardNet
@@ -457,10 +358,16 @@ __device__ __forceinline__ void conv3x3_mfma_s3(const float* act, const float* _
 // splits every output element once and the next layer reads ready bf16 fragments: element (term t, channel c, y, x) of an H x H layer
 // sits at  t * TS + (c / 8) * GS + ((y + 1) * WP + x + 1) * 16 + (c % 8) * 2  bytes - one ds_read_b128 = the 8 channels of one term
 // of one pixel = a lane's B fragment of a k = 32 step.
-template <int H_, int W_, int WP_, int C_>
+// Bank conflicts (ds_read_b128 is served in four groups of 16 lanes - {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... - over a 256-byte
+// bank window): pixels {0-3, 12-15} of lane quarter kq and pixels {4-11} of quarter kq + 1 share a group, so the 8-channel group stride GS
+// decides whether their 16-byte cells collide.  The first version had GS = 64 (mod 256) everywhere: 56 % of the LDS-array cycles of the
+// split HardNet launch were conflict cycles (SQ_LDS_BANK_CONFLICT 2.9e9 of SQ_LDS_IDX_ACTIVE 5.1e9).  GS is rounded up to a multiple of
+// 256 plus GREM, chosen per READER:  16 pixels contiguous (stride-1 reader of a 16 / 32-wide layer): GREM = 0;  2 rows x 8 pixels (8-wide
+// layer, row stride 256 bytes = WP 16): GREM = 128;  16 pixels at a 32-byte pitch (stride-2 reader of a 32-wide layer): GREM = 16.
+template <int H_, int W_, int WP_, int C_, int GREM_ = 0>
 struct LayB {
     static constexpr int H = H_, W = W_, WP = WP_, C = C_;      // H rows x W columns (+ a one-cell halo), row stride WP cells
-    static constexpr int GS = (H_ + 2) * WP_ * 16;        // bytes per 8-channel group
+    static constexpr int GS = (((H_ + 2) * WP_ * 16 + 255) / 256) * 256 + GREM_;      // bytes per 8-channel group
     static constexpr int TS = (C_ / 8) * GS;              // bytes per term
     static constexpr int BYTES = 3 * TS;
 };
@@ -592,7 +499,7 @@ __device__ __forceinline__ void conv3x3_mfma_s3p(const float* act, const float* 
     if (NS & 1) step(w[0], NS - 1);
 }
 
-// Pre-split input with 16 channels (AffNet / OriNet conv1, conv2): one k = 32 step = two taps x 16 channels as in conv3x3_mfma_s3_c16
+// Pre-split input with 16 channels (AffNet / OriNet conv1, conv2): one k = 32 step = two taps x 16 channels
 // (lane group kq: tap 2 s + (kq >> 1), channel group kq & 1), fragments read ready from a LayB layout with the rotating schedule.
 template <int NW, int COUT, typename LI, int STRIDE, int TM, int TN>
 __device__ __forceinline__ void conv3x3_mfma_s3p_c16(const float* act, const float* __restrict__ Ws, f32x4 (&acc)[TM][TN], int wave, int lane) {
@@ -651,73 +558,6 @@ __device__ __forceinline__ void conv3x3_mfma_s3p_c16(const float* act, const flo
                 __builtin_amdgcn_sched_group_barrier(0x008, 6 * TN, 0);
                 __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
             }
-        }
-    }
-}
-
-// 16 input channels: one k = 32 step = TWO taps x 16 channels (lane group kq: tap 2 s + (kq >> 1), channels 8 (kq & 1) .. + 7); the nine taps
-// take five steps, the tenth half-step multiplies zero weights.  Ws [step][term][kq][COUT][8 bf16].
-template <int NW, int COUT, typename LI, int STRIDE, int TM, int TN>
-__device__ __forceinline__ void conv3x3_mfma_s3_c16(const float* act, const float* __restrict__ Ws, f32x4 (&acc)[TM][TN], int wave, int lane) {
-    constexpr int HOUT = LI::H / STRIDE;
-    constexpr int MT = HOUT * HOUT / 16, NT = COUT / 16;
-    constexpr int MG = MT / TM, NG = NT / TN;
-    static_assert(MG * NG == NW, "bad tiling for the split-operand loop");
-    const int mg = wave % MG, ng = wave / MG;
-    const int m = lane & 15, kq = lane >> 4;
-    int a_lane;
-    {
-        const int p = mg * TM * 16 + m;
-        const int oy = p / HOUT, ox = p - oy * HOUT;
-        a_lane = 2 * (kq & 1) * LI::PSG + ((oy * STRIDE) * LI::WP + ox * STRIDE) * 4;
-    }
-    const unsigned a_addr0 = lds_byte_addr(act) + a_lane * 4;
-    auto a_imm = [](int i) { return 4 * (HOUT == 8 ? i * 2 * STRIDE * LI::WP * 4 : (((i * 16) / HOUT) * STRIDE * LI::WP + ((i * 16) % HOUT) * STRIDE) * 4); };
-    constexpr int WS_FLOATS = 5 * 3 * 4 * COUT * 4;
-    const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(Ws, WS_FLOATS);
-    const int w_lane = (kq * COUT + ng * TN * 16 + m) * 16;
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    // same software pipeline as conv3x3_mfma_s3: MFMAs of tile q | split of tile q + 1 | LDS reads of tile q + 2
-    static_assert(TM >= 2, "the pipeline looks two tiles ahead");
-    auto frag_addr = [&](int s) {
-        const int ta = 2 * s, tb = (2 * s + 1 < 9) ? 2 * s + 1 : 8;                   // the pad half-step re-reads tap 8 (times zero weights)
-        const int off_a = ((ta / 3) * LI::WP + ta % 3) * 16, off_b = ((tb / 3) * LI::WP + tb % 3) * 16;      // bytes
-        return a_addr0 + ((kq >> 1) ? off_b : off_a);
-    };
-    Split3 cur;
-    f32x4 rlo, rhi;
-    {
-        const unsigned ab = frag_addr(0);
-        cur = split3_rne(lds_read4(ab + a_imm(0)), lds_read4(ab + a_imm(0) + LI::PSG * 4));
-        rlo = lds_read4(ab + a_imm(1)); rhi = lds_read4(ab + a_imm(1) + LI::PSG * 4);
-    }
-#pragma unroll
-    for (int s = 0; s < 5; ++s) {
-        bf16x8 w[3][TN];
-#pragma unroll
-        for (int t = 0; t < 3; ++t)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-                w[t][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_lane + j * 256, ((s * 3 + t) * 4 * COUT) * 16, 0));
-        const unsigned ab0 = frag_addr(s), ab1 = frag_addr(s + 1 < 5 ? s + 1 : s);
-        constexpr int TW[6] = {0, 1, 2, 0, 1, 0}, TA[6] = {2, 1, 0, 1, 0, 0};
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const unsigned ad2 = (i + 2 < TM) ? ab0 + a_imm(i + 2) : ab1 + a_imm(i + 2 - TM);
-            const f32x4 lo2 = lds_read4(ad2), hi2 = lds_read4(ad2 + LI::PSG * 4);
-            const Split3 nxt = split3_rne(rlo, rhi);
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[TW[t]][j], cur.t[TA[t]], acc[i][j], 0, 0, 0);
-            cur = nxt; rlo = lo2; rhi = hi2;
-            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);      // reads of tile q + 2
-            __builtin_amdgcn_sched_group_barrier(0x002, 48, 0);     // split of tile q + 1 as one VALU burst ...
-            __builtin_amdgcn_sched_group_barrier(0x008, 6 * TN, 0); // ... then the MFMA burst of tile q (the SIMD's other wave fills the gaps)
         }
     }
 }

@@ -54,8 +54,11 @@ int affnet_debug_stream(const void* d_src, void* d_dst, size_t n_bytes, int widt
  *   affnet_split3_rate: sustained rate of the inner-loop shape a trunk layer would have (fragments from LDS, 4 pixel tiles x 1 channel
  *     tile); terms = 6 / 9 on bf16 MFMA, 1 = the fp32 16x16x4 loop over the same tiles.  One launch = n_blocks x 8 waves x reps x 4 tiles
  *     x (16 x 16 x 32) multiply-adds.  d_out: 2 floats (sink). */
-/* EXPLORATORY: != 0 = this context's HardNet trunk launches run the layers of S3_LAYER_MASK (csrc/cnn_mfma.h) on split operands
- * (conv3x3_mfma_s3); the packed HardNet blob always carries the split copy of those layers' weights.  Default 0: exact fp32. */
+/* EXPLORATORY: != 0 = this context's AffNet / OriNet / HardNet trunk launches run conv1 .. conv5 (S3_LAYER_MASK, csrc/cnn_mfma.h) on split
+ * operands: six v_mfma_f32_16x16x32_bf16 products per fp32 product, fp32 accumulate, activations pre-split into bf16 planes in LDS
+ * ("Split-operand trunks").  The packed blobs always carry the split copy of those layers' weights.  Default 0: exact
+ * fp32 MFMA, and switching back restores it bit for bit (test_exploratory_split3_trunks_vs_exact_trunks).  Used only by bench.py --split3 /
+ * its `split3_exploratory` field and the tests. */
 int affnet_debug_split3(affnet_ctx* ctx, int on);
 int affnet_split3_gemm(const float* d_A, const float* d_Bt, int M, int N, int K, int mode, float* d_C, void* stream);
 int affnet_split3_rate(int reps, int terms, int n_blocks, float* d_out, void* stream);

@@ -21,7 +21,7 @@ timeout 120 python bench.py --gpus 2 --steps 1 --warmup 0 > gpurun_out/bench_gpu
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_c2 -o run -- python bench.py --config2 --steps 5 > gpurun_out/prof_c2.log 2>&1; echo "prof config2 exit: $?"
 (python tools/gap_table.py gpurun_out/prof_c2/run_kernel_trace.csv; echo; python tools/gap_table.py gpurun_out/prof_c2/run_kernel_trace.csv --graph) > gpurun_out/gap_table.md 2>&1; tail -n 11 gpurun_out/gap_table.md
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_c5 -o run -- python bench.py --config5 --steps 1 --warmup 1 --no-cpu-baseline --no-secondary > gpurun_out/prof_c5.log 2>&1; echo "prof config5 exit: $?"
-CMD="python bench.py --steps 1 --warmup 1 --batch 64 --chunk 32 --no-cpu-baseline --no-secondary"
+CMD="python bench.py --steps 1 --warmup 1 --batch 64 --chunk 32 --no-cpu-baseline --no-secondary --no-split3"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof -o run -- $CMD > gpurun_out/prof.log 2>&1; echo "prof exit: $?"
 f=$(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -n 12 "$f" | cut -c1-200
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_onepass -o run -- python bench.py --onepass --steps 1 --warmup 1 > gpurun_out/prof_onepass.log 2>&1; echo "prof onepass exit: $?"
@@ -54,7 +54,7 @@ if [ "$SKIP_PMC" != "1" ]; then
   python tools/pmc_traffic.py $(P 3) $(P 4) 32 gpurun_out/fetch_calibration.json > gpurun_out/traffic.json 2> gpurun_out/traffic.log
   head -16 gpurun_out/pmc_summary.txt
   # the stand-alone sampler (secondary_rooflines section of bench.py): kernel stats + FETCH / WRITE passes of a run that includes it
-  CMD2="python bench.py --steps 1 --warmup 1 --batch 32 --chunk 32 --no-cpu-baseline"
+  CMD2="python bench.py --steps 1 --warmup 1 --batch 32 --chunk 32 --no-cpu-baseline --no-split3"
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_sampler -o run -- $CMD2 > gpurun_out/prof_sampler.log 2>&1; echo "prof sampler exit $?"
   timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmc_sampler_f -o run -- $CMD2 > gpurun_out/pmc_sampler_f.log 2>&1; echo "pmc sampler fetch exit $?"
   timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmc_sampler_w -o run -- $CMD2 > gpurun_out/pmc_sampler_w.log 2>&1; echo "pmc sampler write exit $?"

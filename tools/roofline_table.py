@@ -36,7 +36,9 @@ def main(prefix):
     aff_eval = bench.get("roofline", {}).get("affnet_patches_evaluated_per_image")
     if aff_eval:
         FLOP["cnn32_trunk_kernel<0"] = aff_eval * 19193856.0
-    calls_per_batch = stats["void cnn32_trunk_kernel<2, 8, false>"][0]      # one HardNet launch per 32-image call
+    # one HardNet trunk launch per 32-image call; a run that also took the EXPLORATORY split-operand steps (bench.py without --no-split3)
+    # has them under their own template instantiation <2, 8, false, true> - every other kernel is shared by both kinds of step
+    calls_per_batch = sum(v[0] for k, v in stats.items() if k.startswith("void cnn32_trunk_kernel<2, 8, false"))
     P0, P = H * W, octave_pixels(H, W)
     alg = {"blur2d_kernel": (P0 + 9 * P) * 4.0 * IMGS, "hessian_nms_kernel": 5 * P * 4.0 * IMGS}
     print("| kernel | launches / 32-image call | mean us | HBM bytes / launch (PMC, calibrated) | PMC GB/s | % of 8 TB/s | algorithmic rate |")
@@ -50,8 +52,16 @@ def main(prefix):
         hbm = t["hbm_bytes"] if t else None
         gbs = hbm / avg_ns if hbm else None                                  # bytes / ns = GB/s
         algs = ""
+        split = "cnn32_trunk_kernel" in name and name.rstrip().endswith("true>")
+        if "cnn32_trunk_kernel" in name:                                     # exact and split instantiations: launches of their own steps only
+            own = sum(v[0] for k, v in stats.items() if k.startswith("void cnn32_trunk_kernel<2, 8, false") and k.rstrip().endswith("true>") == split)
+            per_call = calls / float(max(1, own))
         for key, fl in FLOP.items():
-            if key in name:
+            if key in name and split:
+                tf = fl * IMGS / (per_call * avg_ns * 1e-9) / 1e12
+                algs = ("EXPLORATORY split operands: %.1f TFLOP/s fp32-equivalent; executed bf16 products (6 per fp32 product) %.0f TFLOP/s = %.1f %% of "
+                        "the 2517 bf16 MFMA peak" % (tf, 6 * tf, 100 * 6 * tf / 2516.8))
+            elif key in name:
                 tf = fl * IMGS / (per_call * avg_ns * 1e-9) / 1e12            # all launches of the kernel in one 32-image call
                 algs = "%.1f TFLOP/s = %.1f %% of 157.3" % (tf, 100 * tf / 157.3)
                 if per_call > 1.01:
