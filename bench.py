@@ -50,15 +50,23 @@ GRAF = os.path.join(ROOT, "tests", "golden", "graf_img1.png")
 
 
 # ----------------------------------------------------------------------------------------------------------------------
-def pmc_traffic(images_per_launch):
+def pmc_traffic(images_per_launch, split=False):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
     in separate passes, tools/gpu_full.sh + tools/pmc_traffic.py; counters cannot be read from inside this process)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*traffic.json")))
-    if not files:
-        return None, None
-    d = json.load(open(files[-1]))
-    k = d["kernels"].get("void cnn32_trunk_kernel<2, 8, false>") or d["kernels"].get("void cnn32_trunk_kernel<2, 8>")
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")) if "sampler" not in os.path.basename(f))
+    d = k = None
+    for f in reversed(files):                  # newest evidence set that has the exact-fp32 HardNet trunk (its name gained template arguments over the rounds)
+        d = json.load(open(f))
+        names = ("void cnn32_trunk_kernel<2, 8, false, true>",) if split else \
+                ("void cnn32_trunk_kernel<2, 8, false, false>", "void cnn32_trunk_kernel<2, 8, false>", "void cnn32_trunk_kernel<2, 8>")
+        for name in names:
+            k = d["kernels"].get(name)
+            if k:
+                break
+        if k:
+            files = [f]
+            break
     if not k:
         return None, None
     scale = images_per_launch / float(d["images_per_launch"])
@@ -696,7 +704,7 @@ def run(args, world):
         kp_per_img = kps / max(1, args.steps * args.batch * world)
         flops_launch = kp_per_img * img_per_launch * (FLOP_HARD - FLOP_HARD_HEAD)
         achieved = flops_launch / (trunk_ms * 1e-3) / 1e12 if trunk_ms > 0 else 0.0
-        traffic, traffic_note = pmc_traffic(img_per_launch)
+        traffic, traffic_note = pmc_traffic(img_per_launch, split=args.split3)
         cfg_idx = 4 if args.config5 else 2
         metric = "keypoints/sec (detect+AffNet+OriNet+HardNet) per image, %d kp @%dx%d" % (NKP, W, H)
         if H2D:
