@@ -207,6 +207,7 @@ struct CnnArgs {
     int n_max;
     float* out;            // AffNet/OriNet: (n,2,2); HardNet: trunk output (n,8192)
     int dbg_layer;         // >= 0: dump activations after this trunk layer of patch 0 and exit
+    int s3_alt;            // EXPLORATORY split path: the two waves of a SIMD alternate at the higher priority inside the MFMA loops
     float* dbg_out;
     unsigned long long* dbg_time;   // != NULL: s_memtime stamps [patch][wave][32] at the phase boundaries (tuning aid)
     // Row window [row_begin, row_begin + gridDim.x) of every image, and the lazy-evaluation predicate of the fused pipeline: when
@@ -373,6 +374,10 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
     if (STAMPS && a.dbg_layer == 0) { dump_planes<CB, LayC0, NTHR>(act, a.dbg_out); return; }
     if (!HALF) CNN_STAMP(2);
 
+    // the two waves of a SIMD take turns at the higher priority inside the split MFMA loops: without it one of them runs ahead (conv3: 26.5 k
+    // cycles for the faster, 32.3 k for the slower wave) and the slower one finishes alone; with it 166 k -> 159 k cycles per patch, 15.24 ->
+    // 15.03 ms per 48000 patches (power-limited: the clock gives part of it back).  AffNet / OriNet (two workgroups per CU) do not gain.
+    const bool s3_alt = a.s3_alt != 0 && KIND == AFFNET_NET_HARDNET;
     if constexpr (S3 && KIND == AFFNET_NET_HARDNET) {
         // EXPLORATORY (affnet_debug_split3): conv1 .. conv5 on split operands - fp32 = three bf16 terms, six v_mfma_f32_16x16x32_bf16 per
         // 32-channel block.  conv0 .. conv4 write their outputs PRE-SPLIT (three bf16 planes, LayB), conv1 .. conv5 read ready fragments
@@ -390,7 +395,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
             __syncthreads();
             CNN_STAMP(2);
             if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3p<NW, CB, CB, LBH, 1, 4, 2>(act, a.packed + a.off.w_s3[1], acc_a, wave, lane);
+            conv3x3_mfma_s3p<NW, CB, CB, LBH, 1, 4, 2>(act, a.packed + a.off.w_s3[1], acc_a, wave, lane, s3_alt);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
             __syncthreads();
             if (tid < 12 * 32) {                                         // pass 0 left conv0 row 16 in the bottom halo row: zero again
@@ -400,7 +405,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
             conv0_half_split<NW, LBH, 2>(patch, w0, bias0, act, 1, wave, lane);
             __syncthreads();
             if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3p<NW, CB, CB, LBH, 1, 4, 2>(act, a.packed + a.off.w_s3[1], acc_b, wave, lane);
+            conv3x3_mfma_s3p<NW, CB, CB, LBH, 1, 4, 2>(act, a.packed + a.off.w_s3[1], acc_b, wave, lane, s3_alt);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
             CNN_STAMP(3);
             __syncthreads();
@@ -415,7 +420,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
             __syncthreads();
             CNN_STAMP(4);
             if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3p<NW, CB, 2 * CB, LBH2, 2, 2, 2>(act, a.packed + a.off.w_s3[2], acc2_a, wave, lane);
+            conv3x3_mfma_s3p<NW, CB, 2 * CB, LBH2, 2, 2, 2>(act, a.packed + a.off.w_s3[2], acc2_a, wave, lane, s3_alt);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
             __syncthreads();
             store_tiles_split<CB, LBH2, 4, 2>(act, bias1, acc_b, wave, lane);
@@ -426,7 +431,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
             }
             __syncthreads();
             if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3p<NW, CB, 2 * CB, LBH2, 2, 2, 2>(act, a.packed + a.off.w_s3[2], acc2_b, wave, lane);
+            conv3x3_mfma_s3p<NW, CB, 2 * CB, LBH2, 2, 2, 2>(act, a.packed + a.off.w_s3[2], acc2_b, wave, lane, s3_alt);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
             CNN_STAMP(5);
             __syncthreads();
@@ -440,7 +445,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
             f32x4 acc_[4][2], bias_[2];                                  // conv3: 64 -> 64 @16x16
             prefetch_bias<NW, 16, 4, 2>(a.packed + a.off.b[3], bias_, wave, lane);
             if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3p<NW, 2 * CB, 2 * CB, LB2, 1, 4, 2>(act, a.packed + a.off.w_s3[3], acc_, wave, lane);
+            conv3x3_mfma_s3p<NW, 2 * CB, 2 * CB, LB2, 1, 4, 2>(act, a.packed + a.off.w_s3[3], acc_, wave, lane, s3_alt);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
             CNN_STAMP(7);
             __syncthreads();
@@ -452,7 +457,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
             f32x4 acc_[2][2], bias_[2];                                  // conv4: 64 -> 128, stride 2 -> 8x8
             prefetch_bias<NW, 8, 2, 2>(a.packed + a.off.b[4], bias_, wave, lane);
             if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3p<NW, 2 * CB, 4 * CB, LB2, 2, 2, 2>(act, a.packed + a.off.w_s3[4], acc_, wave, lane);
+            conv3x3_mfma_s3p<NW, 2 * CB, 4 * CB, LB2, 2, 2, 2>(act, a.packed + a.off.w_s3[4], acc_, wave, lane, s3_alt);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
             CNN_STAMP(9);
             __syncthreads();
@@ -466,7 +471,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
             f32x4 acc5[T5M][T5N], bias5s[T5N];
             prefetch_bias<NW, 8, T5M, T5N>(a.packed + a.off.b[5], bias5s, wave, lane);
             if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3p<NW, 4 * CB, 4 * CB, LB4, 1, T5M, T5N>(act, a.packed + a.off.w_s3[5], acc5, wave, lane);
+            conv3x3_mfma_s3p<NW, 4 * CB, 4 * CB, LB4, 1, T5M, T5N>(act, a.packed + a.off.w_s3[5], acc5, wave, lane, s3_alt);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
             CNN_STAMP(11);
             store_tiles_global<4 * CB, T5M, T5N>(a.out + pidx * (64 * 4 * CB), bias5s, acc5, wave, lane);
@@ -487,20 +492,20 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
             prefetch_bias<NW, 32, 8, 1>(a.packed + a.off.b[1], bias1, wave, lane);
             conv0_half_split<NW, LBH, 1>(patch, w0, bias0, act, 0, wave, lane);
             __syncthreads();
-            conv3x3_mfma_s3p_c16<NW, CB, LBH, 1, 4, 1>(act, a.packed + a.off.w_s3[1], acc_a, wave, lane);
+            conv3x3_mfma_s3p_c16<NW, CB, LBH, 1, 4, 1>(act, a.packed + a.off.w_s3[1], acc_a, wave, lane, s3_alt);
             __syncthreads();
             if (tid < 6 * 32)                                            // pass 0 left conv0 row 16 in the bottom halo row: zero again
                 *reinterpret_cast<f32x4*>(base + (tid >> 5) * LBH::GS + (17 * LBH::WP + (tid & 31) + 1) * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
             conv0_half_split<NW, LBH, 1>(patch, w0, bias0, act, 1, wave, lane);
             __syncthreads();
-            conv3x3_mfma_s3p_c16<NW, CB, LBH, 1, 4, 1>(act, a.packed + a.off.w_s3[1], acc_b, wave, lane);
+            conv3x3_mfma_s3p_c16<NW, CB, LBH, 1, 4, 1>(act, a.packed + a.off.w_s3[1], acc_b, wave, lane, s3_alt);
             __syncthreads();
             zero_halo_b<LBH2, NTHR>(act);                                // another group stride than LBH (bank conflicts of the stride-2 reader)
             store_tiles_split<CB, LBH2, 4, 1>(act, bias1, acc_a, wave, lane);
             f32x4 acc2_a[2][1], acc2_b[2][1], bias2[1];
             bias2[0] = *reinterpret_cast<const f32x4*>(&a.packed[a.off.b[2] + (wave >> 2) * 16 + 4 * (lane >> 4)]);
             __syncthreads();
-            conv3x3_mfma_s3p_c16<NW, 2 * CB, LBH2, 2, 2, 1>(act, a.packed + a.off.w_s3[2], acc2_a, wave, lane);
+            conv3x3_mfma_s3p_c16<NW, 2 * CB, LBH2, 2, 2, 1>(act, a.packed + a.off.w_s3[2], acc2_a, wave, lane, s3_alt);
             __syncthreads();
             store_tiles_split<CB, LBH2, 4, 1>(act, bias1, acc_b, wave, lane);
             if (wave == 7) {                                             // conv1 row 15 (tiles 2, 3 of wave 7 in pass 0) = the top halo row of pass 1
@@ -509,7 +514,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
                 for (int i = 2; i < 4; ++i) split_store_tile<LBH2, 1>(base, ((i - 2) * 16 + n + 1) * 16, 0, bias1, acc_a[i], lane >> 4);
             }
             __syncthreads();
-            conv3x3_mfma_s3p_c16<NW, 2 * CB, LBH2, 2, 2, 1>(act, a.packed + a.off.w_s3[2], acc2_b, wave, lane);
+            conv3x3_mfma_s3p_c16<NW, 2 * CB, LBH2, 2, 2, 1>(act, a.packed + a.off.w_s3[2], acc2_b, wave, lane, s3_alt);
             __syncthreads();
             zero_halo_b<LB2, NTHR>(act);
             store_tiles_split<2 * CB, LB2, 2, 1, 8>(act, bias2, acc2_a, wave, lane, 0);
@@ -519,7 +524,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         {
             f32x4 acc_[2][2], bias_[2];                                  // conv3: 32 -> 32 @16x16
             prefetch_bias<NW, 16, 2, 2>(a.packed + a.off.b[3], bias_, wave, lane);
-            conv3x3_mfma_s3p<NW, 2 * CB, 2 * CB, LB2, 1, 2, 2>(act, a.packed + a.off.w_s3[3], acc_, wave, lane);
+            conv3x3_mfma_s3p<NW, 2 * CB, 2 * CB, LB2, 1, 2, 2>(act, a.packed + a.off.w_s3[3], acc_, wave, lane, s3_alt);
             __syncthreads();
             store_tiles_split<2 * CB, LB2, 2, 2>(act, bias_, acc_, wave, lane);      // in place: the halo is still zero
             __syncthreads();
@@ -527,7 +532,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         {
             f32x4 acc_[1][2], bias_[2];                                  // conv4: 32 -> 64, stride 2 -> 8x8
             prefetch_bias<NW, 8, 1, 2>(a.packed + a.off.b[4], bias_, wave, lane);
-            conv3x3_mfma_s3p<NW, 2 * CB, 4 * CB, LB2, 2, 1, 2>(act, a.packed + a.off.w_s3[4], acc_, wave, lane);
+            conv3x3_mfma_s3p<NW, 2 * CB, 4 * CB, LB2, 2, 1, 2>(act, a.packed + a.off.w_s3[4], acc_, wave, lane, s3_alt);
             __syncthreads();
             zero_halo_b<LB4, NTHR>(act);
             store_tiles_split<4 * CB, LB4, 1, 2>(act, bias_, acc_, wave, lane);
@@ -536,7 +541,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         {
             f32x4 acc5[T4M][T4N], bias5s[T4N];                           // conv5: 64 -> 64 @8x8 in the exact path's tiling (the heads read it)
             prefetch_bias<NW, 8, T4M, T4N>(a.packed + a.off.b[5], bias5s, wave, lane);
-            conv3x3_mfma_s3p<NW, 4 * CB, 4 * CB, LB4, 1, T4M, T4N>(act, a.packed + a.off.w_s3[5], acc5, wave, lane);
+            conv3x3_mfma_s3p<NW, 4 * CB, 4 * CB, LB4, 1, T4M, T4N>(act, a.packed + a.off.w_s3[5], acc5, wave, lane, s3_alt);
             if constexpr (KIND != AFFNET_NET_HARDNET)
                 head_partials<KIND, T4M>(a.packed + a.off.head_w, bias5s, acc5,
                                          a.out + pidx * (KIND == AFFNET_NET_AFFNET ? HEAD_PART_AFF : HEAD_PART_ORI), wave, lane);
@@ -889,6 +894,7 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
     // small-tile loops reach 85-90 % of the pipe rate with two waves per SIMD; 16-wave HardNet workgroups - slower too.)
 #define TRUNK_LAUNCH(K) do { if (a.dbg_time || dbg_layer >= 0) hipLaunchKernelGGL((cnn32_trunk_kernel<K, 8, true>), grid, dim3(512), 0, st, a, ps); \
                              else hipLaunchKernelGGL((cnn32_trunk_kernel<K, 8, false>), grid, dim3(512), 0, st, a, ps); } while (0)
+    a.s3_alt = ctx->split3_alt ? 1 : 0;
     const bool s3 = ctx->split3 && !a.dbg_time && dbg_layer < 0;      // EXPLORATORY (affnet_debug_split3): split-operand layers
     if (ctx->split3 && a.dbg_time && dbg_layer < 0 && kind == AFFNET_NET_HARDNET)      // phase stamps of the split-operand HardNet (tuning aid)
         hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_HARDNET, 8, true, true>), grid, dim3(512), 0, st, a, ps);
@@ -977,6 +983,7 @@ int aff_hardnet_forward_pyr_marked(affnet_ctx* ctx, const float* packed, const f
 
 extern "C" int affnet_debug_split3(affnet_ctx* ctx, int on) {
     if (!ctx) return AFFNET_ERR_INVALID;
+    ctx->split3_alt = (on & 2) == 0;      // on = 3: split operands without the alternating wave priorities (A/B aid)
     ctx->split3 = on != 0;      // EXPLORATORY: conv1 .. conv5 of the three trunks on split operands (fp32 = 3 x bf16) for this context's launches
     return AFFNET_OK;
 }

@@ -426,7 +426,7 @@ __device__ __forceinline__ void store_tiles_split(float* act, const f32x4 (&bias
 
 // The contraction on a PRE-SPLIT input (layout LI = LayB): no VALU in the loop - three ds_read_b128 per pixel tile and k = 32 step.
 template <int NW, int CIN, int COUT, typename LI, int STRIDE, int TM, int TN>
-__device__ __forceinline__ void conv3x3_mfma_s3p(const float* act, const float* __restrict__ Ws, f32x4 (&acc)[TM][TN], int wave, int lane) {
+__device__ __forceinline__ void conv3x3_mfma_s3p(const float* act, const float* __restrict__ Ws, f32x4 (&acc)[TM][TN], int wave, int lane, bool alt_prio) {
     constexpr int HOUT = LI::H / STRIDE, WOUT = LI::W / STRIDE;
     constexpr int MT = HOUT * WOUT / 16, NT = COUT / 16;
     constexpr int MG = MT / TM, NG = NT / TN;
@@ -472,6 +472,10 @@ __device__ __forceinline__ void conv3x3_mfma_s3p(const float* act, const float* 
         for (int t = 0; t < 3; ++t) a[i][t] = __builtin_bit_cast(bf16x8, lds_read4(ab + a_imm(i) + t * LI::TS));
     };
     auto step = [&](const bf16x8 (&wc)[3][TN], int s_next) {
+        if (alt_prio) {                       // the two waves of a SIMD (w, w + 4) take turns at the higher priority, one step each
+            if ((s_next ^ (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         const unsigned ab = frag_addr(s_next);
         constexpr int TW[6] = {0, 1, 2, 0, 1, 0}, TA[6] = {2, 1, 0, 1, 0, 0};      // smallest terms first
 #pragma unroll
@@ -497,12 +501,13 @@ __device__ __forceinline__ void conv3x3_mfma_s3p(const float* act, const float* 
         step(w[1], (s + 2 < NS) ? s + 2 : s + 1);                        // the last step re-reads its own fragments (never used)
     }
     if (NS & 1) step(w[0], NS - 1);
+    if (alt_prio) __builtin_amdgcn_s_setprio(0);
 }
 
 // Pre-split input with 16 channels (AffNet / OriNet conv1, conv2): one k = 32 step = two taps x 16 channels
 // (lane group kq: tap 2 s + (kq >> 1), channel group kq & 1), fragments read ready from a LayB layout with the rotating schedule.
 template <int NW, int COUT, typename LI, int STRIDE, int TM, int TN>
-__device__ __forceinline__ void conv3x3_mfma_s3p_c16(const float* act, const float* __restrict__ Ws, f32x4 (&acc)[TM][TN], int wave, int lane) {
+__device__ __forceinline__ void conv3x3_mfma_s3p_c16(const float* act, const float* __restrict__ Ws, f32x4 (&acc)[TM][TN], int wave, int lane, bool alt_prio) {
     constexpr int HOUT = LI::H / STRIDE, WOUT = LI::W / STRIDE;
     constexpr int MT = HOUT * WOUT / 16, NT = COUT / 16;
     constexpr int MG = MT / TM, NG = NT / TN;
@@ -545,6 +550,10 @@ __device__ __forceinline__ void conv3x3_mfma_s3p_c16(const float* act, const flo
             for (int j = 0; j < TN; ++j)
                 w[t][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_lane + j * 256, ((s * 3 + t) * 4 * COUT) * 16, 0));
         const unsigned abn = frag_addr(s + 1 < 5 ? s + 1 : s);
+        if (alt_prio) {
+            if ((s ^ (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
         constexpr int TW[6] = {0, 1, 2, 0, 1, 0}, TA[6] = {2, 1, 0, 1, 0, 0};
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -560,6 +569,7 @@ __device__ __forceinline__ void conv3x3_mfma_s3p_c16(const float* act, const flo
             }
         }
     }
+    if (alt_prio) __builtin_amdgcn_s_setprio(0);
 }
 
 // Same contraction with ONE A register set that is reloaded in place (for TM = 8 under a 128-VGPR budget, where two

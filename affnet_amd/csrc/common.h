@@ -105,6 +105,7 @@ struct affnet_ctx {
     int prof_calls = 0;
     // tuning aid (include/affnet_hip_debug.h): s_memtime stamp buffer of THIS context's CNN launches, or NULL
     unsigned long long* dbg_time = nullptr;
+    bool split3_alt = true;            // EXPLORATORY: alternating wave priorities in the split loops (affnet_debug_split3 bit 1 clears it)
     bool split3 = false;               // EXPLORATORY (affnet_debug_split3): HardNet trunk layers on split bf16 operands; never the default
     // the whole path captured as one HIP graph (affnet_graph_capture_extract): one launch instead of ~45 for latency-bound callers
     hipGraph_t graph = nullptr;

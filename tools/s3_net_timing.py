@@ -14,7 +14,7 @@ O = affnet_amd.OriNetFast(PS=32); O.load_state_dict(torch.load(os.path.join(ROOT
 H = affnet_amd.HardNet(); H.load_state_dict(affnet_amd.synthetic_hardnet_state(0)); H.to(dev)
 big = (torch.rand(48000, 1, 32, 32) * 255).to(dev)
 ctx = engine.utility_ctx(dev)
-for split in (0, 1, 0, 1):
+for split in (0, 1, 3, 1, 3):          # 0 exact, 1 split operands, 3 split without the alternating wave priorities (A/B)
     lib.affnet_debug_split3(ctx, split)
     row = []
     for nm, net in (("AffNet", A), ("OriNet", O), ("HardNet", H)):
@@ -25,5 +25,5 @@ for split in (0, 1, 0, 1):
             e0.record(); net(big); e1.record(); torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1))
         row.append("%s %.3f ms" % (nm, best))
-    print("split3" if split else "exact ", " | ".join(row))
+    print({0: "exact        ", 1: "split3       ", 3: "split3 no-alt"}[split], " | ".join(row))
 lib.affnet_debug_split3(ctx, 0)
