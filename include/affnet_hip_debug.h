@@ -57,8 +57,9 @@ int affnet_debug_stream(const void* d_src, void* d_dst, size_t n_bytes, int widt
 /* EXPLORATORY: != 0 = this context's AffNet / OriNet / HardNet trunk launches run conv1 .. conv5 (S3_LAYER_MASK, csrc/cnn_mfma.h) on split
  * operands: six v_mfma_f32_16x16x32_bf16 products per fp32 product, fp32 accumulate, activations pre-split into bf16 planes in LDS
  * ("Split-operand trunks").  The packed blobs always carry the split copy of those layers' weights.  Default 0: exact
- * fp32 MFMA, and switching back restores it bit for bit (test_exploratory_split3_trunks_vs_exact_trunks).  Used only by bench.py --split3 /
- * its `split3_exploratory` field and the tests. */
+ * fp32 MFMA, and switching back restores it bit for bit (test_exploratory_split3_trunks_vs_exact_trunks).  on = 3: the same without the
+ * alternating wave priorities of the HardNet loops (A/B aid of tools/s3_net_timing.py; results identical).  Used only by bench.py
+ * --split3 / its `split3_exploratory` field, the tests and the tools. */
 int affnet_debug_split3(affnet_ctx* ctx, int on);
 int affnet_split3_gemm(const float* d_A, const float* d_Bt, int M, int N, int K, int mode, float* d_C, void* stream);
 int affnet_split3_rate(int reps, int terms, int n_blocks, float* d_out, void* stream);
