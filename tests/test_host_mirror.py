@@ -3,6 +3,7 @@
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -204,3 +205,24 @@ def test_headers_are_plain_c():
         subprocess.check_call(["gcc", "-std=c99", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", h)])
         src = open(os.path.join(ROOT, "include", h)).read()
         assert "hip/" not in src and "torch" not in re.sub(r"/\*.*?\*/", "", src, flags=re.S), h
+
+
+def test_bench_finds_the_counter_traffic_of_its_dominant_kernel():
+    """bench.py fills roofline.traffic from the committed rocprofv3 --pmc passes; the trunk kernel's name gained template arguments over the
+    rounds, and a lookup under an old name silently produced `traffic: null` once (round 3).  Both instantiations must be found in profiles/."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_for_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    argv = sys.argv
+    try:
+        sys.argv = ["bench.py"]
+        spec.loader.exec_module(bench)
+    finally:
+        sys.argv = argv
+    exact, note = bench.pmc_traffic(32)
+    assert exact and 2.0e9 < exact < 6.0e9 and "traffic.json" in note, (exact, note)        # ~3.8 GB per 32-image HardNet trunk launch
+    split, note3 = bench.pmc_traffic(32, split=True)
+    assert split and 2.0e9 < split < 8.0e9 and "traffic.json" in note3, (split, note3)
+    half, _ = bench.pmc_traffic(16)
+    assert abs(half * 2 - exact) < 1e-3 * exact
