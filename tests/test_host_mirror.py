@@ -226,3 +226,34 @@ def test_bench_finds_the_counter_traffic_of_its_dominant_kernel():
     assert split and 2.0e9 < split < 8.0e9 and "traffic.json" in note3, (split, note3)
     half, _ = bench.pmc_traffic(16)
     assert abs(half * 2 - exact) < 1e-3 * exact
+
+
+@pytest.mark.parametrize("kind,name", [(0, "AffNet"), (1, "OriNet"), (2, "HardNet")])
+def test_split_weight_copies_are_exact(kind, name, weights):
+    """EXPLORATORY split-operand path (affnet_debug_split3): the packed blob carries conv1 .. conv5 once more as three bf16 terms in the
+    bf16 MFMA's fragment order.  The three terms of a weight must add up to the BN-folded fp32 weight of the exact path EXACTLY (24-bit
+    significand = 3 x 8 bits, exact remainders) - the split path's only error is then the 2^-25 of the six-product truncation - and sit
+    where the kernels read them: [tap][cin/32][term][kq][cout][8] (cin >= 32), [step][term][kq = 2 (tap & 1) + c / 8][cout][8] (cin = 16)."""
+    from affnet_amd import engine
+    blob = engine.pack_state_dict(kind, weights[name])
+    layers, off = _unpack_trunk(kind, blob)
+    off += {0: 3 * 4096 + 4, 1: 2 * 4096 + 4, 2: 8192 * 128 + 128}[kind]          # behind the head weights and bias
+    bits = blob.numpy().view(np.uint16)
+    for i in range(1, 6):
+        W = layers[i][0].numpy().astype(np.float64)                                   # (co, ci, 3, 3): what the fp32 path multiplies with
+        co, ci = W.shape[:2]
+        n_fl = (5 if ci == 16 else 9 * (ci // 32)) * 3 * 4 * co * 4
+        raw = bits[2 * off: 2 * (off + n_fl)].astype(np.uint32) << 16
+        terms = raw.view(np.float32).astype(np.float64)
+        if ci == 16:
+            t = terms.reshape(5, 3, 2, 2, co, 8).transpose(1, 4, 3, 5, 0, 2).reshape(3, co, 16, 10)     # (term, n, c = 8 cg + j, tap = 2 step + half)
+            assert np.all(t[..., 9] == 0.0), "the pad half-step must multiply zeros"
+            t = t[..., :9]
+        else:
+            t = terms.reshape(9, ci // 32, 3, 4, co, 8).transpose(2, 4, 1, 3, 5, 0).reshape(3, co, ci, 9)
+        rec = t.sum(axis=0).reshape(co, ci, 3, 3)
+        assert np.array_equal(rec, W), (name, i, float(np.abs(rec - W).max()))
+        mag = np.abs(t)                                                               # term k is at most 2^-8 of term k - 1 (nearest-even split)
+        assert np.all(mag[1] <= mag[0] * 2.0 ** -8 + 1e-45) and np.all(mag[2] <= mag[1] * 2.0 ** -8 + 1e-45)
+        off += n_fl
+    assert off == blob.numel(), (off, blob.numel())
