@@ -257,3 +257,20 @@ def test_split_weight_copies_are_exact(kind, name, weights):
         assert np.all(mag[1] <= mag[0] * 2.0 ** -8 + 1e-45) and np.all(mag[2] <= mag[1] * 2.0 ** -8 + 1e-45)
         off += n_fl
     assert off == blob.numel(), (off, blob.numel())
+
+
+def test_roofline_table_regenerates_from_the_tracked_evidence():
+    """tools/roofline_table.py on the newest full evidence set in profiles/: runs, prices the exact-fp32 trunks against the fp32 MFMA peak
+    with no fraction above 1 (round 2 printed 204 % for the lazily evaluated AffNet), and labels the split-operand instantiations."""
+    import glob
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sets = sorted(f[:-len("_kernel_stats.csv")] for f in glob.glob(os.path.join(root, "profiles", "r*_s*_kernel_stats.csv"))
+                  if "split3" not in f and "config" not in f and "onepass" not in f)
+    sets = [s for s in sets if os.path.exists(s + "_traffic.json") and os.path.exists(s + "_bench_default.json")]
+    assert sets, "no full evidence set in profiles/"
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "roofline_table.py"), sets[-1]], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-400:]
+    fracs = [float(m) for m in re.findall(r"= ([0-9.]+) % of 157\.3", out.stdout)]
+    assert len(fracs) >= 4 and max(fracs) < 100.0 and max(fracs) > 80.0, fracs
+    assert "bench line:" in out.stdout
