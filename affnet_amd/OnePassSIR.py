@@ -25,8 +25,10 @@ from .HandCraftedModules import OrientationDetector, _HipHandCrafted
 
 class OnePassSIR(nn.Module):
     def __init__(self, border=16, num_features=500, patch_size=32, mrSize=3.0, nlevels=3, th=None, num_Baum_iters=0, init_sigma=1.6,
-                 RespNet=None, OriNet=None, AffNet=None):
+                 RespNet=None, OriNet=None, AffNet=None, arith="fp32"):
         super(OnePassSIR, self).__init__()
+        self.arith = arith           # "fp32" (exact fp32 MFMA, default) / "fp32_split3": see ScaleSpaceAffinePatchExtractor
+        _lib.arith_code(arith)
         self.mrSize, self.PS, self.b = mrSize, patch_size, border
         self.num, self.th = num_features, th
         if th is not None:          # OnePassSIR.py:31-34
@@ -54,14 +56,18 @@ class OnePassSIR(nn.Module):
             raise ValueError("expected a (B,1,H,W) image batch (B = 1: the reference's shape)")
         key = (x.size(0), x.size(2), x.size(3), x.device, self.num, float(self.th), self.mrSize, self.b, self.init_sigma, self.nlevels, self.max_keep,
                self.raw_div)
+        if self._ctx is not None and self._ctx_key == key and self._ctx.arith != _lib.arith_code(self.arith):
+            self._ctx.set_arith(self.arith)
         if self._ctx is None or self._ctx_key != key:
             self._ctx = engine.Context(x.size(2), x.size(3), x.device, self.nlevels, self.init_sigma, self.b, self.mrSize, float(self.th), self.num,
-                                       self.num, self.max_keep, batch=x.size(0), baum_iters=0, raw_div=self.raw_div, onepass=True)
+                                       self.num, self.max_keep, batch=x.size(0), baum_iters=0, raw_div=self.raw_div, onepass=True, arith=self.arith)
             self._ctx_key = key
         return self._ctx
 
     def enqueue(self, x, do_ori=True, desc=None):
         """Whole path without host synchronisation; x (B,1,H,W).  Returns capacity-sized device tensors + the device row counts."""
+        if do_ori and not isinstance(self.OriNet, (_HipPatchNet, _HipHandCrafted)):      # before anything is enqueued
+            raise NotImplementedError("enqueue() is the no-synchronisation path: a foreign OriNet runs Python between the stages - use run() / forward()")
         ctx = self._context(x)
         dev, st = x.device, engine.stream_of(x.device)
         img = x.contiguous().float()
@@ -72,8 +78,6 @@ class OnePassSIR(nn.Module):
         count = torch.zeros(B, dtype=torch.int32, device=dev)
         dsc = torch.empty(B, F, 128, dtype=torch.float32, device=dev) if desc is not None else None
         self._detect(ctx, img, st)
-        if do_ori and not isinstance(self.OriNet, (_HipPatchNet, _HipHandCrafted)):
-            raise NotImplementedError("enqueue() is the no-synchronisation path: a foreign OriNet runs Python between the stages - use run() / forward()")
         nets = _lib.Nets()
         if do_ori:
             if isinstance(self.OriNet, _HipHandCrafted):

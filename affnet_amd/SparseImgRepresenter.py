@@ -27,8 +27,11 @@ from .HandCraftedModules import AffineShapeEstimator, OrientationDetector, _HipH
 
 class ScaleSpaceAffinePatchExtractor(nn.Module):
     def __init__(self, border=16, num_features=500, patch_size=32, mrSize=3.0, nlevels=3, num_Baum_iters=0,
-                 init_sigma=1.6, th=None, RespNet=None, OriNet=None, AffNet=None):
+                 init_sigma=1.6, th=None, RespNet=None, OriNet=None, AffNet=None, arith="fp32"):
         super(ScaleSpaceAffinePatchExtractor, self).__init__()
+        self.arith = arith           # arithmetic of the native CNN slots' contractions: "fp32" = exact fp32 MFMA (default), "fp32_split3" = fp32 as
+                                     # three bf16 terms on the bf16 MFMA, fp32 accumulate (include/affnet_hip.h AFFNET_ARITH_*; same parity bars)
+        _lib.arith_code(arith)       # raises on an unknown mode
         self.mrSize, self.PS, self.b = mrSize, patch_size, border
         self.num, self.nlevels = num_features, nlevels
         self.num_Baum_iters, self.init_sigma = num_Baum_iters, init_sigma
@@ -61,10 +64,12 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
         pre = int(1.5 * self.num) if self.num_Baum_iters > 0 else self.num
         key = (x.size(0), x.size(2), x.size(3), x.device, pre, self.num, float(self.th), self.mrSize, self.b, self.init_sigma,
                self.nlevels, self.max_keep, self.num_Baum_iters, self.raw_div, self.lazy_shape_rows)
+        if self._ctx is not None and self._ctx_key == key and self._ctx.arith != _lib.arith_code(self.arith):
+            self._ctx.set_arith(self.arith)          # same buffers, other arithmetic: no new context
         if self._ctx is None or self._ctx_key != key:
             self._ctx = engine.Context(x.size(2), x.size(3), x.device, self.nlevels, self.init_sigma, self.b, self.mrSize,
                                        float(self.th), self.num, pre, self.max_keep, batch=x.size(0), baum_iters=self.num_Baum_iters, raw_div=self.raw_div,
-                                       lazy_shape_rows=self.lazy_shape_rows)
+                                       lazy_shape_rows=self.lazy_shape_rows, arith=self.arith)
             self._ctx_key = key
         return self._ctx
 

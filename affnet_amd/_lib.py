@@ -12,6 +12,21 @@ LIB_PATH = os.path.join(_HERE, "libaffnet_hip.so")
 
 MAX_OCTAVES, MAX_LEVELS, MAX_TAPS = 16, 8, 37
 NET_AFFNET, NET_ORINET, NET_HARDNET, NET_AFFNET_FULLCONV = 0, 1, 2, 3
+ARITH_FP32_MFMA, ARITH_FP32_SPLIT3 = 0, 1        # include/affnet_hip.h AFFNET_ARITH_*
+ARITH_NAMES = {"fp32": ARITH_FP32_MFMA, "fp32_mfma": ARITH_FP32_MFMA, "fp32_split3": ARITH_FP32_SPLIT3, "split3": ARITH_FP32_SPLIT3}
+
+
+def arith_code(arith):
+    """'fp32' (default: exact fp32 MFMA) / 'fp32_split3' (fp32 = 3 x bf16 split operands) or an AFFNET_ARITH_* integer -> the integer."""
+    if arith is None:
+        return ARITH_FP32_MFMA
+    if isinstance(arith, str):
+        if arith.lower() not in ARITH_NAMES:
+            raise ValueError("arith must be one of %s" % sorted(ARITH_NAMES))
+        return ARITH_NAMES[arith.lower()]
+    if int(arith) not in (ARITH_FP32_MFMA, ARITH_FP32_SPLIT3):
+        raise ValueError("arith must be AFFNET_ARITH_FP32_MFMA (0) or AFFNET_ARITH_FP32_SPLIT3 (1)")
+    return int(arith)
 OK, ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_EMPTY = 0, -1, -2, -3, -4
 
 
@@ -32,6 +47,7 @@ class Config(C.Structure):
         ("mr_size", C.c_float), ("threshold", C.c_float),
         ("num_features", C.c_int32), ("num_prefilter", C.c_int32),
         ("max_raw_per_octave_div", C.c_int32), ("max_keep", C.c_int32), ("batch", C.c_int32), ("baum_iters", C.c_int32),
+        ("arith", C.c_int32),
     ]
 
 
@@ -47,6 +63,8 @@ SYMBOLS = {
     "affnet_ctx_destroy": (None, [_P]),
     "affnet_last_error": (C.c_char_p, [_P]),
     "affnet_version": (C.c_char_p, []),
+    "affnet_set_arith": (_I, [_P, _I]),
+    "affnet_get_arith": (_I, [_P]),
     "affnet_workspace_bytes": (_SZ, [_P]),
     "affnet_bind_workspace": (_I, [_P, _P, _SZ]),
     "affnet_pyramid_level_offset": (C.c_int64, [_P, _I, _I]),
@@ -107,7 +125,7 @@ DEBUG_SYMBOLS = {
     "affnet_cnn32_debug_layer": (_I, [_P, _I, _P, _P, _I, _P, _P]),
     "affnet_cnn32_probe": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "affnet_selftest_mfma": (_I, [_P, _P, _P, _P]),
-    "affnet_debug_split3": (_I, [_P, _I]),
+    "affnet_debug_split3_variant": (_I, [_P, _I]),
     "affnet_split3_gemm": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "affnet_split3_rate": (_I, [_I, _I, _I, _P, _P]),
     "affnet_debug_stream": (_I, [_P, _P, _SZ, _I, _I, _I, _P]),

@@ -28,6 +28,8 @@ class _HipPatchNet(nn.Module):
     def __init__(self):
         super(_HipPatchNet, self).__init__()
         self._packed = None            # BN-folded, MFMA-ordered blob on the device
+        self.arith = "fp32"            # stand-alone calls of this net: "fp32" (exact fp32 MFMA, default) or "fp32_split3" (fp32 = 3 x bf16 split
+                                       # operands; include/affnet_hip.h AFFNET_ARITH_*).  Inside an extractor the extractor's `arith` decides.
         self._packed_version = None    # _weights_stamp() it was built from
 
     def _weights_stamp(self):
@@ -58,7 +60,7 @@ class _HipPatchNet(nn.Module):
         if self.training:
             raise RuntimeError("affnet_amd nets are inference-only (call .eval()); training is out of scope")
         engine.require_cuda(patches, "patches")
-        return engine.cnn_forward(self.KIND, self.packed_weights(patches.device), patches)
+        return engine.cnn_forward(self.KIND, self.packed_weights(patches.device), patches, arith=self.arith)
 
 
 class AffNetFast(_HipPatchNet):
@@ -101,7 +103,7 @@ class AffNetFastFullConv(_HipPatchNet):
         engine.require_cuda(input, "image")
         if input.dim() != 4 or input.size(0) != 1 or input.size(1) != 1:
             raise ValueError("expected a (1,1,H,W) image")
-        return engine.fullconv_forward(self.packed_weights(input.device), input)
+        return engine.fullconv_forward(self.packed_weights(input.device), input, arith=self.arith)
 
 
 class OriNetFast(_HipPatchNet):

@@ -895,8 +895,9 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
 #define TRUNK_LAUNCH(K) do { if (a.dbg_time || dbg_layer >= 0) hipLaunchKernelGGL((cnn32_trunk_kernel<K, 8, true>), grid, dim3(512), 0, st, a, ps); \
                              else hipLaunchKernelGGL((cnn32_trunk_kernel<K, 8, false>), grid, dim3(512), 0, st, a, ps); } while (0)
     a.s3_alt = ctx->split3_alt ? 1 : 0;
-    const bool s3 = ctx->split3 && !a.dbg_time && dbg_layer < 0;      // EXPLORATORY (affnet_debug_split3): split-operand layers
-    if (ctx->split3 && a.dbg_time && dbg_layer < 0 && kind == AFFNET_NET_HARDNET)      // phase stamps of the split-operand HardNet (tuning aid)
+    const bool split = ctx->arith == AFFNET_ARITH_FP32_SPLIT3;
+    const bool s3 = split && !a.dbg_time && dbg_layer < 0;             // conv1 .. conv5 on split operands (affnet_set_arith)
+    if (split && a.dbg_time && dbg_layer < 0 && kind == AFFNET_NET_HARDNET)      // phase stamps of the split-operand HardNet (tuning aid)
         hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_HARDNET, 8, true, true>), grid, dim3(512), 0, st, a, ps);
     else if (s3 && kind == AFFNET_NET_AFFNET) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_AFFNET, 8, false, true>), grid, dim3(512), 0, st, a, ps);
     else if (s3 && kind == AFFNET_NET_ORINET) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_ORINET, 8, false, true>), grid, dim3(512), 0, st, a, ps);
@@ -981,10 +982,9 @@ int aff_hardnet_forward_pyr_marked(affnet_ctx* ctx, const float* packed, const f
     return cnn_launch(ctx, AFFNET_NET_HARDNET, packed, nullptr, lafs, ids, count, n_max, out, scratch, -1, nullptr, st, true);
 }
 
-extern "C" int affnet_debug_split3(affnet_ctx* ctx, int on) {
+extern "C" int affnet_debug_split3_variant(affnet_ctx* ctx, int bits) {
     if (!ctx) return AFFNET_ERR_INVALID;
-    ctx->split3_alt = (on & 2) == 0;      // on = 3: split operands without the alternating wave priorities (A/B aid)
-    ctx->split3 = on != 0;      // EXPLORATORY: conv1 .. conv5 of the three trunks on split operands (fp32 = 3 x bf16) for this context's launches
+    ctx->split3_alt = (bits & 2) == 0;      // bit 1: split-operand HardNet loops without the alternating wave priorities (A/B aid)
     return AFFNET_OK;
 }
 

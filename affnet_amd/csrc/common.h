@@ -105,8 +105,8 @@ struct affnet_ctx {
     int prof_calls = 0;
     // tuning aid (include/affnet_hip_debug.h): s_memtime stamp buffer of THIS context's CNN launches, or NULL
     unsigned long long* dbg_time = nullptr;
-    bool split3_alt = true;            // EXPLORATORY: alternating wave priorities in the split loops (affnet_debug_split3 bit 1 clears it)
-    bool split3 = false;               // EXPLORATORY (affnet_debug_split3): HardNet trunk layers on split bf16 operands; never the default
+    int arith = AFFNET_ARITH_FP32_MFMA;   // arithmetic of the CNN contractions (cfg.arith / affnet_set_arith): exact fp32 MFMA or fp32 = 3 x bf16 split operands
+    bool split3_alt = true;            // tuning aid: alternating wave priorities in the split HardNet loops (affnet_debug_split3_variant bit 1 clears it)
     // the whole path captured as one HIP graph (affnet_graph_capture_extract): one launch instead of ~45 for latency-bound callers
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
@@ -168,7 +168,12 @@ struct AffZeroSegs {
     unsigned char* p[8];
     size_t bytes[8];
     int n = 0;
-    void add(void* ptr, size_t nbytes) { if (ptr && nbytes && n < 8) { p[n] = (unsigned char*)ptr; bytes[n] = nbytes; ++n; } }
+    bool overflow = false;   // more than 8 segments were added: aff_zero_multi_async refuses the launch instead of leaving an area uncleared
+    void add(void* ptr, size_t nbytes) {
+        if (!ptr || !nbytes) return;
+        if (n >= 8) { overflow = true; return; }
+        p[n] = (unsigned char*)ptr; bytes[n] = nbytes; ++n;
+    }
 };
 int aff_zero_multi_async(affnet_ctx* ctx, const AffZeroSegs& z, hipStream_t st);
 int aff_copy_async(affnet_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t st);

@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void aff_zero_multi_kernel(AffZeroSegs z) {
 }
 
 int aff_zero_multi_async(affnet_ctx* ctx, const AffZeroSegs& z, hipStream_t st) {
+    if (z.overflow) return aff_fail(ctx, AFFNET_ERR_INVALID, "internal: more than 8 areas in one fused clear (AffZeroSegs)");
     if (z.n <= 0) return AFFNET_OK;
     size_t blocks = 1;
     for (int i = 0; i < z.n; ++i) {
@@ -112,6 +113,7 @@ extern "C" int affnet_host_base_grid(int ps, float* out) {  // exported for the 
 static int validate(affnet_ctx* ctx, const affnet_config* c) {
     if (c->height < 8 || c->width < 8) return aff_fail(ctx, AFFNET_ERR_INVALID, "image %dx%d too small", c->height, c->width);
     if (c->batch > 4096) return aff_fail(ctx, AFFNET_ERR_INVALID, "batch=%d (max 4096)", c->batch);
+    if (c->arith != AFFNET_ARITH_FP32_MFMA && c->arith != AFFNET_ARITH_FP32_SPLIT3) return aff_fail(ctx, AFFNET_ERR_INVALID, "arith=%d (AFFNET_ARITH_*)", c->arith);
     if (c->n_octaves < 1 || c->n_octaves > AFFNET_MAX_OCTAVES) return aff_fail(ctx, AFFNET_ERR_INVALID, "n_octaves=%d", c->n_octaves);
     if (c->levels_per_octave < 3 || c->levels_per_octave > AFFNET_MAX_LEVELS)
         return aff_fail(ctx, AFFNET_ERR_INVALID, "levels_per_octave=%d", c->levels_per_octave);
@@ -141,6 +143,7 @@ extern "C" int affnet_ctx_create(affnet_ctx** out, int device, const affnet_conf
         return AFFNET_OK;
     }
     ctx->cfg = *cfg;
+    ctx->arith = cfg->arith;
     int rc = validate(ctx, cfg);
     if (rc != AFFNET_OK) { *out = ctx; return rc; }
     const affnet_config& c = ctx->cfg;
@@ -213,6 +216,15 @@ extern "C" int affnet_ctx_create(affnet_ctx** out, int device, const affnet_conf
 }
 
 extern "C" void affnet_ctx_destroy(affnet_ctx* ctx) { delete ctx; }
+
+extern "C" int affnet_set_arith(affnet_ctx* ctx, int arith) {
+    if (!ctx) return AFFNET_ERR_INVALID;
+    if (arith != AFFNET_ARITH_FP32_MFMA && arith != AFFNET_ARITH_FP32_SPLIT3) return aff_fail(ctx, AFFNET_ERR_INVALID, "arith=%d (AFFNET_ARITH_*)", arith);
+    ctx->arith = arith;
+    ctx->cfg.arith = arith;
+    return AFFNET_OK;
+}
+extern "C" int affnet_get_arith(const affnet_ctx* ctx) { return ctx ? ctx->arith : AFFNET_ERR_INVALID; }
 
 extern "C" size_t affnet_workspace_bytes(const affnet_ctx* ctx) { return ctx ? ctx->ws_bytes : 0; }
 

@@ -234,9 +234,14 @@ __global__ __launch_bounds__(256, (NL <= 5 ? 3 : 1)) void hessian_nms_kernel(Hes
             const bool border_ok = (hp.border < w) && (hp.border < h);
             // NMS: each thread owns 4 pixels of one row.  Per level the 3 x 6 response window is read once; the three-row column
             // maxima are shared by the 4 pixels and by the NL - 2 detection levels (max is order-independent: same values).
-            const int ty = threadIdx.x >> 4, txb = (threadIdx.x & 15) * 4;
+            int tn = threadIdx.x;                 // opaque per tile like tq below: the 12 queue codes (l << 10 | ty << 6 | tx) are loop invariants too
+            asm volatile("" : "+v"(tn));
+            const int ty = tn >> 4, txb = (tn & 15) * 4;
             const int gy = y0 + ty;
-            float cm[NL][6], ctr[NL][4];
+            // m5[l][q]: 3 x 3 maximum around pixel q of level l.  (Kept per level as the six column maxima cm[l][0..5] and reduced per
+            // pixel later, the 30 + 20 live registers of this pass put the NL = 5 instantiation 5 VGPRs over the 168 that three
+            // workgroups per CU allow: 5 spilled registers, 24 B of scratch per thread.  max is order-independent: same values.)
+            float m5[NL][4], ctr[NL][4];
 #pragma unroll
             for (int l = 0; l < NL; ++l) {
                 // top-left of the window of pixel txb (response tile has a 1-px halo); txb is a multiple of 4 and the rows are 16-byte
@@ -250,11 +255,14 @@ __global__ __launch_bounds__(256, (NL <= 5 ? 3 : 1)) void hessian_nms_kernel(Hes
                     const float2 q2 = *reinterpret_cast<const float2*>(r + dy * HR_S + 4);
                     win[dy][0] = q4.x; win[dy][1] = q4.y; win[dy][2] = q4.z; win[dy][3] = q4.w; win[dy][4] = q2.x; win[dy][5] = q2.y;
                 }
+                float cm[6];
 #pragma unroll
                 for (int k = 0; k < 6; ++k) {
-                    cm[l][k] = fmaxf(fmaxf(win[0][k], win[1][k]), win[2][k]);
+                    cm[k] = fmaxf(fmaxf(win[0][k], win[1][k]), win[2][k]);
                     if (k >= 1 && k <= 4) ctr[l][k - 1] = win[1][k];
                 }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) m5[l][q] = fmaxf(fmaxf(cm[q], cm[q + 1]), cm[q + 2]);
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -262,14 +270,11 @@ __global__ __launch_bounds__(256, (NL <= 5 ? 3 : 1)) void hessian_nms_kernel(Hes
                 if (gx >= w || gy >= h) break;
                 const bool in_border = !border_ok || gy < hp.border || gy >= h - hp.border || gx < hp.border || gx >= w - hp.border;
                 if (in_border) continue;                      // zero_response_at_border -> nms value 0 -> never a candidate
-                float m5[NL];
-#pragma unroll
-                for (int l = 0; l < NL; ++l) m5[l] = fmaxf(fmaxf(cm[l][q], cm[l][q + 1]), cm[l][q + 2]);
                 unsigned hits = 0;
 #pragma unroll
                 for (int l = 1; l <= NL - 2; ++l) {
                     const float c = ctr[l][q];
-                    const float M = fmaxf(fmaxf(m5[l - 1], m5[l]), m5[l + 1]);
+                    const float M = fmaxf(fmaxf(m5[l - 1][q], m5[l][q]), m5[l + 1][q]);
                     const float d = c - M;
                     const float e = d + 1e-5f;
                     if (!(e > 0.0f) || c == 0.0f) continue;    // keep * x == 0 -> contributes nothing anywhere
@@ -281,7 +286,12 @@ __global__ __launch_bounds__(256, (NL <= 5 ? 3 : 1)) void hessian_nms_kernel(Hes
         __syncthreads();
         const int n_q = s_n;
         if (n_q == 0) continue;                               // uniform
-        for (int e = threadIdx.x; e < n_q; e += 256) {
+        // The thread index of the centroid / copy-out part is made opaque per tile: derived from threadIdx.x, its loop-invariant addresses
+        // (queue slots, staging-list rows at 1 KB steps) were hoisted out of the tile loop and held in registers across the whole tile -
+        // what pushed the NL = 5 instantiation 5 VGPRs over the 168 of three workgroups per CU (5 spills, 24 B of scratch per thread).
+        int tq = threadIdx.x;
+        asm volatile("" : "+v"(tq));
+        for (int e = tq; e < n_q; e += 256) {
             const unsigned code = s_queue[e];
             const int l = (code >> 10) & 63, qy = (code >> 6) & 15, qx = code & 63;
             const unsigned lower = code >> 16;
@@ -331,10 +341,10 @@ __global__ __launch_bounds__(256, (NL <= 5 ? 3 : 1)) void hessian_nms_kernel(Hes
         }
         __syncthreads();
         const int n_loc = n_q < HN_CAP ? n_q : HN_CAP;
-        if (threadIdx.x == 0) s_base = atomicAdd(p.raw_cnt, n_loc);
+        if (tq == 0) s_base = atomicAdd(p.raw_cnt, n_loc);
         __syncthreads();
         const int base = s_base;
-        for (int i = threadIdx.x; i < n_loc; i += 256) {
+        for (int i = tq; i < n_loc; i += 256) {
             if (base + i < p.raw_cap) p.raw[base + i] = s_list[i];
             else atomicOr(overflow, 1);
         }

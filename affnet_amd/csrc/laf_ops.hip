@@ -127,8 +127,10 @@ __global__ __launch_bounds__(256) void shape_filter_kernel(const float* __restri
 //   otherwise      -> stable compaction of the good rows                              - nonzero branch (:154-156)
 // The detector hands over rows sorted by descending response (CNT_SEL_MODE == 1) whenever it had more candidates than C, and then
 // "the N largest keys" are simply the first N good rows: both branches are a prefix count of the good flags.  Only when the rows
-// are NOT sorted (fewer than C candidates) and there are more than N survivors - or the N-th good row's key is not positive, so
-// that the zero keys of rejected rows compete with it - the keys are ranked by comparison (brute force from LDS tiles; rare and small).
+// are NOT sorted (fewer than C candidates, or caller-supplied rows of affnet_shape_filter_select that are not in descending response
+// order: checked here row by row, the flag of the last detector call alone is not trusted) and there are more than N survivors - or
+// the N-th good row's key is not positive, so that the zero keys of rejected rows compete with it - the keys are ranked by comparison
+// (brute force from LDS tiles; rare and small).
 __global__ __launch_bounds__(1024) void shape_select_kernel(const float* __restrict__ resp, const float* __restrict__ lafs,
                                                             const int32_t* __restrict__ ids, const float* __restrict__ A,
                                                             const float* __restrict__ key, const int32_t* __restrict__ good,
@@ -154,6 +156,7 @@ __global__ __launch_bounds__(1024) void shape_select_kernel(const float* __restr
         if (!topk && surv > out_cap) atomicOr(&cnt[CNT_OVERFLOW], 8);
         s_general = (topk && !sorted) ? 1 : 0;
     }
+    __syncthreads();
     // rows past the output count: zero (the caller's buffers are not cleared separately)
     for (int r = n_out + t; r < out_cap; r += 1024) {
         out_resp[r] = 0.0f;
@@ -165,7 +168,13 @@ __global__ __launch_bounds__(1024) void shape_select_kernel(const float* __restr
     const int seg = (n + 1023) / 1024;
     const int r0 = t * seg, r1 = min(r0 + seg, n);
     int mine = 0;
-    for (int r = r0; r < r1; ++r) mine += good[r] != 0;
+    bool unsorted = false;      // CNT_SEL_MODE is what the context's LAST detector call left behind; the rows handed to the public stage entry
+                                // (affnet_shape_filter_select) may be anything: the prefix shortcut is taken only if they really are sorted
+    for (int r = r0; r < r1; ++r) {
+        mine += good[r] != 0;
+        if (topk && sorted && r > 0 && !(resp[r] <= resp[r - 1])) unsorted = true;
+    }
+    if (unsorted) s_general = 1;     // (thread 0's initialisation of s_general precedes the first barrier below)
     int inc = mine;
 #pragma unroll
     for (int ofs = 1; ofs < 64; ofs <<= 1) {

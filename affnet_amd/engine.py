@@ -17,14 +17,16 @@ def require_cuda(t, what="tensor"):
         raise RuntimeError("affnet_amd: %s must live on the MI355X (tensor.cuda()); this implementation has no CPU path" % what)
 
 
-def utility_ctx(device):
-    """Context without a pyramid, for stand-alone stage calls."""
+def utility_ctx(device, arith=0):
+    """Context without a pyramid, for stand-alone stage calls (one per device and arithmetic mode)."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    if idx not in _UTILITY:
+    key = (idx, _lib.arith_code(arith))
+    if key not in _UTILITY:
         h = C.c_void_p()
         check(lib.affnet_ctx_create(C.byref(h), idx, None), None, "affnet_ctx_create(utility)")
-        _UTILITY[idx] = h
-    return _UTILITY[idx]
+        check(lib.affnet_set_arith(h, key[1]), h, "affnet_set_arith")
+        _UTILITY[key] = h
+    return _UTILITY[key]
 
 
 def stream_of(device):
@@ -35,12 +37,13 @@ class Context(object):
     """One extractor instance on one device: config, workspace, pyramid views."""
 
     def __init__(self, height, width, device, n_levels, init_sigma, border, mr_size, threshold,
-                 num_features, num_prefilter, max_keep=16384, batch=1, baum_iters=0, raw_div=4, onepass=False, lazy_shape_rows=-1):
+                 num_features, num_prefilter, max_keep=16384, batch=1, baum_iters=0, raw_div=4, onepass=False, lazy_shape_rows=-1, arith=0):
         self.plan = PyramidPlan(height, width, n_levels, init_sigma, border)
         self.batch = int(batch)
         self.onepass = bool(onepass)
         self.cfg = self.plan.fill_config(mr_size, threshold, num_features, num_prefilter, max_keep, raw_div=raw_div, batch=self.batch, baum_iters=baum_iters,
-                                         onepass=onepass, lazy_shape_rows=lazy_shape_rows)
+                                         onepass=onepass, lazy_shape_rows=lazy_shape_rows, arith=arith)
+        self.arith = _lib.arith_code(arith)
         self.device = device
         self.handle = C.c_void_p()
         idx = device.index if device.index is not None else torch.cuda.current_device()
@@ -52,6 +55,11 @@ class Context(object):
         self.cap_pre = lib.affnet_capacity_prefilter(self.handle)
         self.cap_final = lib.affnet_capacity_final(self.handle)
         self._ws_f32 = self.workspace.view(torch.float32)
+
+    def set_arith(self, arith):
+        """Switches the arithmetic of this context's CNN contractions (affnet_set_arith); 'fp32' restores the default bit for bit."""
+        self.arith = _lib.arith_code(arith)
+        check(lib.affnet_set_arith(self.handle, self.arith), self.handle, "affnet_set_arith")
 
     def pyramid_views(self, image=0):
         """scale_pyr[o][l] of image `image` of the batch as (1,1,h,w) views into the workspace
@@ -127,7 +135,7 @@ def pack_state_dict(kind, sd):
     return out
 
 
-def cnn_forward(kind, packed, patches, scratch=None):
+def cnn_forward(kind, packed, patches, scratch=None, arith=0):
     """patches (n,1,32,32) or (n,32,32) cuda fp32 -> (n,2,2) / (n,128)."""
     require_cuda(patches, "patches")
     if patches.dim() == 4:
@@ -144,13 +152,13 @@ def cnn_forward(kind, packed, patches, scratch=None):
         return out
     if scratch is None:       # HardNet: conv5 tensors + split-K partials of the head GEMM; AffNet / OriNet: per-wave head partials
         scratch = torch.empty(n * ((8192 + 512) if kind == _lib.NET_HARDNET else 144), dtype=torch.float32, device=dev)
-    ctx = utility_ctx(dev)
+    ctx = utility_ctx(dev, arith)
     rc = lib.affnet_cnn32_forward(ctx, kind, ptr(packed), ptr(patches), None, n, ptr(out), ptr(scratch), stream_of(dev))
     check(rc, ctx, "affnet_cnn32_forward")
     return out
 
 
-def fullconv_forward(packed, img):
+def fullconv_forward(packed, img, arith=0):
     """(1,1,H,W) cuda fp32 -> (1,4,H,W): dense AffNetFastFullConv map (architectures.py:666-674)."""
     img = img.contiguous().float()
     h, w = img.size(2), img.size(3)
@@ -160,7 +168,7 @@ def fullconv_forward(packed, img):
     dev = img.device
     scratch = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
     out = torch.empty(1, 4, h, w, dtype=torch.float32, device=dev)
-    ctx = utility_ctx(dev)
+    ctx = utility_ctx(dev, arith)
     check(lib.affnet_fullconv_forward(ctx, ptr(packed), ptr(img), h, w, ptr(out), ptr(scratch), stream_of(dev)), ctx, "affnet_fullconv_forward")
     return out
 

@@ -59,7 +59,7 @@ class PyramidPlan(object):
         self.blur_sigmas = self.blur_sigmas_per_octave[0]
         self.levels_per_octave = n_levels + 2
 
-    def fill_config(self, mr_size, threshold, num_features, num_prefilter, max_keep=16384, raw_div=4, batch=1, baum_iters=0, onepass=False, lazy_shape_rows=-1):
+    def fill_config(self, mr_size, threshold, num_features, num_prefilter, max_keep=16384, raw_div=4, batch=1, baum_iters=0, onepass=False, lazy_shape_rows=-1, arith=0):
         if self.n_octaves > _lib.MAX_OCTAVES or self.levels_per_octave > _lib.MAX_LEVELS:
             raise ValueError("pyramid too deep for the library limits")
         c = _lib.Config()
@@ -98,6 +98,7 @@ class PyramidPlan(object):
         c.baum_iters = int(baum_iters)
         c.onepass = 1 if onepass else 0
         c.lazy_shape_rows = int(lazy_shape_rows)
+        c.arith = _lib.arith_code(arith)
         return c
 
 

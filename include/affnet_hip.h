@@ -59,6 +59,19 @@ extern "C" {
 #define AFFNET_NET_AFFNET_FULLCONV 3 /* architectures.py:629-674 AffNetFastFullConv: same state-dict layout as AffNetFast (the
                                       * shipped AffNet.pth loads unchanged), evaluated densely on whole images (OnePassSIR)   */
 
+/* Arithmetic of the CNN contractions (the 3x3 conv layers conv1..conv5 of AffNetFast / OriNetFast / HardNet / AffNetFastFullConv and the
+ * HardNet 8x8 head; architectures.py:204-252,33-82,629-674, HardNet.py:61-101).  Everything else - pyramid, detector, sampler, conv0, the
+ * AffNet / OriNet heads, normalisations - is IEEE fp32 in both modes.
+ *   FP32_MFMA   (default): v_mfma_f32_16x16x4_f32, every product and sum in fp32 (an fmaf chain in k order).
+ *   FP32_SPLIT3 : every fp32 operand x is carried as x = x0 + x1 + x2 with each term rounded to bf16 (exact: 3 x 8 significand bits);
+ *                 a product w * a is the six bf16 products w_i * a_j with i + j <= 2 on v_mfma_f32_16x16x32_bf16 (each exact in the
+ *                 fp32 accumulator), accumulated in fp32.  Operands stay fp32 at every interface (weights, activations between layers,
+ *                 outputs); the dropped terms are <= 2^-24 relative per product, i.e. this is another fp32 summation, not narrower
+ *                 arithmetic (K = 8192 dot product: 2.6e-7 of sum|a||b| vs 2.1e-7 for the fmaf chain).  Results
+ *                 differ from FP32_MFMA by summation order only (descriptors ~1e-6); the parity bars are the same for both modes. */
+#define AFFNET_ARITH_FP32_MFMA 0
+#define AFFNET_ARITH_FP32_SPLIT3 1
+
 typedef struct affnet_ctx affnet_ctx;
 
 /*
@@ -104,6 +117,8 @@ typedef struct affnet_config {
                                             * loops in Python; here one launch covers the batch (BASELINE configs[2]). */
     int32_t baum_iters;                    /* num_Baum_iters (ctor kwarg, SparseImgRepresenter.py:22): AffNet shape iterations with
                                             * re-extraction (:127-146); <= 0: 1 when AffNet weights are passed, else none    */
+    int32_t arith;                         /* AFFNET_ARITH_*: arithmetic of the CNN contractions of this context's calls (0 = exact fp32
+                                            * MFMA, the default); may be changed later with affnet_set_arith                        */
 } affnet_config;
 
 /* ---- context ------------------------------------------------------------------------------- */
@@ -116,6 +131,11 @@ void affnet_ctx_destroy(affnet_ctx* ctx);
 const char* affnet_last_error(const affnet_ctx* ctx);
 /* Library / build identification, e.g. "affnet_hip 0.1 gfx950". */
 const char* affnet_version(void);
+/* Arithmetic mode (AFFNET_ARITH_*) of the CNN contractions launched through this context from now on (utility contexts too).  The
+ * packed weight blobs serve both modes; switching back to AFFNET_ARITH_FP32_MFMA restores the default path bit for bit.  A graph
+ * captured earlier (affnet_graph_capture_extract) keeps the mode it was captured with. */
+int affnet_set_arith(affnet_ctx* ctx, int arith);
+int affnet_get_arith(const affnet_ctx* ctx);
 
 /* Bytes of caller-owned device workspace the context needs (pyramid + detector lists +
  * CNN scratch).  Offsets into it are exposed so the host mirror can present the pyramid as

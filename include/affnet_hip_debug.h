@@ -48,19 +48,16 @@ int affnet_selftest_mfma(const float* d_A, const float* d_B, float* d_out, void*
  * factors that tools/pmc_traffic.py applies. */
 int affnet_debug_stream(const void* d_src, void* d_dst, size_t n_bytes, int width, int mode, int halo, void* stream);
 
-/* EXPLORATORY (not used by any product path): fp32 operands as three bf16 terms on v_mfma_f32_16x16x32_bf16 (csrc/split_probe.hip).
+/* Numerics / rate probes of the split-operand arithmetic (AFFNET_ARITH_FP32_SPLIT3): fp32 operands as three bf16 terms on v_mfma_f32_16x16x32_bf16 (csrc/split_probe.hip).
  *   affnet_split3_gemm: d_C (M x N) = d_A (M x K) * d_Bt^T (d_Bt: N x K), M, N multiples of 16, K of 32.  mode 0 = the exact-fp32
  *     v_mfma_f32_16x16x4_f32 chain (today's arithmetic), 1 = six split terms, 2 = nine, 3 = the leading bf16 term only.
  *   affnet_split3_rate: sustained rate of the inner-loop shape a trunk layer would have (fragments from LDS, 4 pixel tiles x 1 channel
  *     tile); terms = 6 / 9 on bf16 MFMA, 1 = the fp32 16x16x4 loop over the same tiles.  One launch = n_blocks x 8 waves x reps x 4 tiles
  *     x (16 x 16 x 32) multiply-adds.  d_out: 2 floats (sink). */
-/* EXPLORATORY: != 0 = this context's AffNet / OriNet / HardNet trunk launches run conv1 .. conv5 (S3_LAYER_MASK, csrc/cnn_mfma.h) on split
- * operands: six v_mfma_f32_16x16x32_bf16 products per fp32 product, fp32 accumulate, activations pre-split into bf16 planes in LDS
- * ("Split-operand trunks").  The packed blobs always carry the split copy of those layers' weights.  Default 0: exact
- * fp32 MFMA, and switching back restores it bit for bit (test_exploratory_split3_trunks_vs_exact_trunks).  on = 3: the same without the
- * alternating wave priorities of the HardNet loops (A/B aid of tools/s3_net_timing.py; results identical).  Used only by bench.py
- * --split3 / its `split3_exploratory` field, the tests and the tools. */
-int affnet_debug_split3(affnet_ctx* ctx, int on);
+/* Tuning aid for AFFNET_ARITH_FP32_SPLIT3 (include/affnet_hip.h: affnet_set_arith is the product switch): variant bits of the
+ * split-operand trunk launches of this context.  bit 1 (value 2): no alternating wave priorities in the HardNet loops (A/B aid of
+ * tools/s3_net_timing.py; results identical).  Does not change the arithmetic mode. */
+int affnet_debug_split3_variant(affnet_ctx* ctx, int bits);
 int affnet_split3_gemm(const float* d_A, const float* d_Bt, int M, int N, int K, int mode, float* d_C, void* stream);
 int affnet_split3_rate(int reps, int terms, int n_blocks, float* d_out, void* stream);
 

@@ -376,6 +376,16 @@ def affnet_forward(sd, patches):
     return rectify_up_is_up(A)
 
 
+def affnet_raw(sd, patches):
+    """architectures.py:227-229,240-246: the three numbers AffNetFast builds its matrix from, (1 + x0, x1, 1 + x2) = (a11, a21, a22) BEFORE
+    rectifyAffineTransformationUpIsUp.  This is what the reference's own TorchScript trace convertJIT/AffNetJIT.pt returns
+    (convertJIT/convert_OriNet_and_AffNet_to_JIT.ipynb), i.e. the quantity a second, independently produced CNN oracle can be compared on."""
+    y = cnn_trunk(sd, input_norm(patches))
+    y = torch.tanh(F.conv2d(y, sd["features.19.weight"], sd["features.19.bias"]))
+    xy = F.adaptive_avg_pool2d(y, 1).view(-1, 3)
+    return xy + torch.tensor([1.0, 0.0, 1.0])
+
+
 def affnet_batched(sd, patches, bs=256):
     """Utils.py:37-66 (batched_forward, chunks of 256)."""
     n = patches.size(0)

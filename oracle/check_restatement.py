@@ -94,6 +94,14 @@ def run(fast=False):
         ok &= same("LAFs", L.numpy(), L2.numpy())
         ok &= same("responses", r.numpy(), r2.numpy())
         ok &= same("descriptors", D.numpy(), D2.numpy())
+    # second opinion on the two CNN trunks: the reference's own TorchScript traces (convertJIT/*.pt), run live
+    print("== AffNet / OriNet restatement vs the reference's TorchScript traces (raw outputs; float noise allowed: std_mean vs mean + std)")
+    rp = torch.rand(64, 1, 32, 32, generator=torch.Generator().manual_seed(7)) * 255
+    with torch.no_grad():
+        for nm, got in (("AffNetJIT.pt", orc.affnet_raw(aff_sd, rp)), ("OriNetJIT.pt", orc.orinet_vector(ori_sd, rp))):
+            d = float((rh.load_jit_trace(nm)(rp) - got).abs().max())
+            print("  %-40s max abs diff %.3g %s" % (nm, d, "ok" if d < 2e-6 else "MISMATCH"))
+            ok &= d < 2e-6
     # OnePassSIR (fully-convolutional AffNet once per octave) - oracle/onepass_oracle.py
     print("== OnePassSIR path (AffNetFastFullConv with the shipped AffNet.pth, border = 15 as in the reference's scripts)")
     x = orc.synthetic_image(240, 320, 1)

@@ -78,6 +78,15 @@ def load_state_dict(name):
     return ck["state_dict"]
 
 
+def load_jit_trace(name):
+    """The reference's own TorchScript traces of the two shape / orientation CNNs (convertJIT/AffNetJIT.pt, OriNetJIT.pt), loaded
+    where they lie: a second CNN oracle that shares no code with oracle/affnet_oracle.py."""
+    import torch
+    m = torch.jit.load(os.path.join(REF_ROOT, "convertJIT", name), map_location="cpu")
+    m.eval()
+    return m
+
+
 def import_onepass_sir():
     """OnePassSIR.py cannot be imported under Python 3: its forward() holds ONE Python-2 statement
     (`print time.time() - t, 'detection multiscale'`, OnePassSIR.py:144).  The source is read from the reference, that single

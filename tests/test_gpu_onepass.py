@@ -100,14 +100,23 @@ def test_nms2d(amd):
         assert int((got > 0).sum()) > 10
 
 
-def _check_onepass(amd, nets, weights, x, n, name, do_ori=True, th=None):
+ARITH = ["fp32", "fp32_split3"]        # include/affnet_hip.h AFFNET_ARITH_*: both modes run the end-to-end cases with the same bars
+_ORACLE_RUNS = {}
+
+
+def _check_onepass(amd, nets, weights, x, n, name, do_ori=True, th=None, arith="fp32"):
     FC, O, H = nets
-    det = amd.OnePassSIR(mrSize=5.192, num_features=n, border=15, num_Baum_iters=1, th=th, AffNet=FC, OriNet=O).to(DEV)
+    name = name + ("" if arith == "fp32" else " [arith %s]" % arith)
+    det = amd.OnePassSIR(mrSize=5.192, num_features=n, border=15, num_Baum_iters=1, th=th, AffNet=FC, OriNet=O, arith=arith).to(DEV)
     res = det.run(x.to(DEV), do_ori=do_ori, desc=H)
-    ex = opo.OnePassOracle(mrSize=5.192, num_features=n, border=15, th=th, affnet_sd=weights["AffNet"], orinet_sd=weights["OriNet"])
-    Lw, rw = ex(x, do_ori=do_ori)
-    with torch.no_grad():
-        Dw = orc.hardnet_forward(weights["HardNet"], ex.extract_patches_from_pyr(Lw, PS=32))
+    key = (tuple(x.shape), float(x.sum()), n, do_ori, th)
+    if key not in _ORACLE_RUNS:            # the CPU oracle's output is shared by the arithmetic-mode parametrisation
+        ex = opo.OnePassOracle(mrSize=5.192, num_features=n, border=15, th=th, affnet_sd=weights["AffNet"], orinet_sd=weights["OriNet"])
+        Lw, rw = ex(x, do_ori=do_ori)
+        with torch.no_grad():
+            Dw = orc.hardnet_forward(weights["HardNet"], ex.extract_patches_from_pyr(Lw, PS=32))
+        _ORACLE_RUNS[key] = (ex, Lw, rw, Dw)
+    ex, Lw, rw, Dw = _ORACLE_RUNS[key]
     L, r, D = res["LAFs"].cpu().numpy(), res["responses"].cpu().numpy(), res["descriptors"].cpu().numpy()
     gi, wi = _match(res["ids"].cpu().numpy(), ex.keys.numpy())
     dl = np.abs(L[gi] - Lw.numpy()[wi]).reshape(len(gi), -1).max(axis=1)
@@ -125,27 +134,32 @@ def _check_onepass(amd, nets, weights, x, n, name, do_ori=True, th=None):
     return det, res, ex
 
 
-def test_onepass_sir_vs_oracle_and_golden(amd, nets, weights, golden_dir):
+@pytest.mark.parametrize("arith", ARITH)
+def test_onepass_sir_vs_oracle_and_golden(amd, nets, weights, golden_dir, arith):
     g = np.load(os.path.join(golden_dir, "onepass_synth.npz"))
     x = orc.synthetic_image(240, 320, 1)
-    det, res, ex = _check_onepass(amd, nets, weights, x, 300, "OnePassSIR 320x240, 300 kp")
-    # the affine maps the detector used are the stand-alone dense maps
+    det, res, ex = _check_onepass(amd, nets, weights, x, 300, "OnePassSIR 320x240, 300 kp", arith=arith)
+    # the affine maps the detector used are the stand-alone dense maps (same arithmetic mode)
     FC = nets[0]
     assert len(det.aff_maps) == len(ex.aff_maps) == len(det.scale_pyr)
-    for o in range(len(det.aff_maps)):
-        assert torch.equal(det.aff_maps[o], FC(det.scale_pyr[o][0]))
-        assert float((det.aff_maps[o].cpu() - ex.aff_maps[o]).abs().max()) < 5e-5
+    FC.arith = arith
+    try:
+        for o in range(len(det.aff_maps)):
+            assert torch.equal(det.aff_maps[o], FC(det.scale_pyr[o][0]))
+            assert float((det.aff_maps[o].cpu() - ex.aff_maps[o]).abs().max()) < 5e-5
+    finally:
+        FC.arith = "fp32"
     # golden (the reference's own OnePassSIR output, rows in response order): match through the response bit pattern
     L, r = res["LAFs"].cpu().numpy(), res["responses"].cpu().numpy()
     # (+ the frame centre: the golden holds two rows with the same response, 50.77 px apart)
     gi, wi = match_rows(r, L, g["resp_n300"], g["LAFs_n300"])
     dl = np.abs(L[gi] - g["LAFs_n300"][wi]).reshape(len(gi), -1).max(axis=1)
-    record_parity("OnePassSIR 320x240, 300 kp vs the reference's golden output", matched=int(len(gi)), laf_max_px=float(dl.max()),
+    record_parity("OnePassSIR 320x240, 300 kp vs the reference's golden output" + ("" if arith == "fp32" else " [arith %s]" % arith), matched=int(len(gi)), laf_max_px=float(dl.max()),
                   golden_rows_with_tied_responses=tie_groups(g["resp_n300"]), laf_rows_within_1e_3=float((dl < 1e-3).mean()))
     assert len(gi) >= 0.995 * 300 and (dl < 1e-3).all(), "rows %s" % np.nonzero(dl >= 1e-3)[0].tolist()
     # fewer detections than the budget: every candidate that survives the boundary test, (octave, level, pixel) order
     FCn, O, H = nets
-    det2 = amd.OnePassSIR(mrSize=5.192, num_features=5000, border=15, num_Baum_iters=1, AffNet=FCn, OriNet=O).to(DEV)
+    det2 = amd.OnePassSIR(mrSize=5.192, num_features=5000, border=15, num_Baum_iters=1, AffNet=FCn, OriNet=O, arith=arith).to(DEV)
     L2, r2 = det2(x.to(DEV), do_ori=False)
     assert abs(L2.shape[0] - g["LAFs_all_noori"].shape[0]) <= 2
     if L2.shape[0] == g["LAFs_all_noori"].shape[0]:
@@ -174,9 +188,10 @@ def test_onepass_sir_threshold_mode(amd, nets, weights, th):
     assert np.all(np.diff(_keys(res["ids"].cpu().numpy())) > 0), "threshold mode emits (octave, level, pixel) order"
 
 
-def test_onepass_sir_metric_size(amd, nets, weights):
+@pytest.mark.parametrize("arith", ARITH)
+def test_onepass_sir_metric_size(amd, nets, weights, arith):
     """1024 x 768, 2000 kp: the per-level top-k really cuts here (octave 0 levels hold more than 2000 positive maxima)."""
-    _check_onepass(amd, nets, weights, orc.synthetic_image(768, 1024, 1), 2000, "OnePassSIR 1024x768, 2000 kp")
+    _check_onepass(amd, nets, weights, orc.synthetic_image(768, 1024, 1), 2000, "OnePassSIR 1024x768, 2000 kp", arith=arith)
 
 
 def test_onepass_foreign_dense_affnet_slot_and_batch(amd, nets, weights):

@@ -81,6 +81,58 @@ def test_context_layout_no_gpu_needed():
     _lib.lib.affnet_ctx_destroy(h2)
 
 
+def test_arith_mode_is_part_of_the_boundary():
+    """include/affnet_hip.h: AFFNET_ARITH_FP32_MFMA (default) / AFFNET_ARITH_FP32_SPLIT3 through affnet_config.arith and affnet_set_arith,
+    mirrored by the `arith` kwarg of the extractors and the nets' `.arith` attribute; unknown modes are errors, not silent defaults."""
+    import affnet_amd
+    from affnet_amd import _lib
+    from affnet_amd.host_plan import PyramidPlan
+    hdr = open(os.path.join(ROOT, "include", "affnet_hip.h")).read()
+    assert re.search(r"#define AFFNET_ARITH_FP32_MFMA 0\b", hdr) and re.search(r"#define AFFNET_ARITH_FP32_SPLIT3 1\b", hdr)
+    assert (_lib.ARITH_FP32_MFMA, _lib.ARITH_FP32_SPLIT3) == (0, 1)
+    for cfg_arith in (0, 1):
+        cfg = PyramidPlan(240, 320).fill_config(5.192, 0.0, 300, 450, arith=cfg_arith)
+        h = C.c_void_p()
+        assert _lib.lib.affnet_ctx_create(C.byref(h), 0, C.byref(cfg)) == 0
+        assert _lib.lib.affnet_get_arith(h) == cfg_arith
+        assert _lib.lib.affnet_set_arith(h, 1 - cfg_arith) == 0 and _lib.lib.affnet_get_arith(h) == 1 - cfg_arith
+        assert _lib.lib.affnet_set_arith(h, 7) == _lib.ERR_INVALID and b"arith" in _lib.lib.affnet_last_error(h)
+        assert _lib.lib.affnet_get_arith(h) == 1 - cfg_arith
+        _lib.lib.affnet_ctx_destroy(h)
+    bad = PyramidPlan(240, 320).fill_config(5.192, 0.0, 300, 450)
+    bad.arith = 3
+    h = C.c_void_p()
+    assert _lib.lib.affnet_ctx_create(C.byref(h), 0, C.byref(bad)) == _lib.ERR_INVALID
+    _lib.lib.affnet_ctx_destroy(h)
+    u = C.c_void_p()                                                      # utility context (cfg == NULL): default exact fp32
+    assert _lib.lib.affnet_ctx_create(C.byref(u), 0, None) == 0 and _lib.lib.affnet_get_arith(u) == 0
+    _lib.lib.affnet_ctx_destroy(u)
+    assert _lib.arith_code("fp32") == 0 and _lib.arith_code("fp32_split3") == 1 and _lib.arith_code(None) == 0
+    with pytest.raises(ValueError):
+        _lib.arith_code("bf16")
+    with pytest.raises(ValueError):
+        affnet_amd.ScaleSpaceAffinePatchExtractor(arith="tf32")
+    assert affnet_amd.ScaleSpaceAffinePatchExtractor().arith == "fp32" and affnet_amd.AffNetFast().arith == "fp32"
+
+
+def test_no_product_kernel_spills_registers():
+    """Read from the built objects (tools/kernel_resources.py -> the code objects' metadata notes): no kernel of the library may spill
+    VGPRs or use scratch memory.  Round 3 shipped hessian_nms_kernel<5> with 5 spilled registers and 24 B of scratch per thread because
+    its launch bound asked for an occupancy its register count missed by five; loop-invariant addresses held across the tile loop were
+    the cause."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources as kr
+    ks = kr.all_kernels()
+    assert len(ks) > 100, "metadata of the built objects not found (run __graft_entry__.build())"
+    bad = {k["name"]: (k.get("vgpr_spill_count", 0), k.get("sgpr_spill_count", 0), k.get("private_segment_fixed_size", 0)) for k in ks.values()
+           if k.get("vgpr_spill_count", 0) or k.get("private_segment_fixed_size", 0)}
+    assert not bad, bad
+    h5 = [k for k in ks.values() if "hessian_nms_kernelILi5E" in k["name"]][0]
+    assert h5["group_segment_fixed_size"] == 52520 and kr.workgroups_per_cu(h5) == 3, h5      # three workgroups per CU by LDS AND by registers
+    trunk = [k for k in ks.values() if "cnn32_trunk_kernelILi2ELi8ELb0ELb0E" in k["name"]][0]
+    assert trunk["group_segment_fixed_size"] <= 160 * 1024 and kr.workgroups_per_cu(trunk) == 1
+
+
 def _unpack_trunk(kind, blob):
     """Rebuilds conv weights / biases from the packed blob (the layout cnn32.hip documents)."""
     cb = 32 if kind == 2 else 16
@@ -230,7 +282,7 @@ def test_bench_finds_the_counter_traffic_of_its_dominant_kernel():
 
 @pytest.mark.parametrize("kind,name", [(0, "AffNet"), (1, "OriNet"), (2, "HardNet")])
 def test_split_weight_copies_are_exact(kind, name, weights):
-    """EXPLORATORY split-operand path (affnet_debug_split3): the packed blob carries conv1 .. conv5 once more as three bf16 terms in the
+    """AFFNET_ARITH_FP32_SPLIT3 (include/affnet_hip.h): the packed blob carries conv1 .. conv5 once more as three bf16 terms in the
     bf16 MFMA's fragment order.  The three terms of a weight must add up to the BN-folded fp32 weight of the exact path EXACTLY (24-bit
     significand = 3 x 8 bits, exact remainders) - the split path's only error is then the 2^-25 of the six-product truncation - and sit
     where the kernels read them: [tap][cin/32][term][kq][cout][8] (cin >= 32), [step][term][kq = 2 (tap & 1) + c / 8][cout][8] (cin = 16)."""

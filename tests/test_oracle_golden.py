@@ -78,6 +78,26 @@ def test_cnn_vectors(golden_dir, weights):
         _close(orc.hardnet_forward(weights["HardNet"], p).numpy(), g["hardnet"], 1e-5, "HardNet")
 
 
+def test_cnn_restatement_vs_the_reference_jit_traces(golden_dir, weights):
+    """Second CNN oracle: the reference ships TorchScript traces of AffNet / OriNet made by its author from the same
+    checkpoints (convertJIT/AffNetJIT.pt, OriNetJIT.pt); tests/golden/cnn_jit_raw.npz holds their UNMODIFIED outputs on the random patches
+    (tests/golden/make_golden_jit.py): the raw (1 + x0, x1, 1 + x2) of AffNet and the raw (y, x) OriNet feeds to atan2 - the quantity the
+    parity outliers hinge on.  The restatement shares no code with the traces and must agree to float noise (measured 2.4e-7 / 1.3e-7)."""
+    g, j = np.load(os.path.join(golden_dir, "cnn_random_patches.npz")), np.load(os.path.join(golden_dir, "cnn_jit_raw.npz"))
+    p = torch.from_numpy(g["patches"])
+    with torch.no_grad():
+        a, o = orc.affnet_raw(weights["AffNet"], p), orc.orinet_vector(weights["OriNet"], p)
+    _close(a.numpy(), j["affnet_raw"], 2e-6, "AffNet raw vs AffNetJIT.pt")
+    _close(o.numpy(), j["orinet_raw"], 2e-6, "OriNet raw vs OriNetJIT.pt")
+    # and the traces' outputs through the rest of the reference's formulas give the golden matrices of the eager reference modules
+    A = torch.zeros(p.size(0), 2, 2)
+    jr = torch.from_numpy(j["affnet_raw"])
+    A[:, 0, 0], A[:, 1, 0], A[:, 1, 1] = jr[:, 0], jr[:, 1], jr[:, 2]
+    _close(orc.rectify_up_is_up(A).numpy(), g["affnet"], 1e-5, "rectify(AffNetJIT) vs AffNetFast golden")
+    jo = torch.from_numpy(j["orinet_raw"])
+    _close(orc.rotation_matrix(torch.atan2(jo[:, 0] + 1e-8, jo[:, 1] + 1e-8)).numpy(), g["orinet"], 1e-5, "rotation(OriNetJIT) vs OriNetFast golden")
+
+
 def test_sampler_vectors(golden_dir):
     g = np.load(os.path.join(golden_dir, "sampler_synth.npz"))
     x = orc.synthetic_image(240, 320, 1)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Phase breakdown (s_memtime stamps) of the EXPLORATORY split-operand HardNet trunk next to the exact fp32 one (tuning aid)."""
+"""Phase breakdown (s_memtime stamps) of the split-operand (arith fp32_split3) HardNet trunk next to the exact fp32 one (tuning aid)."""
 import os, sys
 import numpy as np
 import torch
@@ -17,7 +17,7 @@ names = ["input+norm", "conv0", "conv1 mfma", "conv1 store", "conv2 mfma", "conv
          "conv4 mfma", "conv4 store", "conv5 mfma"]
 ctx = engine.utility_ctx(dev)
 for split in (0, 1):
-    lib.affnet_debug_split3(ctx, split)
+    lib.affnet_set_arith(ctx, split)
     H(p); torch.cuda.synchronize()
     st = torch.zeros(n * nw * 32, dtype=torch.int64, device=dev)
     lib.affnet_cnn32_debug_timing(ctx, ptr(st))
@@ -29,9 +29,20 @@ for split in (0, 1):
     for i in range(11):
         print("  %-12s mean %8.0f  max-over-waves %8.0f" % (names[i], d[:, :, i].mean(), d[:, :, i].max(axis=1).mean()))
     print("  total per patch %.0f ticks" % (t[:, :, 11].max(axis=1) - t[:, :, 0].min(axis=1)).mean())
+    if split:
+        # per wave: which SIMD it ran on (HW_ID bits 5:4 on gfx9) and how long each MFMA loop took - is the loss imbalance between the two
+        # waves of a SIMD, between SIMDs, or common to all?
+        hw = st.cpu().numpy().reshape(n, nw, 32)[:, :, 14]
+        simd = (hw >> 4) & 3
+        print("  wave -> SIMD (patch 0): %s ; same mapping in %.0f %% of the patches" % (simd[0].tolist(), 100.0 * (simd == simd[0]).all(axis=1).mean()))
+        for i in (2, 4, 6, 8, 10):
+            print("  %-12s per wave: %s" % (names[i], " ".join("%6.0f" % d[:, w, i].mean() for w in range(nw))))
+        # finish-time spread inside a SIMD pair and across SIMDs (conv3 loop)
+        fin = t[:, :, 7] - t[:, :, 6].min(axis=1, keepdims=True)
+        print("  conv3 loop finish (ticks after the slowest start): per wave %s" % " ".join("%6.0f" % fin[:, w].mean() for w in range(nw)))
     big = (torch.rand(48000, 1, 32, 32) * 255).to(dev)
     H(big); torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); H(big); e1.record(); torch.cuda.synchronize()
     print("  48000 patches: %.3f ms" % e0.elapsed_time(e1))
-lib.affnet_debug_split3(ctx, 0)
+lib.affnet_set_arith(ctx, 0)
