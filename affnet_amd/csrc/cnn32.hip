@@ -339,10 +339,10 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         const int y = e < 34 ? 0 : (e < 68 ? 33 : 1 + ((e - 68) >> 1)), x = e < 34 ? e : (e < 68 ? e - 34 : ((e - 68) & 1) * 33);
         patch[y * WP32 + x] = 0.0f;
     }
-    constexpr bool HALF = S3;                                     // EXPLORATORY split path: conv0 .. conv2 in two half-patch passes
-    typedef LayB<16, 32, 34, CB> LBH;                            // conv0 output of half a patch, pre-split (HALF only); read by conv1 (stride 1)
-    typedef LayB<16, 32, 34, CB, 16> LBH2;                       // conv1 output of half a patch; read by conv2 at stride 2
-    if constexpr (HALF) zero_halo_b<LBH, NTHR>(act);
+    constexpr bool HALF = S3;                                     // split-operand arithmetic: conv0 .. conv2 in two half-patch passes
+    typedef LayQ<16, 32, 34, CB> LQH;                            // conv0 output of half a patch, pre-split (HALF only); read by conv1 (stride 1)
+    typedef LayQ<16, 32, 34, CB, 16> LQH2;                       // conv1 output of half a patch; read by conv2 at stride 2
+    if constexpr (HALF) zero_halo_q<LQH, NTHR>(act);
     else zero_halo<LayC0, NTHR>(act, CB);
     float sum = 0.f;
 #pragma unroll
@@ -374,177 +374,203 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
     if (STAMPS && a.dbg_layer == 0) { dump_planes<CB, LayC0, NTHR>(act, a.dbg_out); return; }
     if (!HALF) CNN_STAMP(2);
 
-    // the two waves of a SIMD take turns at the higher priority inside the split MFMA loops: without it one of them runs ahead (conv3: 26.5 k
-    // cycles for the faster, 32.3 k for the slower wave) and the slower one finishes alone; with it 166 k -> 159 k cycles per patch, 15.24 ->
-    // 15.03 ms per 48000 patches (power-limited: the clock gives part of it back).  AffNet / OriNet (two workgroups per CU) do not gain.
+    // AFFNET_ARITH_FP32_SPLIT3 (affnet_set_arith): conv1 .. conv5 on split operands - every fp32 operand as three bf16 terms, six
+    // v_mfma_f32_16x16x32_bf16 per product, fp32 accumulate.  conv0 .. conv4 write their outputs PRE-SPLIT into term-interleaved cells (LayQ),
+    // conv1 .. conv5 read ready fragments (conv3x3_mfma_s3q): no VALU work inside the MFMA loops ("Split-operand trunks").
+    // The first weight fragments of a loop are requested before the barriers / epilogue in front of it.
+    // HardNet (one workgroup per CU): optionally (affnet_debug_split3_variant bit 0) the two waves of a SIMD take turns at the higher priority
+    // inside the loops.  Round 3's tile-major loops gained 2.5 % from it; with the term-major loops it costs 1 % (default off).
     const bool s3_alt = a.s3_alt != 0 && KIND == AFFNET_NET_HARDNET;
     if constexpr (S3 && KIND == AFFNET_NET_HARDNET) {
-        // EXPLORATORY (affnet_debug_split3): conv1 .. conv5 on split operands - fp32 = three bf16 terms, six v_mfma_f32_16x16x32_bf16 per
-        // 32-channel block.  conv0 .. conv4 write their outputs PRE-SPLIT (three bf16 planes, LayB), conv1 .. conv5 read ready fragments
-        // (conv3x3_mfma_s3p): no VALU work inside the MFMA loops ("Split-operand trunks").
-        typedef LayB<16, 16, 18, 2 * CB> LB2;                            // conv2 / conv3 outputs: 64 channels @16x16 (126 KB)
-        typedef LayB<8, 8, 16, 4 * CB, 128> LB4;                         // conv4 output: 128 channels @8x8, row stride 256 B (126 KB)
-        static_assert(LB2::BYTES <= TrunkLds<CB>::ACT * 4 && LB4::BYTES <= TrunkLds<CB>::ACT * 4, "pre-split layouts must fit the activation buffer");
-        if constexpr (CB == 32) {
-            // conv0 + conv1 in two half-patch passes: the pre-split conv0 output of 32 channels @32x32 would be 222 KB, half of it (16 rows +
-            // a halo row either side) is 117 KB.  conv1 splits nothing in its loop (the on-the-fly version split every pixel once per tap: 9x).
-            static_assert(LBH::BYTES <= TrunkLds<CB>::ACT * 4 && LBH2::BYTES <= TrunkLds<CB>::ACT * 4, "the half-patch layouts must fit the activation buffer");
-            f32x4 acc_a[4][2], acc_b[4][2];
-            prefetch_bias<NW, 32, 8, 2>(a.packed + a.off.b[1], bias1, wave, lane);
-            conv0_half_split<NW, LBH, 2>(patch, w0, bias0, act, 0, wave, lane);
-            __syncthreads();
-            CNN_STAMP(2);
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3p<NW, CB, CB, LBH, 1, 4, 2>(act, a.packed + a.off.w_s3[1], acc_a, wave, lane, s3_alt);
-            if (PRIO) __builtin_amdgcn_s_setprio(3);
-            __syncthreads();
-            if (tid < 12 * 32) {                                         // pass 0 left conv0 row 16 in the bottom halo row: zero again
-                char* base = reinterpret_cast<char*>(act);
-                *reinterpret_cast<f32x4*>(base + (tid >> 5) * LBH::GS + (17 * LBH::WP + (tid & 31) + 1) * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-            conv0_half_split<NW, LBH, 2>(patch, w0, bias0, act, 1, wave, lane);
-            __syncthreads();
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3p<NW, CB, CB, LBH, 1, 4, 2>(act, a.packed + a.off.w_s3[1], acc_b, wave, lane, s3_alt);
-            if (PRIO) __builtin_amdgcn_s_setprio(3);
-            CNN_STAMP(3);
-            __syncthreads();
-            // conv1's output goes back into the same half layout, pre-split, and conv2 (stride 2: output rows 0 .. 7 read input rows
-            // -1 .. 15, rows 8 .. 15 read 15 .. 31) runs in two passes as well
-            char* base = reinterpret_cast<char*>(act);
-            zero_halo_b<LBH2, NTHR>(act);                                // another group stride than LBH (bank conflicts of the stride-2 reader)
-            store_tiles_split<CB, LBH2, 4, 2>(act, bias1, acc_a, wave, lane);
-            f32x4 acc2_a[2][2], acc2_b[2][2], bias2[2];
-#pragma unroll
-            for (int j = 0; j < 2; ++j) bias2[j] = *reinterpret_cast<const f32x4*>(&a.packed[a.off.b[2] + ((wave >> 2) * 2 + j) * 16 + 4 * (lane >> 4)]);
-            __syncthreads();
-            CNN_STAMP(4);
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3p<NW, CB, 2 * CB, LBH2, 2, 2, 2>(act, a.packed + a.off.w_s3[2], acc2_a, wave, lane, s3_alt);
-            if (PRIO) __builtin_amdgcn_s_setprio(3);
-            __syncthreads();
-            store_tiles_split<CB, LBH2, 4, 2>(act, bias1, acc_b, wave, lane);
-            if (wave == 7) {                                             // conv1 row 15 (tiles 2, 3 of wave 7 in pass 0) = the top halo row of pass 1
-                const int n = lane & 15;
-#pragma unroll
-                for (int i = 2; i < 4; ++i) split_store_tile<LBH2, 2>(base, ((i - 2) * 16 + n + 1) * 16, 0, bias1, acc_a[i], lane >> 4);
-            }
-            __syncthreads();
-            if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3p<NW, CB, 2 * CB, LBH2, 2, 2, 2>(act, a.packed + a.off.w_s3[2], acc2_b, wave, lane, s3_alt);
-            if (PRIO) __builtin_amdgcn_s_setprio(3);
-            CNN_STAMP(5);
-            __syncthreads();
-            zero_halo_b<LB2, NTHR>(act);
-            store_tiles_split<2 * CB, LB2, 2, 2, 8>(act, bias2, acc2_a, wave, lane, 0);
-            store_tiles_split<2 * CB, LB2, 2, 2, 8>(act, bias2, acc2_b, wave, lane, 8);
-            __syncthreads();
-            CNN_STAMP(6);
+        typedef LayQ<16, 16, 18, 2 * CB> LQ2;                            // conv2 / conv3 outputs: 64 channels @16x16 (122 KB)
+        typedef LayQ<8, 8, 16, 4 * CB, 128> LQ4;                         // conv4 output: 128 channels @8x8, row pitch 768 B (122 KB)
+        static_assert(LQ2::BYTES <= TrunkLds<CB>::ACT * 4 && LQ4::BYTES <= TrunkLds<CB>::ACT * 4 && LQH::BYTES <= TrunkLds<CB>::ACT * 4 &&
+                      LQH2::BYTES <= TrunkLds<CB>::ACT * 4, "pre-split layouts must fit the activation buffer");
+        char* base = reinterpret_cast<char*>(act);
+        // conv0 + conv1 in two half-patch passes: the pre-split conv0 output of 32 channels @32x32 would be 222 KB, half of it (16 rows +
+        // a halo row either side) is 115 KB
+        f32x4 acc_a[4][2], acc_b[4][2];
+        S3W<2> wf1, wf2;
+        s3_prefetch_w0<NW, CB, CB, 32, 4, 2>(a.packed + a.off.w_s3[1], wf1, wave, lane);
+        prefetch_bias<NW, 32, 8, 2>(a.packed + a.off.b[1], bias1, wave, lane);
+        conv0_half_split_q<NW, LQH, 2>(patch, w0, bias0, act, 0, wave, lane);
+        __syncthreads();
+        CNN_STAMP(2);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        conv3x3_mfma_s3q<NW, CB, CB, LQH, 1, 4, 2>(act, a.packed + a.off.w_s3[1], wf1, acc_a, wave, lane, s3_alt);
+        if (PRIO) __builtin_amdgcn_s_setprio(3);
+        __syncthreads();
+        if (tid < 12 * 32) {                                         // pass 0 left conv0 row 16 in the bottom halo row: zero again (3 terms x 4 groups x 32 cells)
+            const int t = tid / 128, g = (tid >> 5) & 3, x = tid & 31;
+            *reinterpret_cast<f32x4*>(base + g * LQH::GS + (17 * LQH::WP + x + 1) * LQH::CELL + t * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+        conv0_half_split_q<NW, LQH, 2>(patch, w0, bias0, act, 1, wave, lane);
+        __syncthreads();
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        conv3x3_mfma_s3q<NW, CB, CB, LQH, 1, 4, 2>(act, a.packed + a.off.w_s3[1], wf1, acc_b, wave, lane, s3_alt);
+        if (PRIO) __builtin_amdgcn_s_setprio(3);
+        CNN_STAMP(3);
+        s3_prefetch_w0<NW, CB, 2 * CB, 8, 2, 2>(a.packed + a.off.w_s3[2], wf2, wave, lane);
+        f32x4 acc2_a[2][2], acc2_b[2][2], bias2[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bias2[j] = *reinterpret_cast<const f32x4*>(&a.packed[a.off.b[2] + ((wave >> 2) * 2 + j) * 16 + 4 * (lane >> 4)]);
+        __syncthreads();
+        // conv1's output goes back into the same half layout, pre-split, and conv2 (stride 2: output rows 0 .. 7 read input rows
+        // -1 .. 15, rows 8 .. 15 read 15 .. 31) runs in two passes as well
+        zero_halo_q<LQH2, NTHR>(act);                                // another group stride than LQH (bank conflicts of the stride-2 reader)
+        store_tiles_split_q<CB, LQH2, 4, 2>(act, bias1, acc_a, wave, lane);
+        __syncthreads();
+        CNN_STAMP(4);
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 2, 2>(act, a.packed + a.off.w_s3[2], wf2, acc2_a, wave, lane, s3_alt);
+        if (PRIO) __builtin_amdgcn_s_setprio(3);
+        __syncthreads();
+        store_tiles_split_q<CB, LQH2, 4, 2>(act, bias1, acc_b, wave, lane);
+        if (wave == 7) {                                             // conv1 row 15 (tiles 2, 3 of wave 7 in pass 0) = the top halo row of pass 1
+            const int n = lane & 15;
+#pragma unroll
+            for (int i = 2; i < 4; ++i) split_store_tile_q<LQH2, 2>(base, ((i - 2) * 16 + n + 1) * LQH2::CELL, 0, bias1, acc_a[i], lane >> 4);
+        }
+        __syncthreads();
+        if (PRIO) __builtin_amdgcn_s_setprio(0);
+        conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 2, 2>(act, a.packed + a.off.w_s3[2], wf2, acc2_b, wave, lane, s3_alt);
+        if (PRIO) __builtin_amdgcn_s_setprio(3);
+        CNN_STAMP(5);
+        S3W<2> wf3, wf4, wf5;
+        f32x4 bias3[2], bias4[2], bias5s[2];
+        s3_prefetch_w0<NW, 2 * CB, 2 * CB, 16, 4, 2>(a.packed + a.off.w_s3[3], wf3, wave, lane);
+        prefetch_bias<NW, 16, 4, 2>(a.packed + a.off.b[3], bias3, wave, lane);
+        __syncthreads();
+        zero_halo_q<LQ2, NTHR>(act);
+        store_tiles_split_q<2 * CB, LQ2, 2, 2, 8>(act, bias2, acc2_a, wave, lane, 0);
+        store_tiles_split_q<2 * CB, LQ2, 2, 2, 8>(act, bias2, acc2_b, wave, lane, 8);
+        __syncthreads();
+        CNN_STAMP(6);
         {
-            f32x4 acc_[4][2], bias_[2];                                  // conv3: 64 -> 64 @16x16
-            prefetch_bias<NW, 16, 4, 2>(a.packed + a.off.b[3], bias_, wave, lane);
+            f32x4 acc_[4][2];                                            // conv3: 64 -> 64 @16x16
             if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3p<NW, 2 * CB, 2 * CB, LB2, 1, 4, 2>(act, a.packed + a.off.w_s3[3], acc_, wave, lane, s3_alt);
+            conv3x3_mfma_s3q<NW, 2 * CB, 2 * CB, LQ2, 1, 4, 2>(act, a.packed + a.off.w_s3[3], wf3, acc_, wave, lane, s3_alt);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
             CNN_STAMP(7);
+            s3_prefetch_w0<NW, 2 * CB, 4 * CB, 4, 2, 2>(a.packed + a.off.w_s3[4], wf4, wave, lane);
+            prefetch_bias<NW, 8, 2, 2>(a.packed + a.off.b[4], bias4, wave, lane);
             __syncthreads();
-            store_tiles_split<2 * CB, LB2, 4, 2>(act, bias_, acc_, wave, lane);      // same layout in place: the halo is still zero
+            store_tiles_split_q<2 * CB, LQ2, 4, 2>(act, bias3, acc_, wave, lane);      // same layout in place: the halo is still zero
             __syncthreads();
             CNN_STAMP(8);
         }
         {
-            f32x4 acc_[2][2], bias_[2];                                  // conv4: 64 -> 128, stride 2 -> 8x8
-            prefetch_bias<NW, 8, 2, 2>(a.packed + a.off.b[4], bias_, wave, lane);
+            f32x4 acc_[2][2];                                            // conv4: 64 -> 128, stride 2 -> 8x8
             if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3p<NW, 2 * CB, 4 * CB, LB2, 2, 2, 2>(act, a.packed + a.off.w_s3[4], acc_, wave, lane, s3_alt);
+            conv3x3_mfma_s3q<NW, 2 * CB, 4 * CB, LQ2, 2, 2, 2>(act, a.packed + a.off.w_s3[4], wf4, acc_, wave, lane, s3_alt);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
             CNN_STAMP(9);
+            s3_prefetch_w0<NW, 4 * CB, 4 * CB, 4, 2, 2>(a.packed + a.off.w_s3[5], wf5, wave, lane);
+            prefetch_bias<NW, 8, 2, 2>(a.packed + a.off.b[5], bias5s, wave, lane);
             __syncthreads();
-            zero_halo_b<LB4, NTHR>(act);
-            store_tiles_split<4 * CB, LB4, 2, 2>(act, bias_, acc_, wave, lane);
+            zero_halo_q<LQ4, NTHR>(act);
+            store_tiles_split_q<4 * CB, LQ4, 2, 2>(act, bias4, acc_, wave, lane);
             __syncthreads();
             CNN_STAMP(10);
         }
         {
-            constexpr int T5M = 2, T5N = 2;                              // conv5: 128 -> 128 @8x8, conv5 tensor -> HBM for the head GEMM
-            f32x4 acc5[T5M][T5N], bias5s[T5N];
-            prefetch_bias<NW, 8, T5M, T5N>(a.packed + a.off.b[5], bias5s, wave, lane);
+            f32x4 acc5[2][2];                                            // conv5: 128 -> 128 @8x8, conv5 tensor -> HBM for the head GEMM
             if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3p<NW, 4 * CB, 4 * CB, LB4, 1, T5M, T5N>(act, a.packed + a.off.w_s3[5], acc5, wave, lane, s3_alt);
+            conv3x3_mfma_s3q<NW, 4 * CB, 4 * CB, LQ4, 1, 2, 2>(act, a.packed + a.off.w_s3[5], wf5, acc5, wave, lane, s3_alt);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
             CNN_STAMP(11);
-            store_tiles_global<4 * CB, T5M, T5N>(a.out + pidx * (64 * 4 * CB), bias5s, acc5, wave, lane);
+            store_tiles_global<4 * CB, 2, 2>(a.out + pidx * (64 * 4 * CB), bias5s, acc5, wave, lane);
         }
         return;
     }
 
     if constexpr (S3 && CB == 16) {
-        // EXPLORATORY (affnet_debug_split3): AffNet / OriNet on split operands, same structure as the HardNet branch: conv0 .. conv2 in two
-        // half-patch passes on pre-split layouts (conv1 / conv2 have 16 input channels: two taps per k = 32 step), conv3 .. conv5 whole.
-        typedef LayB<16, 16, 18, 2 * CB> LB2;                            // conv2 / conv3 outputs: 32 channels @16x16 (63 KB)
-        typedef LayB<8, 8, 16, 4 * CB, 128> LB4;                         // conv4 output: 64 channels @8x8, row stride 256 B (63 KB)
-        static_assert(LBH::BYTES <= TrunkLds<CB>::ACT * 4 && LBH2::BYTES <= TrunkLds<CB>::ACT * 4 && LB2::BYTES <= TrunkLds<CB>::ACT * 4 && LB4::BYTES <= TrunkLds<CB>::ACT * 4,
+        // AffNet / OriNet on split operands, same structure as the HardNet branch: conv0 .. conv2 in two half-patch passes on pre-split
+        // layouts (conv1 / conv2 have 16 input channels: two taps per k = 32 step), conv3 .. conv5 whole.
+        typedef LayQ<16, 16, 18, 2 * CB> LQ2;                            // conv2 / conv3 outputs: 32 channels @16x16 (61 KB)
+        typedef LayQ<8, 8, 16, 4 * CB, 128> LQ4;                         // conv4 output: 64 channels @8x8, row pitch 768 B (61 KB)
+        static_assert(LQH::BYTES <= TrunkLds<CB>::ACT * 4 && LQH2::BYTES <= TrunkLds<CB>::ACT * 4 && LQ2::BYTES <= TrunkLds<CB>::ACT * 4 && LQ4::BYTES <= TrunkLds<CB>::ACT * 4,
                       "pre-split layouts must fit the activation buffer");
+        char* base = reinterpret_cast<char*>(act);
+        f32x4 acc_a[4][1], acc_b[4][1];
+        // (128 VGPRs at two workgroups per CU: a loop's first weight fragments are requested right in front of it here - held across the
+        // previous epilogue like in the HardNet branch they cost 17 / 23 spilled registers)
+        S3W<1> wf1, wf2;
+        prefetch_bias_fresh<NW, 32, 8, 1>(a.packed + a.off.b[1], bias1, wave, lane);
+        conv0_half_split_q<NW, LQH, 1>(patch, w0, bias0, act, 0, wave, lane);
+        s3_prefetch_w0<NW, CB, CB, 32, 4, 1>(a.packed + a.off.w_s3[1], wf1, wave, lane);
+        __syncthreads();
+        conv3x3_mfma_s3q<NW, CB, CB, LQH, 1, 4, 1>(act, a.packed + a.off.w_s3[1], wf1, acc_a, wave, lane, false);
+        __syncthreads();
+        if (tid < 6 * 32) {                                              // pass 0 left conv0 row 16 in the bottom halo row: zero again (3 terms x 2 groups x 32 cells)
+            const int t = tid >> 6, g = (tid >> 5) & 1, x = tid & 31;
+            *reinterpret_cast<f32x4*>(base + g * LQH::GS + (17 * LQH::WP + x + 1) * LQH::CELL + t * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        conv0_half_split_q<NW, LQH, 1>(patch, w0, bias0, act, 1, wave, lane);
+        s3_prefetch_w0<NW, CB, CB, 32, 4, 1>(a.packed + a.off.w_s3[1], wf1, wave, lane);
+        __syncthreads();
+        conv3x3_mfma_s3q<NW, CB, CB, LQH, 1, 4, 1>(act, a.packed + a.off.w_s3[1], wf1, acc_b, wave, lane, false);
+        f32x4 acc2_a[2][1], acc2_b[2][1], bias2[1];
         {
-            char* base = reinterpret_cast<char*>(act);
-            f32x4 acc_a[4][1], acc_b[4][1];
-            prefetch_bias<NW, 32, 8, 1>(a.packed + a.off.b[1], bias1, wave, lane);
-            conv0_half_split<NW, LBH, 1>(patch, w0, bias0, act, 0, wave, lane);
-            __syncthreads();
-            conv3x3_mfma_s3p_c16<NW, CB, LBH, 1, 4, 1>(act, a.packed + a.off.w_s3[1], acc_a, wave, lane, s3_alt);
-            __syncthreads();
-            if (tid < 6 * 32)                                            // pass 0 left conv0 row 16 in the bottom halo row: zero again
-                *reinterpret_cast<f32x4*>(base + (tid >> 5) * LBH::GS + (17 * LBH::WP + (tid & 31) + 1) * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
-            conv0_half_split<NW, LBH, 1>(patch, w0, bias0, act, 1, wave, lane);
-            __syncthreads();
-            conv3x3_mfma_s3p_c16<NW, CB, LBH, 1, 4, 1>(act, a.packed + a.off.w_s3[1], acc_b, wave, lane, s3_alt);
-            __syncthreads();
-            zero_halo_b<LBH2, NTHR>(act);                                // another group stride than LBH (bank conflicts of the stride-2 reader)
-            store_tiles_split<CB, LBH2, 4, 1>(act, bias1, acc_a, wave, lane);
-            f32x4 acc2_a[2][1], acc2_b[2][1], bias2[1];
-            bias2[0] = *reinterpret_cast<const f32x4*>(&a.packed[a.off.b[2] + (wave >> 2) * 16 + 4 * (lane >> 4)]);
-            __syncthreads();
-            conv3x3_mfma_s3p_c16<NW, 2 * CB, LBH2, 2, 2, 1>(act, a.packed + a.off.w_s3[2], acc2_a, wave, lane, s3_alt);
-            __syncthreads();
-            store_tiles_split<CB, LBH2, 4, 1>(act, bias1, acc_b, wave, lane);
-            if (wave == 7) {                                             // conv1 row 15 (tiles 2, 3 of wave 7 in pass 0) = the top halo row of pass 1
-                const int n = lane & 15;
+            int l2 = lane;
+            asm volatile("" : "+v"(l2));
+            bias2[0] = *reinterpret_cast<const f32x4*>(&a.packed[a.off.b[2] + (wave >> 2) * 16 + 4 * (l2 >> 4)]);
+        }
+        __syncthreads();
+        zero_halo_q<LQH2, NTHR>(act);                                    // another group stride than LQH (bank conflicts of the stride-2 reader)
+        store_tiles_split_q<CB, LQH2, 4, 1>(act, bias1, acc_a, wave, lane);
+        s3_prefetch_w0<NW, CB, 2 * CB, 8, 2, 1>(a.packed + a.off.w_s3[2], wf2, wave, lane);
+        __syncthreads();
+        conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 2, 1>(act, a.packed + a.off.w_s3[2], wf2, acc2_a, wave, lane, false);
+        __syncthreads();
+        store_tiles_split_q<CB, LQH2, 4, 1>(act, bias1, acc_b, wave, lane);
+        if (wave == 7) {                                                 // conv1 row 15 (tiles 2, 3 of wave 7 in pass 0) = the top halo row of pass 1
+            const int n = lane & 15;
 #pragma unroll
-                for (int i = 2; i < 4; ++i) split_store_tile<LBH2, 1>(base, ((i - 2) * 16 + n + 1) * 16, 0, bias1, acc_a[i], lane >> 4);
-            }
+            for (int i = 2; i < 4; ++i) split_store_tile_q<LQH2, 1>(base, ((i - 2) * 16 + n + 1) * LQH2::CELL, 0, bias1, acc_a[i], lane >> 4);
+        }
+        s3_prefetch_w0<NW, CB, 2 * CB, 8, 2, 1>(a.packed + a.off.w_s3[2], wf2, wave, lane);
+        __syncthreads();
+        conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 2, 1>(act, a.packed + a.off.w_s3[2], wf2, acc2_b, wave, lane, false);
+        S3W<2> wf3, wf4;
+        f32x4 bias3[2], bias4[2];
+        __syncthreads();
+        zero_halo_q<LQ2, NTHR>(act);
+        store_tiles_split_q<2 * CB, LQ2, 2, 1, 8>(act, bias2, acc2_a, wave, lane, 0);
+        store_tiles_split_q<2 * CB, LQ2, 2, 1, 8>(act, bias2, acc2_b, wave, lane, 8);
+        s3_prefetch_w0<NW, 2 * CB, 2 * CB, 16, 2, 2>(a.packed + a.off.w_s3[3], wf3, wave, lane);
+        prefetch_bias_fresh<NW, 16, 2, 2>(a.packed + a.off.b[3], bias3, wave, lane);
+        __syncthreads();
+        {
+            f32x4 acc_[2][2];                                            // conv3: 32 -> 32 @16x16
+            conv3x3_mfma_s3q<NW, 2 * CB, 2 * CB, LQ2, 1, 2, 2>(act, a.packed + a.off.w_s3[3], wf3, acc_, wave, lane, false);
             __syncthreads();
-            conv3x3_mfma_s3p_c16<NW, 2 * CB, LBH2, 2, 2, 1>(act, a.packed + a.off.w_s3[2], acc2_b, wave, lane, s3_alt);
+            store_tiles_split_q<2 * CB, LQ2, 2, 2>(act, bias3, acc_, wave, lane);      // in place: the halo is still zero
+            s3_prefetch_w0<NW, 2 * CB, 4 * CB, 4, 1, 2>(a.packed + a.off.w_s3[4], wf4, wave, lane);
+            prefetch_bias_fresh<NW, 8, 1, 2>(a.packed + a.off.b[4], bias4, wave, lane);
             __syncthreads();
-            zero_halo_b<LB2, NTHR>(act);
-            store_tiles_split<2 * CB, LB2, 2, 1, 8>(act, bias2, acc2_a, wave, lane, 0);
-            store_tiles_split<2 * CB, LB2, 2, 1, 8>(act, bias2, acc2_b, wave, lane, 8);
+        }
+        S3W<T4N> wf5;
+        f32x4 bias5s[T4N];
+        {
+            f32x4 acc_[1][2];                                            // conv4: 32 -> 64, stride 2 -> 8x8
+            conv3x3_mfma_s3q<NW, 2 * CB, 4 * CB, LQ2, 2, 1, 2>(act, a.packed + a.off.w_s3[4], wf4, acc_, wave, lane, false);
+            __syncthreads();
+            zero_halo_q<LQ4, NTHR>(act);
+            store_tiles_split_q<4 * CB, LQ4, 1, 2>(act, bias4, acc_, wave, lane);
+            s3_prefetch_w0<NW, 4 * CB, 4 * CB, 4, T4M, T4N>(a.packed + a.off.w_s3[5], wf5, wave, lane);
+            prefetch_bias_fresh<NW, 8, T4M, T4N>(a.packed + a.off.b[5], bias5s, wave, lane);
             __syncthreads();
         }
         {
-            f32x4 acc_[2][2], bias_[2];                                  // conv3: 32 -> 32 @16x16
-            prefetch_bias<NW, 16, 2, 2>(a.packed + a.off.b[3], bias_, wave, lane);
-            conv3x3_mfma_s3p<NW, 2 * CB, 2 * CB, LB2, 1, 2, 2>(act, a.packed + a.off.w_s3[3], acc_, wave, lane, s3_alt);
-            __syncthreads();
-            store_tiles_split<2 * CB, LB2, 2, 2>(act, bias_, acc_, wave, lane);      // in place: the halo is still zero
-            __syncthreads();
-        }
-        {
-            f32x4 acc_[1][2], bias_[2];                                  // conv4: 32 -> 64, stride 2 -> 8x8
-            prefetch_bias<NW, 8, 1, 2>(a.packed + a.off.b[4], bias_, wave, lane);
-            conv3x3_mfma_s3p<NW, 2 * CB, 4 * CB, LB2, 2, 1, 2>(act, a.packed + a.off.w_s3[4], acc_, wave, lane, s3_alt);
-            __syncthreads();
-            zero_halo_b<LB4, NTHR>(act);
-            store_tiles_split<4 * CB, LB4, 1, 2>(act, bias_, acc_, wave, lane);
-            __syncthreads();
-        }
-        {
-            f32x4 acc5[T4M][T4N], bias5s[T4N];                           // conv5: 64 -> 64 @8x8 in the exact path's tiling (the heads read it)
-            prefetch_bias<NW, 8, T4M, T4N>(a.packed + a.off.b[5], bias5s, wave, lane);
-            conv3x3_mfma_s3p<NW, 4 * CB, 4 * CB, LB4, 1, T4M, T4N>(act, a.packed + a.off.w_s3[5], acc5, wave, lane, s3_alt);
-            if constexpr (KIND != AFFNET_NET_HARDNET)
+            f32x4 acc5[T4M][T4N];                                        // conv5: 64 -> 64 @8x8 in the exact path's tiling (the heads read it)
+            conv3x3_mfma_s3q<NW, 4 * CB, 4 * CB, LQ4, 1, T4M, T4N>(act, a.packed + a.off.w_s3[5], wf5, acc5, wave, lane, false);
+            if constexpr (KIND != AFFNET_NET_HARDNET) {
+                int lane_h = lane;                                       // opaque: 4 * (lane >> 4) is recomputed here, not carried (and spilled) from the kernel's top
+                asm volatile("" : "+v"(lane_h));
                 head_partials<KIND, T4M>(a.packed + a.off.head_w, bias5s, acc5,
-                                         a.out + pidx * (KIND == AFFNET_NET_AFFNET ? HEAD_PART_AFF : HEAD_PART_ORI), wave, lane);
+                                         a.out + pidx * (KIND == AFFNET_NET_AFFNET ? HEAD_PART_AFF : HEAD_PART_ORI), wave, lane_h);
+            }
         }
         return;
     }
@@ -984,7 +1010,7 @@ int aff_hardnet_forward_pyr_marked(affnet_ctx* ctx, const float* packed, const f
 
 extern "C" int affnet_debug_split3_variant(affnet_ctx* ctx, int bits) {
     if (!ctx) return AFFNET_ERR_INVALID;
-    ctx->split3_alt = (bits & 2) == 0;      // bit 1: split-operand HardNet loops without the alternating wave priorities (A/B aid)
+    ctx->split3_alt = (bits & 1) != 0;      // bit 0: split-operand HardNet loops WITH alternating wave priorities (A/B aid; default off since round 4)
     return AFFNET_OK;
 }
 

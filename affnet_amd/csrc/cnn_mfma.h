@@ -203,6 +203,14 @@ __device__ __forceinline__ void prefetch_bias(const float* __restrict__ bias, f3
     for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const f32x4*>(&bias[(ng * TN + j) * 16 + 4 * (lane >> 4)]);   // channels 4g..4g+3
 }
 
+// Same with the lane index made opaque: the compiler then recomputes 4 * (lane >> 4) here instead of keeping it in a register across the
+// whole kernel (at the 128-VGPR cap of the 16-channel split trunks that one value was spilled to scratch).
+template <int NW, int HOUT, int TM, int TN>
+__device__ __forceinline__ void prefetch_bias_fresh(const float* __restrict__ bias, f32x4 (&bv)[TN], int wave, int lane) {
+    asm volatile("" : "+v"(lane));
+    prefetch_bias<NW, HOUT, TM, TN>(bias, bv, wave, lane);
+}
+
 // PROBE (tuning aid, affnet_cnn32_probe): bit 0 = skip the weight loads, bit 1 = skip the activation loads inside the loop,
 // bit 3 = activation reads from lane-consecutive addresses (bank-conflict-free reference pattern).
 template <int NW, int CIN, int COUT, typename LI, int STRIDE, int TM, int TN, int GRP, int PROBE = 0>
@@ -570,6 +578,288 @@ __device__ __forceinline__ void conv3x3_mfma_s3p_c16(const float* act, const flo
         }
     }
     if (alt_prio) __builtin_amdgcn_s_setprio(0);
+}
+
+// ---- round 4: term-interleaved pre-split layout + term-major MFMA order ------------------------------------------------------------
+// LayB keeps the three bf16 planes of a layer TS bytes apart.  2 * TS exceeds the 16-bit DS offset field for every layer here, so each
+// fragment read of the loops above needed its own v_add_u32 (3 per pixel tile and step) and the hazard s_nops the compiler puts between an
+// MFMA and a VALU write of a register the MFMA reads - inside the MFMA stream.  LayQ interleaves the terms INSIDE the pixel cell:
+// element (term t, channel c, y, x) sits at  (c / 8) * GS + ((y + 1) * WP + x + 1) * 48 + t * 16 + (c % 8) * 2  bytes, so the three
+// terms of a lane's fragment are one address + immediates 0 / 16 / 32, the tiles of a wave further immediates, and a k = 32 step costs ONE
+// v_add (step offset, an SGPR) instead of 3 TM.  Bank behaviour of the 48-byte pixel pitch (ds_read_b128, 16-lane service groups, tools/
+// bank model in DESIGN.md): 16 pixels of a row at 48 B cover the 64 banks exactly once (12 m mod 64 are the sixteen multiples of 4), so
+// the stride-1 readers are conflict free with GS = 0 (mod 256); 16 pixels at a 96 B pitch (stride-2 reader of a 32-wide layer) with
+// GS = 16 (mod 256); two rows of 8 pixels with a 768 B row pitch (8-wide layers, WP = 16) with GS = 128 (mod 256).  Only the stride-2
+// reader of the 16-wide layers (conv4) keeps 2-way conflicts: its row pitch 2 * 18 * 48 B would have to be a multiple of 256 B (WP = 24:
+// 166 KB for the 64-channel layers).
+template <int H_, int W_, int WP_, int C_, int GREM_ = 0>
+struct LayQ {
+    static constexpr int H = H_, W = W_, WP = WP_, C = C_;      // H rows x W columns (+ a one-cell halo), row stride WP cells of 48 bytes
+    static constexpr int CELL = 48;
+    static constexpr int GS = (((H_ + 2) * WP_ * CELL + 255) / 256) * 256 + GREM_;      // bytes per 8-channel group
+    static constexpr int BYTES = (C_ / 8) * GS;
+};
+
+template <typename L, int NTHR>
+__device__ __forceinline__ void zero_halo_q(float* act, int tid = threadIdx.x) {
+    constexpr int H = L::H, W = L::W, CELLS = 2 * (W + 2) + 2 * H, GROUPS = L::C / 8;
+    char* base = reinterpret_cast<char*>(act);
+    for (int i = tid; i < GROUPS * CELLS * 3; i += NTHR) {           // one 16-byte store = one term of one halo cell
+        const int t = i % 3, ce = i / 3;
+        const int g = ce / CELLS, e = ce - g * CELLS;
+        int y, x;
+        if (e < W + 2) { y = 0; x = e; }
+        else if (e < 2 * (W + 2)) { y = H + 1; x = e - (W + 2); }
+        else { const int r = e - 2 * (W + 2); y = 1 + (r >> 1); x = (r & 1) ? W + 1 : 0; }
+        *reinterpret_cast<f32x4*>(base + (size_t)g * L::GS + (y * L::WP + x) * L::CELL + t * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+}
+
+// (+ bias,) ReLU, split into three bf16 terms, store ONE pixel tile into a LayQ layout: `cell` = byte offset of the lane's pixel cell
+template <typename LO, int TN, bool ADD_BIAS = true>
+__device__ __forceinline__ void split_store_tile_q(char* base, int cell, int nt0, const f32x4 (&bias)[TN], const f32x4 (&acc)[TN], int g) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        f32x4 v = acc[j];
+        if (ADD_BIAS) v += bias[j];
+        v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+        const int c0 = (nt0 + j) * 16 + 4 * g;                           // first of this lane's 4 channels
+        char* dst = base + (c0 >> 3) * LO::GS + cell + (c0 & 4) * 2;
+        f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const unsigned u0 = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
+            const unsigned u1 = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
+            *reinterpret_cast<uint2*>(dst + t * 16) = make_uint2(u0, u1);
+            if (t < 2) { split_remainder(lo, u0); split_remainder(hi, u1); }
+        }
+    }
+}
+
+template <int COUT, typename LO, int TM, int TN, int HT = LO::H>
+__device__ __forceinline__ void store_tiles_split_q(float* act, const f32x4 (&bias)[TN], const f32x4 (&acc)[TM][TN], int wave, int lane, int row_off = 0) {
+    constexpr int W = LO::W;
+    constexpr int MT = HT * W / 16, MG = MT / TM;
+    const int mg = wave % MG, ng = wave / MG;
+    const int n = lane & 15, g = lane >> 4;
+    char* base = reinterpret_cast<char*>(act);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int p = (mg * TM + i) * 16 + n;
+        const int oy = p / W, ox = p - oy * W;
+        split_store_tile_q<LO, TN>(base, ((oy + row_off + 1) * LO::WP + ox + 1) * LO::CELL, ng * TN, bias, acc[i], g);
+    }
+}
+
+// Weight fragments of one k = 32 step of a split layer: [term][channel tile]
+template <int TN>
+struct S3W {
+    bf16x8 w[3][TN];
+};
+
+// Lane part of the weight address of a split layer (bytes): the step offset is an SGPR, the tile offset an immediate
+template <int NW, int COUT, int MG, int TN>
+__device__ __forceinline__ int s3_w_lane(int wave, int lane) {
+    return (((lane >> 4) * COUT) + (wave / MG) * TN * 16 + (lane & 15)) * 16;
+}
+template <int COUT, int TN>
+__device__ __forceinline__ void s3_load_w(S3W<TN>& dst, __amdgpu_buffer_rsrc_t wrsrc, int w_lane, int s) {
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+            dst.w[t][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_lane + j * 256, ((s * 3 + t) * 4 * COUT) * 16, 0));
+}
+// The first step's weights of a layer do not depend on the activations: requested BEFORE the barriers / epilogue of the previous layer
+// (1 - 2 k cycles of L2 latency under load, otherwise paid with an idle matrix pipe at the head of every loop).
+template <int NW, int CIN, int COUT, int HOUT_TILES, int TM, int TN>
+__device__ __forceinline__ void s3_prefetch_w0(const float* __restrict__ Ws, S3W<TN>& w0, int wave, int lane) {
+    constexpr int MG = HOUT_TILES / TM;
+    constexpr int WS_FLOATS = (CIN == 16 ? 5 : 9 * (CIN / 32)) * 3 * 4 * COUT * 4;
+    s3_load_w<COUT, TN>(w0, weight_rsrc(Ws, WS_FLOATS), s3_w_lane<NW, COUT, MG, TN>(wave, lane), 0);
+}
+
+// The contraction on a term-interleaved pre-split input (LI = LayQ).  MFMA order is TERM-MAJOR: a term pair (w_i, a_j) runs over all
+// TM x TN tiles of the wave before the next pair starts, so consecutive MFMAs never share an accumulator (the tile-major order of
+// conv3x3_mfma_s3p chained six dependent MFMAs per accumulator, two chains interleaved) and the activation terms retire one after the
+// other: pairs (w0 a0, w1 a0, w2 a0) - a0 dead, its registers take the NEXT step's a0 - (w0 a1, w1 a1) - a1 reloaded - (w0 a2) - a2
+// reloaded.  Every fragment read has >= 24 MFMAs (a0), 32 (a1), 40 (a2) of this wave between issue and use.  The order of the six pairs
+// inside a step does not matter numerically: the fp32 accumulator already carries the sum over all previous steps.
+// C16 = true: 16 input channels (AffNet / OriNet conv1, conv2): one k = 32 step = two taps x 16 channels (lane quarter kq: tap 2 s + (kq >> 1),
+// channel group kq & 1), 5 steps, the pad half-step re-reads tap 8 against zero weights.
+// PROBE (tools/probes/s3_loop_probe.hip only): bit 0 = no weight loads inside the loop, bit 1 = no fragment reloads, bits 4.. = s_nop pacing
+template <int NW, int CIN, int COUT, typename LI, int STRIDE, int TM, int TN, int PROBE = 0>
+__device__ __forceinline__ void conv3x3_mfma_s3q(const float* act, const float* __restrict__ Ws, const S3W<TN>& w_first, f32x4 (&acc)[TM][TN],
+                                                 int wave, int lane, bool alt_prio) {
+    constexpr bool C16 = (CIN == 16);
+    constexpr int HOUT = LI::H / STRIDE, WOUT = LI::W / STRIDE;
+    constexpr int MT = HOUT * WOUT / 16, NT = COUT / 16;
+    constexpr int MG = MT / TM, NG = NT / TN;
+    constexpr int NG32 = C16 ? 1 : CIN / 32, NS = C16 ? 5 : 9 * NG32;
+    static_assert(MG * NG == NW && (C16 || CIN % 32 == 0) && LI::C == CIN, "bad tiling for the split-operand loop");
+    const int mg = wave % MG;
+    const int m = lane & 15, kq = lane >> 4;
+    int a_lane;                                                            // bytes
+    {
+        const int p = mg * TM * 16 + m;
+        const int oy = p / WOUT, ox = p - oy * WOUT;
+        a_lane = (C16 ? (kq & 1) : kq) * LI::GS + ((oy * STRIDE) * LI::WP + ox * STRIDE) * LI::CELL;
+    }
+    const unsigned a_addr0 = lds_byte_addr(act) + a_lane;
+    auto a_imm = [](int i) { return LI::CELL * (WOUT == 8 ? i * 2 * STRIDE * LI::WP : (((i * 16) / WOUT) * STRIDE * LI::WP + ((i * 16) % WOUT) * STRIDE)); };
+    static_assert(LI::CELL * ((TM - 1) * 2 * STRIDE * LI::WP + 2 * STRIDE * LI::WP) + 32 < 65536, "tile immediates must fit the DS offset field");
+    constexpr int WS_FLOATS = (C16 ? 5 : 9 * NG32) * 3 * 4 * COUT * 4;
+    const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(Ws, WS_FLOATS);
+    const int w_lane = s3_w_lane<NW, COUT, MG, TN>(wave, lane);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto frag_addr = [&](int s) -> unsigned {
+        if (C16) {
+            const int ta = 2 * s, tb = (2 * s + 1 < 9) ? 2 * s + 1 : 8;
+            const int off_a = ((ta / 3) * LI::WP + ta % 3) * LI::CELL, off_b = ((tb / 3) * LI::WP + tb % 3) * LI::CELL;
+            return a_addr0 + ((kq >> 1) ? off_b : off_a);
+        }
+        const int tap = s / NG32, G = s - tap * NG32;
+        const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
+        return a_addr0 + 4 * G * LI::GS + (ky * LI::WP + kx) * LI::CELL;
+    };
+    bf16x8 a[TM][3];
+    S3W<TN> wb[2];
+    wb[0] = w_first;
+    {
+        const unsigned ab = frag_addr(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) a[i][t] = __builtin_bit_cast(bf16x8, lds_read4(ab + a_imm(i) + t * 16));
+    }
+    auto pair_mfma = [&](const S3W<TN>& wc, int tw, int ta) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc.w[tw][j], a[i][ta], acc[i][j], 0, 0, 0);
+                if constexpr ((PROBE >> 4) != 0) __builtin_amdgcn_sched_barrier(0);
+                if constexpr ((PROBE >> 4) != 0) asm volatile("s_nop %0" ::"n"((PROBE >> 4) - 1));
+                if constexpr ((PROBE >> 4) != 0) __builtin_amdgcn_sched_barrier(0);
+            }
+    };
+    auto reload = [&](unsigned ab, int t) {
+        if constexpr (PROBE & 2) return;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i][t] = __builtin_bit_cast(bf16x8, lds_read4(ab + a_imm(i) + t * 16));
+    };
+    // one step: weights of step s_next requested first (spread between the first MFMAs), fragments of s_next as the terms retire
+    const int wave_hi = __builtin_amdgcn_readfirstlane(wave >> 2);      // scalar: the priority switch below must not become a divergent branch
+    auto step = [&](const S3W<TN>& wc, S3W<TN>& wn, int s_next, bool load_next) {
+        if (alt_prio) {                       // the two waves of a SIMD (w, w + 4) take turns at the higher priority, one step each
+            if ((s_next ^ wave_hi) & 1) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+        unsigned ab = frag_addr(s_next);
+        asm("" : "+v"(ab));
+        if constexpr (PROBE & 1) { if (load_next) wn = wc; }
+        else { if (load_next) s3_load_w<COUT, TN>(wn, wrsrc, w_lane, s_next); }
+        constexpr int NT_ = TM * TN;
+        pair_mfma(wc, 0, 0); pair_mfma(wc, 1, 0); pair_mfma(wc, 2, 0);
+        if (load_next) reload(ab, 0);
+        pair_mfma(wc, 0, 1); pair_mfma(wc, 1, 1);
+        if (load_next) reload(ab, 1);
+        pair_mfma(wc, 0, 2);
+        if (load_next) reload(ab, 2);
+        // pin the interleaving: one weight load after each of the first 3 TN MFMAs, the fragment reads where their registers die
+        if (load_next && PROBE == 0) {
+#pragma unroll
+            for (int l = 0; l < 3 * TN; ++l) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NT_ - 3 * TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT_, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, NT_, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    static_assert(3 * TN <= 3 * TM * TN, "weight loads are spread over the first term pairs");
+    if constexpr (C16) {
+        // 16 input channels (5 steps, fully unrolled; AffNet / OriNet conv1, conv2 at 128 VGPRs and four waves per SIMD): ONE weight set,
+        // the next step's fragments are requested when the current step's last term pair has been issued - the other waves of the SIMD
+        // cover the L2 round trip (a second set cost 8 - 10 spilled registers here)
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const bool more = s + 1 < NS;
+            unsigned ab = frag_addr(more ? s + 1 : s);
+            asm("" : "+v"(ab));
+            constexpr int NT_ = TM * TN;
+            pair_mfma(wb[0], 0, 0); pair_mfma(wb[0], 1, 0); pair_mfma(wb[0], 2, 0);
+            if (more) reload(ab, 0);
+            pair_mfma(wb[0], 0, 1); pair_mfma(wb[0], 1, 1);
+            if (more) reload(ab, 1);
+            pair_mfma(wb[0], 0, 2);
+            if (more) {
+                reload(ab, 2);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * NT_, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT_, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, NT_, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                s3_load_w<COUT, TN>(wb[0], wrsrc, w_lane, s + 1);
+            }
+        }
+        return;
+    }
+#pragma unroll 1
+    for (int s = 0; s + 2 < NS; s += 2) {
+        step(wb[0], wb[1], s + 1, true);
+        step(wb[1], wb[0], s + 2, true);
+    }
+    if (NS & 1) {                             // NS odd: the loop left the last step in wb[0]
+        step(wb[0], wb[1], NS - 1, false);
+    } else {
+        step(wb[0], wb[1], NS - 1, true);
+        step(wb[1], wb[0], NS - 1, false);
+    }
+    if (alt_prio) __builtin_amdgcn_s_setprio(0);
+}
+
+// The same into a term-interleaved layout (LayQ).
+template <int NW, typename LQH, int TN>
+__device__ __forceinline__ void conv0_half_split_q(const float* patch, const float (&b)[3][TN], const f32x4 (&bv)[TN], float* act, int pass,
+                                                   int wave, int lane) {
+    static_assert(NW == 8 && LQH::H == 16 && LQH::W == 32 && LQH::C == 16 * TN, "half-patch conv0: 8 waves, all channel tiles in every wave");
+    const int m = lane & 15, kq = lane >> 4;
+    int toff[3];
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+        const int t = 4 * s3 + kq;
+        toff[s3] = t < 9 ? (t / 3) * WP32 + (t % 3) : 0;
+    }
+    char* base = reinterpret_cast<char*>(act);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        int row_l, x0;
+        if (k < 4) { const int T = 4 * wave + k; row_l = T >> 1; x0 = (T & 1) * 16; }
+        else { row_l = pass ? -1 : 16; x0 = (wave & 1) * 16; }
+        const int pb = (row_l + 16 * pass) * WP32 + x0 + m;
+        float av[3];
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) av[s3] = patch[pb + toff[s3]];
+        f32x4 acc[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[j] = bv[j];
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s3][j], av[s3], acc[j], 0, 0, 0);
+        split_store_tile_q<LQH, TN, false>(base, ((row_l + 1) * LQH::WP + x0 + m + 1) * LQH::CELL, 0, bv, acc, kq);
+    }
 }
 
 // Same contraction with ONE A register set that is reloaded in place (for TM = 8 under a 128-VGPR budget, where two
