@@ -53,7 +53,7 @@ extern "C" int affnet_cnn32_pack_weights(int kind, const float* const* conv_w, c
                 }
         }
     }
-    // EXPLORATORY split copies (conv1 .. conv5 = S3_LAYER_MASK, all three nets): the same BN-folded fp32 weight as three bf16 terms (nearest even,
+    // split copies for AFFNET_ARITH_FP32_SPLIT3 (conv1 .. conv5 = S3_LAYER_MASK, all three nets): the same BN-folded fp32 weight as three bf16 terms (nearest even,
     // exact remainders), [tap][cin / 32][term][kq][cout][8]: lane (cout, kq) of the bf16 MFMA's A operand = 8 consecutive input channels
     for (int i = 1; i < 6; ++i) {
         if (!L.w_s3[i]) continue;
@@ -82,9 +82,24 @@ extern "C" int affnet_cnn32_pack_weights(int kind, const float* const* conv_w, c
     }
     if (kind == AFFNET_NET_HARDNET) {
         if (!head_bn_mean || !head_bn_var) return AFFNET_ERR_INVALID;
+        uint16_t* hs3 = reinterpret_cast<uint16_t*>(out + L.head_s3);
+        auto bf16_rne_h = [](float x) -> uint32_t { uint32_t u; memcpy(&u, &x, 4); return (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u; };
         for (int n = 0; n < 128; ++n) {
             const float s = 1.0f / sqrtf(head_bn_var[n] + 1e-5f);
             out[L.head_b + n] = -head_bn_mean[n] * s;
+            // split copy of the same BN-folded weights (AFFNET_ARITH_FP32_SPLIT3): three bf16 terms, exact remainders, in the B-fragment order
+            // of hardnet_head_s3_kernel: [k / 32][term][kq = (k % 32) / 8][n][k % 8]
+            for (int c = 0; c < 128; ++c)
+                for (int pp = 0; pp < 64; ++pp) {
+                    const size_t k = (size_t)pp * 128 + c;
+                    float r = head_w[(size_t)n * HEAD_K + c * 64 + pp] * s;
+                    for (int term = 0; term < 3; ++term) {
+                        const uint32_t hb = bf16_rne_h(r);
+                        float hf; memcpy(&hf, &hb, 4);
+                        r -= hf;
+                        hs3[(((((k >> 5) * 3 + term) * 4 + ((k & 31) >> 3)) * 128 + n) << 3) + (k & 7)] = (uint16_t)(hb >> 16);
+                    }
+                }
             // K order of the head GEMM = the trunk kernel's output order k = pixel * 128 + channel; stored interleaved by 4 like
             // the conv weights, [k/16][(k/4)%4][n][k%4], so that one 16-byte load per lane is the B fragment of 4 MFMA k-steps
             for (int c = 0; c < 128; ++c)
@@ -854,6 +869,105 @@ __global__ __launch_bounds__(256, 2) void hardnet_head_kernel(const float* __res
         }
 }
 
+// The same GEMM on split operands (AFFNET_ARITH_FP32_SPLIT3): the A slab is split ONCE per element while it is staged into LDS (each conv5
+// element belongs to exactly one workgroup: M-tile x K-quarter), stored as term-interleaved 48-byte cells of 8 consecutive k
+// (row pitch 128 k * 6 B + 16 B: the 16 rows of an M-tile fall into 16 different 16-byte bank slots), B = the pre-split head weights
+// [k / 32][term][kq][n][8] straight from L2.  Six v_mfma_f32_16x16x32_bf16 per fp32 product in term-major order, fp32 accumulate; same
+// partial-sum scratch and finish kernel as the exact path.
+#define HEAD_S3_ROWB (HEAD_KC * 6 + 16)
+template <int MP>
+__global__ __launch_bounds__(256, 2) void hardnet_head_s3_kernel(const float* __restrict__ trunk, const float* __restrict__ Bw3,
+                                                                 const int32_t* __restrict__ count, int n_max, float* __restrict__ partial) {
+    constexpr int MI = MP / 16;
+    constexpr int NA = MP * HEAD_KC / 4 / 256;
+    __shared__ __attribute__((aligned(16))) char As[MP * HEAD_S3_ROWB];
+    const int n = count ? min(count[blockIdx.z], n_max) : n_max;
+    const int p0 = blockIdx.x * MP;
+    if (p0 >= n) return;
+    const size_t rows_total = (size_t)gridDim.z * n_max;
+    const int kbeg = blockIdx.y * (HEAD_K / HEAD_KSPLIT);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int m = lane & 15, kq = lane >> 4;
+    const __amdgpu_buffer_rsrc_t rA = weight_rsrc(trunk + (size_t)blockIdx.z * n_max * HEAD_K, n * HEAD_K);   // rows >= n -> 0
+    const __amdgpu_buffer_rsrc_t rB = weight_rsrc(Bw3, HEAD_K * 128 * 3 / 2);
+    int offA[NA];
+#pragma unroll
+    for (int r = 0; r < NA; ++r) {
+        const int f = tid + 256 * r, row = f >> 5, c4 = f & 31;
+        offA[r] = ((p0 + row) * HEAD_K + 4 * c4) * 4;
+    }
+    const int offB = ((kq * 128) + wave * 32 + m) * 16;
+    const unsigned a_addr = lds_byte_addr(reinterpret_cast<const float*>(As)) + m * HEAD_S3_ROWB + kq * 48;
+    f32x4 acc[MI][2], stage[NA];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < NA; ++r) stage[r] = buf_read4(rA, offA[r], kbeg * 4);
+#pragma unroll 1
+    for (int k0 = kbeg; k0 < kbeg + HEAD_K / HEAD_KSPLIT; k0 += HEAD_KC) {
+        __syncthreads();                                              // the previous slab has been consumed
+#pragma unroll
+        for (int r = 0; r < NA; ++r) {
+            const int f = tid + 256 * r, row = f >> 5, c4 = f & 31;
+            char* dst = As + row * HEAD_S3_ROWB + (c4 >> 1) * 48 + (c4 & 1) * 8;      // cell = 8 consecutive k, this float4 = its lower / upper half
+            f32x2 lo = {stage[r].x, stage[r].y}, hi = {stage[r].z, stage[r].w};
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const unsigned u0 = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
+                const unsigned u1 = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
+                *reinterpret_cast<uint2*>(dst + t * 16) = make_uint2(u0, u1);
+                if (t < 2) { split_remainder(lo, u0); split_remainder(hi, u1); }
+            }
+        }
+        __syncthreads();
+        if (k0 + HEAD_KC < kbeg + HEAD_K / HEAD_KSPLIT) {
+#pragma unroll
+            for (int r = 0; r < NA; ++r) stage[r] = buf_read4(rA, offA[r], (k0 + HEAD_KC) * 4);
+        }
+        bf16x8 fb[2][3][2];                                           // [buffer][term][N-tile]
+        auto load_b = [&](int buf, int ks) {
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    fb[buf][t][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rB, offB + j * 256, ((ks * 3 + t) * 4 * 128) * 16, 0));
+        };
+        load_b(0, k0 >> 5);
+#pragma unroll
+        for (int s = 0; s < HEAD_KC / 32; ++s) {
+            const int cur = s & 1;
+            if (s + 1 < HEAD_KC / 32) load_b(cur ^ 1, (k0 >> 5) + s + 1);
+            bf16x8 fa[MI][3];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int t = 0; t < 3; ++t) fa[i][t] = __builtin_bit_cast(bf16x8, lds_read4(a_addr + i * 16 * HEAD_S3_ROWB + s * 192 + t * 16));
+            constexpr int TA[6] = {0, 0, 0, 1, 1, 2}, TB[6] = {0, 1, 2, 0, 1, 0};      // term pairs (a_i, b_j), i + j <= 2, term-major
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][TA[q]], fb[cur][TB[q]][j], acc[i][j], 0, 0, 0);
+        }
+    }
+    // acc[i][j][r]: patch p0 + 16 i + 4 (lane>>4) + r, channel 32 wave + 16 j + (lane & 15)
+    const int g = lane >> 4;
+    float* dst = partial + ((size_t)blockIdx.y * rows_total + (size_t)blockIdx.z * n_max) * 128;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = p0 + 16 * i + 4 * g + r;
+            if (row >= n) continue;
+            dst[(size_t)row * 128 + wave * 32 + m] = acc[i][0][r];
+            dst[(size_t)row * 128 + wave * 32 + 16 + m] = acc[i][1][r];
+        }
+}
+
 // One wavefront per patch: sum the K-split partials in fixed order, + BN bias, L2 normalise (eps 1e-8).  Rows past the image's row
 // count are cleared here (the caller's descriptor buffer needs no separate fill).
 __global__ __launch_bounds__(256) void hardnet_finish_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
@@ -952,7 +1066,14 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
         // patches per workgroup: the 64-patch shape once it gives every CU a workgroup, else 32 / 16 (same sums, more workgroups)
         int mp = (aff_cdiv(n_max, 64) * HEAD_KSPLIT * B >= 256) ? 64 : ((aff_cdiv(n_max, 32) * HEAD_KSPLIT * B >= 256) ? 32 : 16);
         if (const char* e = getenv("AFFNET_HEAD_MP")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) mp = v; }   // tuning aid
-        if (mp == 64)
+        if (split) {              // AFFNET_ARITH_FP32_SPLIT3: the head GEMM on split operands as well
+            if (mp == 64)
+                hipLaunchKernelGGL(hardnet_head_s3_kernel<64>, dim3(aff_cdiv(n_max, 64), HEAD_KSPLIT, B), dim3(256), 0, st, scratch, packed + L.head_s3, count, n_max, partial);
+            else if (mp == 32)
+                hipLaunchKernelGGL(hardnet_head_s3_kernel<32>, dim3(aff_cdiv(n_max, 32), HEAD_KSPLIT, B), dim3(256), 0, st, scratch, packed + L.head_s3, count, n_max, partial);
+            else
+                hipLaunchKernelGGL(hardnet_head_s3_kernel<16>, dim3(aff_cdiv(n_max, 16), HEAD_KSPLIT, B), dim3(256), 0, st, scratch, packed + L.head_s3, count, n_max, partial);
+        } else if (mp == 64)
             hipLaunchKernelGGL(hardnet_head_kernel<64>, dim3(aff_cdiv(n_max, 64), HEAD_KSPLIT, B), dim3(256), 0, st, scratch, packed + L.head_w, count, n_max, partial);
         else if (mp == 32)
             hipLaunchKernelGGL(hardnet_head_kernel<32>, dim3(aff_cdiv(n_max, 32), HEAD_KSPLIT, B), dim3(256), 0, st, scratch, packed + L.head_w, count, n_max, partial);

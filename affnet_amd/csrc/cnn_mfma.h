@@ -69,7 +69,8 @@ struct NetLayout {
     int cin[6], cout[6];
     size_t w_off[6], b_off[6];
     size_t head_w, head_b;  // head weights / bias (HardNet: BN-folded [8192][128] + bias[128])
-    size_t w_s3[6];         // EXPLORATORY (0 = none): conv weights once more as three bf16 terms, [tap][cin/32][term][kq][cout][8]
+    size_t w_s3[6];         // AFFNET_ARITH_FP32_SPLIT3 (0 = none): conv weights once more as three bf16 terms, [tap][cin/32][term][kq][cout][8]
+    size_t head_s3;         // HardNet only: the BN-folded head weights as three bf16 terms, [k/32][term][kq][n 128][8]  (k = pixel * 128 + channel)
     size_t total;
 };
 
@@ -97,9 +98,11 @@ static inline NetLayout net_layout(int kind) {
     for (int i = 0; i < 6; ++i) {
         L.w_s3[i] = 0;
         const bool has = (kind == AFFNET_NET_HARDNET && ((S3_LAYER_MASK >> i) & 1)) ||
-                         ((kind == AFFNET_NET_AFFNET || kind == AFFNET_NET_ORINET) && i >= 1);     // 16-channel trunks: conv1 .. conv5
+                         ((kind == AFFNET_NET_AFFNET || kind == AFFNET_NET_ORINET || kind == AFFNET_NET_AFFNET_FULLCONV) && i >= 1);     // 16-channel trunks: conv1 .. conv5
         if (has) { L.w_s3[i] = off; off += s3_floats(L.cin[i], L.cout[i]); }
     }
+    L.head_s3 = 0;
+    if (kind == AFFNET_NET_HARDNET) { L.head_s3 = off; off += (size_t)HEAD_K * 128 * 3 / 2; }
     L.total = off;
     return L;
 }
@@ -107,6 +110,7 @@ static inline NetLayout net_layout(int kind) {
 struct NetOffsets {        // device-side copy of the offsets (by-value kernel argument)
     int w[6], b[6], head_w, head_b;
     int w_s3[6];
+    int head_s3;
 };
 
 static inline NetOffsets to_offsets(const NetLayout& L) {
@@ -114,6 +118,7 @@ static inline NetOffsets to_offsets(const NetLayout& L) {
     for (int i = 0; i < 6; ++i) { o.w[i] = (int)L.w_off[i]; o.b[i] = (int)L.b_off[i]; }
     o.head_w = (int)L.head_w; o.head_b = (int)L.head_b;
     for (int i = 0; i < 6; ++i) o.w_s3[i] = (int)L.w_s3[i];
+    o.head_s3 = (int)L.head_s3;
     return o;
 }
 
@@ -328,13 +333,15 @@ __device__ __forceinline__ void conv3x3_mfma(const float* act, const float* __re
     }
 }
 
-// ---- EXPLORATORY: the same contraction on split operands (fp32 = three bf16 terms) ---------------------------------------------
+// ---- AFFNET_ARITH_FP32_SPLIT3: the same contraction on split operands (fp32 = three bf16 terms) --------------------------------------
+// (round 3's loops on separate term planes, LayB / conv3x3_mfma_s3p: kept for tools/probes/s3_loop_probe.hip, which measures them against
+// the round-4 loops the trunks use: LayQ / conv3x3_mfma_s3q below)
 // x = x0 + x1 + x2 with every term rounded to bf16 is exact for a 24-bit significand, every bf16 x bf16 product is exact in the fp32
 // accumulator of v_mfma_f32_16x16x32_bf16, and the six products with i + j <= 2 carry an fp32 product to 2^-25 relative - at 16x the
 // rate of the fp32 MFMA.  Weights are split at pack time: Ws [tap][CIN/32][term][kq][COUT][8 bf16]; activations are split ONCE, by the
 // epilogue of the layer that produces them, into three bf16 planes (LayB) - the first version kept them fp32 in LDS and split each
 // fragment in registers when it was read (9 taps x NG channel groups times per element): 4.5 VALU instructions per MFMA, matrix pipe
-// 49 % busy (round 3, removed).  Accumulator layout = conv3x3_mfma's.  Selected per context (affnet_debug_split3); never the default.
+// 49 % busy (round 3, removed).  Accumulator layout = conv3x3_mfma's.  Selected per context (affnet_set_arith).
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));

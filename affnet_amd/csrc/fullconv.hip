@@ -215,6 +215,76 @@ __global__ __launch_bounds__(512, 4) void dense_conv_kernel(DenseArgs a) {
     store_tiles_dense<HOUT, TM, TN, true>(out, a.Hout, a.Wout, Y0 / STRIDE, X0 / STRIDE, bias, acc, wave, lane);
 }
 
+// ---- AFFNET_ARITH_FP32_SPLIT3: conv1 .. conv5 of the dense net on split operands -----------------------------------------------------
+// Same tiles-through-LDS scheme; the loader splits every fp32 activation ONCE into three bf16 terms while it stages the input tile (+ 1-px
+// apron of real neighbours) into the term-interleaved cells of LayQ, then the per-patch trunks' own loop (cnn_mfma.h: conv3x3_mfma_s3q) runs on
+// it.  Tiles are LQ::H x LQ::W input pixels (conv1 / conv2: 16 x 32 - the 32 x 32 tile of the exact path would need 111 KB pre-split).
+// Activations stay fp32 [C/4][Y][X] float4 planes in HBM between the layers, conv0 and the 8 x 8 head stay fp32 MFMA.
+template <int HOUT, int WOUT, int TM, int TN>
+__device__ __forceinline__ void store_tiles_dense_rect(float* __restrict__ out, int Hout, int Wout, int Y0, int X0, const f32x4 (&bias)[TN],
+                                                       const f32x4 (&acc)[TM][TN], int wave, int lane) {
+    constexpr int MT = HOUT * WOUT / 16, MG = MT / TM;
+    const int mg = wave % MG, ng = wave / MG;
+    const int n = lane & 15, g = lane >> 4;
+    const size_t plane = (size_t)Hout * Wout * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int p = (mg * TM + i) * 16 + n;
+        const int oy = p / WOUT, ox = p - oy * WOUT;
+        const int Y = Y0 + oy, X = X0 + ox;
+        if (Y >= Hout || X >= Wout) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            f32x4 v = acc[i][j] + bias[j];
+            v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
+            *reinterpret_cast<f32x4*>(out + ((size_t)((ng * TN + j) * 4 + g)) * plane + ((size_t)Y * Wout + X) * 4) = v;
+        }
+    }
+}
+
+template <int CIN, int COUT, int STRIDE, typename LQ, int TM, int TN>
+__global__ __launch_bounds__(512, 4) void dense_conv_s3_kernel(DenseArgs a) {
+    constexpr int NW = 8, TH = LQ::H, TWD = LQ::W, HOUT = TH / STRIDE, WOUT = TWD / STRIDE, NG4 = CIN / 4;
+    static_assert(LQ::C == CIN && LQ::BYTES <= 80 * 1024, "two workgroups per CU");
+    __shared__ __attribute__((aligned(16))) char actb[LQ::BYTES];
+    float* act = reinterpret_cast<float*>(actb);
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const float* in = a.in + blockIdx.z * a.in_stride;
+    float* out = a.out + blockIdx.z * a.out_stride;
+    const int X0 = blockIdx.x * TWD, Y0 = blockIdx.y * TH;              // input-tile origin
+    S3W<TN> w0;
+    f32x4 bias[TN];
+    s3_prefetch_w0<NW, CIN, COUT, HOUT * WOUT / 16, TM, TN>(a.W, w0, wave, lane);
+    {
+        constexpr int MG = (HOUT * WOUT / 16) / TM;                       // rectangular tile: the wave's N-tile group is wave / MG
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bias[j] = *reinterpret_cast<const f32x4*>(&a.bias[((wave / MG) * TN + j) * 16 + 4 * (lane >> 4)]);
+    }
+    // stage the tile + 1-px apron pre-split: one float4 = 4 channels of one pixel = half a cell of 8 channels
+    constexpr int TWA = TWD + 2, NPOS = (TH + 2) * TWA;
+    const size_t plane = (size_t)a.Hin * a.Win * 4;
+    for (int i = tid; i < NG4 * NPOS; i += 512) {
+        const int g = i / NPOS, r = i - g * NPOS;
+        const int ty = r / TWA, tx = r - ty * TWA;
+        const int Y = Y0 + ty - 1, X = X0 + tx - 1;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (Y >= 0 && Y < a.Hin && X >= 0 && X < a.Win) v = *reinterpret_cast<const f32x4*>(in + g * plane + ((size_t)Y * a.Win + X) * 4);
+        char* dst = actb + (g >> 1) * LQ::GS + (ty * LQ::WP + tx) * LQ::CELL + (g & 1) * 8;
+        f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const unsigned u0 = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
+            const unsigned u1 = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
+            *reinterpret_cast<uint2*>(dst + t * 16) = make_uint2(u0, u1);
+            if (t < 2) { split_remainder(lo, u0); split_remainder(hi, u1); }
+        }
+    }
+    __syncthreads();
+    f32x4 acc[TM][TN];
+    conv3x3_mfma_s3q<NW, CIN, COUT, LQ, STRIDE, TM, TN>(act, a.W, w0, acc, wave, lane, false);
+    store_tiles_dense_rect<HOUT, WOUT, TM, TN>(out, a.Hout, a.Wout, Y0 / STRIDE, X0 / STRIDE, bias, acc, wave, lane);
+}
+
 // 8 x 8 valid head 64 -> 3 (+ bias) on the matrix cores.  A direct GEMM would use 3 of the 16 MFMA rows; instead the taps of one
 // kernel ROW are folded into the N dimension: P[(o, kx)][y][x'] = sum over (ky, c) of W[o][c][ky][kx] * in[c][y + ky][x'] is a
 // GEMM with N = 3 * 8 = 24 (two 16-row tiles, 75 % useful), K = 8 * 64 = 512, and out[o][y][x] = bias + sum over kx of
@@ -358,6 +428,32 @@ int aff_fullconv_launch(affnet_ctx* ctx, const float* packed, const float* img, 
     layer(0, norm, bufA, g.Hp, g.Wp, g.Hp, g.Wp);
     hipLaunchKernelGGL(dense_conv0_kernel, dim3(aff_cdiv(g.Wp, 32), aff_cdiv(g.Hp, 32), B), dim3(512), 0, st, a);
     AFF_LAUNCH_CHECK(ctx);
+    if (ctx->arith == AFFNET_ARITH_FP32_SPLIT3) {
+        // conv1 .. conv5 on split operands (three bf16 terms per fp32 operand, six bf16 MFMAs per product, fp32 accumulate)
+        auto layer3 = [&](int i, const float* in, float* o, int Hin, int Win, int Hout, int Wout) {
+            layer(i, in, o, Hin, Win, Hout, Wout);
+            a.W = packed + L.w_s3[i];
+        };
+        typedef LayQ<16, 32, 34, 16> Q1;          // conv1 input tile: 16 rows x 32 columns, 16 channels (59 KB)
+        typedef LayQ<16, 32, 34, 16, 16> Q2;      // conv2 (stride 2) input tile
+        typedef LayQ<16, 16, 18, 32> Q3;          // conv3 / conv4 input tiles (61 KB)
+        typedef LayQ<8, 8, 16, 64, 128> Q5;       // conv5 input tile (61 KB)
+        layer3(1, bufA, bufB, g.Hp, g.Wp, g.Hp, g.Wp);
+        hipLaunchKernelGGL((dense_conv_s3_kernel<16, 16, 1, Q1, 4, 1>), dim3(aff_cdiv(g.Wp, 32), aff_cdiv(g.Hp, 16), B), dim3(512), 0, st, a);
+        AFF_LAUNCH_CHECK(ctx);
+        layer3(2, bufB, bufA, g.Hp, g.Wp, g.H2, g.W2);
+        hipLaunchKernelGGL((dense_conv_s3_kernel<16, 32, 2, Q2, 2, 1>), dim3(aff_cdiv(g.Wp, 32), aff_cdiv(g.Hp, 16), B), dim3(512), 0, st, a);
+        AFF_LAUNCH_CHECK(ctx);
+        layer3(3, bufA, bufB, g.H2, g.W2, g.H2, g.W2);
+        hipLaunchKernelGGL((dense_conv_s3_kernel<32, 32, 1, Q3, 2, 2>), dim3(aff_cdiv(g.W2, 16), aff_cdiv(g.H2, 16), B), dim3(512), 0, st, a);
+        AFF_LAUNCH_CHECK(ctx);
+        layer3(4, bufB, bufA, g.H2, g.W2, g.H4, g.W4);
+        hipLaunchKernelGGL((dense_conv_s3_kernel<32, 64, 2, Q3, 1, 2>), dim3(aff_cdiv(g.W2, 16), aff_cdiv(g.H2, 16), B), dim3(512), 0, st, a);
+        AFF_LAUNCH_CHECK(ctx);
+        layer3(5, bufA, bufB, g.H4, g.W4, g.H4, g.W4);
+        hipLaunchKernelGGL((dense_conv_s3_kernel<64, 64, 1, Q5, 2, 1>), dim3(aff_cdiv(g.W4, 8), aff_cdiv(g.H4, 8), B), dim3(512), 0, st, a);
+        AFF_LAUNCH_CHECK(ctx);
+    } else {
     layer(1, bufA, bufB, g.Hp, g.Wp, g.Hp, g.Wp);
     hipLaunchKernelGGL((dense_conv_kernel<16, 16, 1, LayC0, 8, 1, 1, true>), dim3(aff_cdiv(g.Wp, 32), aff_cdiv(g.Hp, 32), B), dim3(512), 0, st, a);
     AFF_LAUNCH_CHECK(ctx);
@@ -373,6 +469,7 @@ int aff_fullconv_launch(affnet_ctx* ctx, const float* packed, const float* img, 
     layer(5, bufA, bufB, g.H4, g.W4, g.H4, g.W4);
     hipLaunchKernelGGL((dense_conv_kernel<64, 64, 1, LayC4, 2, 1, 2, false>), dim3(aff_cdiv(g.W4, 8), aff_cdiv(g.H4, 8), B), dim3(512), 0, st, a);
     AFF_LAUNCH_CHECK(ctx);
+    }
     hipLaunchKernelGGL(fullconv_head_kernel, dim3(aff_cdiv(g.Wf, FH_SEG), aff_cdiv(g.Hf, 4), B), dim3(256), 0, st, bufB, packed + L.head_w, packed + L.head_b,
                        bufA, g.H4, g.W4, g.Hf, g.Wf, scratch_stride, scratch_stride);
     AFF_LAUNCH_CHECK(ctx);

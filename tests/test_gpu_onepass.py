@@ -67,14 +67,26 @@ def test_local_norm_exact(amd, golden_dir):
         engine.local_norm(torch.zeros(1, 1, 12, 40, device=DEV))          # reflect padding of 16 needs >= 17 px
 
 
-def test_dense_affnet_map(amd, nets, weights, golden_dir):
+_DENSE_ORACLE = {}
+
+
+@pytest.mark.parametrize("arith", ["fp32", "fp32_split3"])
+def test_dense_affnet_map(amd, nets, weights, golden_dir, arith):
     FC = nets[0]
     g = np.load(os.path.join(golden_dir, "onepass_synth.npz"))
     for (h, w, seed) in ((240, 320, 1), (131, 97, 4), (768, 1024, 2)):
         x = orc.synthetic_image(h, w, seed)
-        got = FC(x.to(DEV)).cpu().numpy()
-        with torch.no_grad():
-            want = opo.affnet_fullconv_forward(weights["AffNet"], x).numpy()
+        FC.arith = arith                                              # conv1 .. conv5 of the dense net on split operands (AFFNET_ARITH_FP32_SPLIT3)
+        try:
+            got = FC(x.to(DEV)).cpu().numpy()
+        finally:
+            FC.arith = "fp32"
+        if arith != "fp32":                                           # and the default mode is back, bit for bit
+            assert torch.equal(FC(x.to(DEV)), FC(x.to(DEV)))
+        if (h, w, seed) not in _DENSE_ORACLE:
+            with torch.no_grad():
+                _DENSE_ORACLE[(h, w, seed)] = opo.affnet_fullconv_forward(weights["AffNet"], x).numpy()
+        want = _DENSE_ORACLE[(h, w, seed)]
         assert got.shape == want.shape == (1, 4, h, w)
         d = np.abs(got - want)
         rec = {"max_abs_diff_vs_oracle": float(d.max()), "p99": float(np.percentile(d, 99)), "elements": int(d.size)}
@@ -82,7 +94,7 @@ def test_dense_affnet_map(amd, nets, weights, golden_dir):
             rec["max_abs_diff_vs_golden"] = float(np.abs(got[0, :, ::4, ::4] - g["map_240x320_sub"]).max())
         if (h, w) == (131, 97):
             rec["max_abs_diff_vs_golden"] = float(np.abs(got[0] - g["map_131x97"]).max())
-        record_parity("AffNetFastFullConv dense map %dx%d" % (w, h), **rec)
+        record_parity("AffNetFastFullConv dense map %dx%d%s" % (w, h, "" if arith == "fp32" else " [arith %s]" % arith), **rec)
         assert d.max() < 5e-5, rec
         assert rec.get("max_abs_diff_vs_golden", 0.0) < 5e-5, rec
         assert np.all(got[0, 1] == 0.0)                                   # a12 = 0 * det

@@ -308,6 +308,20 @@ def test_split_weight_copies_are_exact(kind, name, weights):
         mag = np.abs(t)                                                               # term k is at most 2^-8 of term k - 1 (nearest-even split)
         assert np.all(mag[1] <= mag[0] * 2.0 ** -8 + 1e-45) and np.all(mag[2] <= mag[1] * 2.0 ** -8 + 1e-45)
         off += n_fl
+    if kind == 2:
+        # HardNet head (8192 x 128, BN folded): split copy [k / 32][term][kq = (k % 32) / 8][n][k % 8] against the fp32 copy the exact path
+        # multiplies with ([k / 16][(k / 4) % 4][n][k % 4]); k = pixel * 128 + channel in both
+        K = 8192
+        head_off = off - sum((5 if layers[i][0].shape[1] == 16 else 9 * (layers[i][0].shape[1] // 32)) * 3 * 4 * layers[i][0].shape[0] * 4 for i in range(1, 6)) \
+            - (K * 128 + 128)
+        Wf = blob.numpy()[head_off: head_off + K * 128].reshape(K // 16, 4, 128, 4).transpose(0, 1, 3, 2).reshape(K, 128).astype(np.float64)
+        n_fl = K * 128 * 3 // 2
+        raw = bits[2 * off: 2 * (off + n_fl)].astype(np.uint32) << 16
+        t = raw.view(np.float32).astype(np.float64).reshape(K // 32, 3, 4, 128, 8).transpose(1, 0, 2, 4, 3).reshape(3, K, 128)
+        assert np.array_equal(t.sum(axis=0), Wf), float(np.abs(t.sum(axis=0) - Wf).max())
+        mag = np.abs(t)
+        assert np.all(mag[1] <= mag[0] * 2.0 ** -8 + 1e-45) and np.all(mag[2] <= mag[1] * 2.0 ** -8 + 1e-45)
+        off += n_fl
     assert off == blob.numel(), (off, blob.numel())
 
 
