@@ -204,6 +204,62 @@ __device__ __forceinline__ void head_partials(const float* __restrict__ hw, cons
     }
 }
 
+// OriNet head through LDS (round 4).  head_partials<ORINET> makes every lane fetch the weight vector of each of the 2 x 9 (output, tap)
+// pairs for its own pixel: 36 buffer_load_dwordx4 per wave, 295 KB of L2 -> L1 traffic per patch for 32 KB of distinct weights - the head
+// took 14.4 k cycles per workgroup against AffNet's 3.3 k (tools/s3_phase_timing.py), L1-bound.  Here the roles are swapped: a lane owns
+// the WEIGHT position (ky, kx) = its tile pixel and 4 channels, loads those weights once per output (4 loads) and reads the nine shifted
+// ACTIVATIONS from a zero-haloed 10 x 10 copy of the conv5 output in LDS (the activation buffer is dead after the conv5 loop):
+//   out[o][qy][qx] = sum over (ky, kx, c) of  W[o][ky][kx][c] * A[qy + ky - 1][qx + kx - 1][c]      (A = 0 outside the 8 x 8 map)
+// Same products as before, grouped by weight position instead of activation position; same [wave][o * 9 + q] partial layout.
+#define ORI_HP 68        // floats per pixel of the LDS copy (64 channels + 4: consecutive pixels 4 banks apart)
+template <int TM, int NTHR>
+__device__ __forceinline__ void head_partials_ori_lds(const float* __restrict__ hw, const f32x4 (&bias)[1], const f32x4 (&acc)[TM][1],
+                                                      float* __restrict__ part, float* act, int wave, int lane, int tid) {
+    constexpr int MT = 4, MG = MT / TM;
+    const int mg = wave % MG, ng = wave / MG;
+    const int n = lane & 15, g = lane >> 4;
+    const int c4 = ng * 16 + 4 * g;
+    f32x4 v[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        v[i] = acc[i][0] + bias[0];
+        v[i].x = fmaxf(v[i].x, 0.0f); v[i].y = fmaxf(v[i].y, 0.0f); v[i].z = fmaxf(v[i].z, 0.0f); v[i].w = fmaxf(v[i].w, 0.0f);
+    }
+    const __amdgpu_buffer_rsrc_t r = weight_rsrc(hw, 2 * 4096);
+    f32x4 w[2][TM];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) w[o][i] = buf_read4(r, (n * 64 + c4) * 4, (o * 4096 + (mg * TM + i) * 16 * 64) * 4);
+    __syncthreads();                                                     // every wave has finished reading the conv5 input from `act`
+    for (int e = tid; e < 36 * 16; e += NTHR) {                          // zero halo of the 10 x 10 grid: 36 pixels x 16 float4
+        const int hp = e >> 4, q4 = e & 15;
+        const int y = hp < 10 ? 0 : (hp < 20 ? 9 : 1 + ((hp - 20) >> 1)), x = hp < 10 ? hp : (hp < 20 ? hp - 10 : ((hp - 20) & 1) * 9);
+        *reinterpret_cast<f32x4*>(&act[(y * 10 + x) * ORI_HP + 4 * q4]) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    int pbase[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int p = (mg * TM + i) * 16 + n;
+        pbase[i] = ((p >> 3) * 10 + (p & 7)) * ORI_HP + c4;             // (ky, kx) in padded coordinates of tap q = (0, 0)
+        *reinterpret_cast<f32x4*>(&act[pbase[i] + 11 * ORI_HP]) = v[i];  // interior pixel (py + 1, px + 1)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const f32x4 av = *reinterpret_cast<const f32x4*>(&act[pbase[i] + ((q / 3) * 10 + q % 3) * ORI_HP]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { s0 = fmaf(av[j], w[0][i][j], s0); s1 = fmaf(av[j], w[1][i][j], s1); }
+        }
+        s0 = wave_sum(s0);
+        s1 = wave_sum(s1);
+        if (lane == 0) { part[wave * 18 + q] = s0; part[wave * 18 + 9 + q] = s1; }
+    }
+}
+
 struct PyrSrc {            // pyramid sampling source (fused sampler)
     const float* lvl[AFFNET_MAX_OCTAVES][AFFNET_MAX_LEVELS];
     int h[AFFNET_MAX_OCTAVES], w[AFFNET_MAX_OCTAVES];
@@ -515,6 +571,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         conv0_half_split_q<NW, LQH, 1>(patch, w0, bias0, act, 0, wave, lane);
         s3_prefetch_w0<NW, CB, CB, 32, 4, 1>(a.packed + a.off.w_s3[1], wf1, wave, lane);
         __syncthreads();
+        CNN_STAMP(2);
         conv3x3_mfma_s3q<NW, CB, CB, LQH, 1, 4, 1>(act, a.packed + a.off.w_s3[1], wf1, acc_a, wave, lane, false);
         __syncthreads();
         if (tid < 6 * 32) {                                              // pass 0 left conv0 row 16 in the bottom halo row: zero again (3 terms x 2 groups x 32 cells)
@@ -525,6 +582,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         s3_prefetch_w0<NW, CB, CB, 32, 4, 1>(a.packed + a.off.w_s3[1], wf1, wave, lane);
         __syncthreads();
         conv3x3_mfma_s3q<NW, CB, CB, LQH, 1, 4, 1>(act, a.packed + a.off.w_s3[1], wf1, acc_b, wave, lane, false);
+        CNN_STAMP(3);
         f32x4 acc2_a[2][1], acc2_b[2][1], bias2[1];
         {
             int l2 = lane;
@@ -536,6 +594,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         store_tiles_split_q<CB, LQH2, 4, 1>(act, bias1, acc_a, wave, lane);
         s3_prefetch_w0<NW, CB, 2 * CB, 8, 2, 1>(a.packed + a.off.w_s3[2], wf2, wave, lane);
         __syncthreads();
+        CNN_STAMP(4);
         conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 2, 1>(act, a.packed + a.off.w_s3[2], wf2, acc2_a, wave, lane, false);
         __syncthreads();
         store_tiles_split_q<CB, LQH2, 4, 1>(act, bias1, acc_b, wave, lane);
@@ -547,6 +606,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         s3_prefetch_w0<NW, CB, 2 * CB, 8, 2, 1>(a.packed + a.off.w_s3[2], wf2, wave, lane);
         __syncthreads();
         conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 2, 1>(act, a.packed + a.off.w_s3[2], wf2, acc2_b, wave, lane, false);
+        CNN_STAMP(5);
         S3W<2> wf3, wf4;
         f32x4 bias3[2], bias4[2];
         __syncthreads();
@@ -556,36 +616,45 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         s3_prefetch_w0<NW, 2 * CB, 2 * CB, 16, 2, 2>(a.packed + a.off.w_s3[3], wf3, wave, lane);
         prefetch_bias_fresh<NW, 16, 2, 2>(a.packed + a.off.b[3], bias3, wave, lane);
         __syncthreads();
+        CNN_STAMP(6);
         {
             f32x4 acc_[2][2];                                            // conv3: 32 -> 32 @16x16
             conv3x3_mfma_s3q<NW, 2 * CB, 2 * CB, LQ2, 1, 2, 2>(act, a.packed + a.off.w_s3[3], wf3, acc_, wave, lane, false);
+            CNN_STAMP(7);
             __syncthreads();
             store_tiles_split_q<2 * CB, LQ2, 2, 2>(act, bias3, acc_, wave, lane);      // in place: the halo is still zero
             s3_prefetch_w0<NW, 2 * CB, 4 * CB, 4, 1, 2>(a.packed + a.off.w_s3[4], wf4, wave, lane);
             prefetch_bias_fresh<NW, 8, 1, 2>(a.packed + a.off.b[4], bias4, wave, lane);
             __syncthreads();
+            CNN_STAMP(8);
         }
         S3W<T4N> wf5;
         f32x4 bias5s[T4N];
         {
             f32x4 acc_[1][2];                                            // conv4: 32 -> 64, stride 2 -> 8x8
             conv3x3_mfma_s3q<NW, 2 * CB, 4 * CB, LQ2, 2, 1, 2>(act, a.packed + a.off.w_s3[4], wf4, acc_, wave, lane, false);
+            CNN_STAMP(9);
             __syncthreads();
             zero_halo_q<LQ4, NTHR>(act);
             store_tiles_split_q<4 * CB, LQ4, 1, 2>(act, bias4, acc_, wave, lane);
             s3_prefetch_w0<NW, 4 * CB, 4 * CB, 4, T4M, T4N>(a.packed + a.off.w_s3[5], wf5, wave, lane);
             prefetch_bias_fresh<NW, 8, T4M, T4N>(a.packed + a.off.b[5], bias5s, wave, lane);
             __syncthreads();
+            CNN_STAMP(10);
         }
         {
             f32x4 acc5[T4M][T4N];                                        // conv5: 64 -> 64 @8x8 in the exact path's tiling (the heads read it)
             conv3x3_mfma_s3q<NW, 4 * CB, 4 * CB, LQ4, 1, T4M, T4N>(act, a.packed + a.off.w_s3[5], wf5, acc5, wave, lane, false);
+            CNN_STAMP(11);
             if constexpr (KIND != AFFNET_NET_HARDNET) {
                 int lane_h = lane;                                       // opaque: 4 * (lane >> 4) is recomputed here, not carried (and spilled) from the kernel's top
                 asm volatile("" : "+v"(lane_h));
-                head_partials<KIND, T4M>(a.packed + a.off.head_w, bias5s, acc5,
-                                         a.out + pidx * (KIND == AFFNET_NET_AFFNET ? HEAD_PART_AFF : HEAD_PART_ORI), wave, lane_h);
+                if constexpr (KIND == AFFNET_NET_ORINET)
+                    head_partials_ori_lds<T4M, NTHR>(a.packed + a.off.head_w, bias5s, acc5, a.out + pidx * HEAD_PART_ORI, act, wave, lane_h, tid);
+                else
+                    head_partials<KIND, T4M>(a.packed + a.off.head_w, bias5s, acc5, a.out + pidx * HEAD_PART_AFF, wave, lane_h);
             }
+            CNN_STAMP(13);
         }
         return;
     }
@@ -681,7 +750,9 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         if (!STAMPS || a.dbg_layer < 0) {
             if constexpr (KIND == AFFNET_NET_HARDNET)   // conv5 tensor -> HBM as [pixel][channel]; the head GEMM runs over all patches
                 store_tiles_global<4 * CB, T4M, T4N>(a.out + pidx * (64 * 4 * CB), bias5, acc, wave, lane);
-            else                                        // per-wave partial sums of the head's dot products
+            else if constexpr (KIND == AFFNET_NET_ORINET)   // per-wave partial sums of the head's dot products: weights once, shifted activations from LDS
+                head_partials_ori_lds<T4M, NTHR>(a.packed + a.off.head_w, bias5, acc, a.out + pidx * HEAD_PART_ORI, act, wave, lane, tid);
+            else
                 head_partials<KIND, T4M>(a.packed + a.off.head_w, bias5, acc,
                                          a.out + pidx * (KIND == AFFNET_NET_AFFNET ? HEAD_PART_AFF : HEAD_PART_ORI), wave, lane);
             CNN_STAMP(13);
@@ -1037,8 +1108,12 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
     a.s3_alt = ctx->split3_alt ? 1 : 0;
     const bool split = ctx->arith == AFFNET_ARITH_FP32_SPLIT3;
     const bool s3 = split && !a.dbg_time && dbg_layer < 0;             // conv1 .. conv5 on split operands (affnet_set_arith)
-    if (split && a.dbg_time && dbg_layer < 0 && kind == AFFNET_NET_HARDNET)      // phase stamps of the split-operand HardNet (tuning aid)
+    if (split && a.dbg_time && dbg_layer < 0 && kind == AFFNET_NET_HARDNET)      // phase stamps of the split-operand trunks (tuning aid)
         hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_HARDNET, 8, true, true>), grid, dim3(512), 0, st, a, ps);
+    else if (split && a.dbg_time && dbg_layer < 0 && kind == AFFNET_NET_AFFNET)
+        hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_AFFNET, 8, true, true>), grid, dim3(512), 0, st, a, ps);
+    else if (split && a.dbg_time && dbg_layer < 0 && kind == AFFNET_NET_ORINET)
+        hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_ORINET, 8, true, true>), grid, dim3(512), 0, st, a, ps);
     else if (s3 && kind == AFFNET_NET_AFFNET) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_AFFNET, 8, false, true>), grid, dim3(512), 0, st, a, ps);
     else if (s3 && kind == AFFNET_NET_ORINET) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_ORINET, 8, false, true>), grid, dim3(512), 0, st, a, ps);
     else if (s3) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_HARDNET, 8, false, true>), grid, dim3(512), 0, st, a, ps);

@@ -124,8 +124,10 @@ def test_no_product_kernel_spills_registers():
     import kernel_resources as kr
     ks = kr.all_kernels()
     assert len(ks) > 100, "metadata of the built objects not found (run __graft_entry__.build())"
+    # (the STAMPS = true instantiations of the trunk kernel - third template argument - exist only for tools/*_phase_timing.py)
+    tooling = re.compile(r"cnn32_trunk_kernelILi\dELi8ELb1E|probe_kernel|split3_rate|split3_gemm|debug_stream")
     bad = {k["name"]: (k.get("vgpr_spill_count", 0), k.get("sgpr_spill_count", 0), k.get("private_segment_fixed_size", 0)) for k in ks.values()
-           if k.get("vgpr_spill_count", 0) or k.get("private_segment_fixed_size", 0)}
+           if (k.get("vgpr_spill_count", 0) or k.get("private_segment_fixed_size", 0)) and not tooling.search(k["name"])}
     assert not bad, bad
     h5 = [k for k in ks.values() if "hessian_nms_kernelILi5E" in k["name"]][0]
     assert h5["group_segment_fixed_size"] == 52520 and kr.workgroups_per_cu(h5) == 3, h5      # three workgroups per CU by LDS AND by registers
