@@ -164,7 +164,8 @@ class OnePassSIR(nn.Module):
         """x (1,1,H,W) -> dict(LAFs px (N,2,3), responses (N,), ids (N,3) = (octave, level - 1, pixel), descriptors (N,128) | None)."""
         if x.size(0) != 1:
             raise ValueError("run() / forward() are batch-size-1 like the reference; use enqueue() for batches")
-        if do_ori and not isinstance(self.OriNet, (_HipPatchNet, _HipHandCrafted)):
+        staged = do_ori and not isinstance(self.OriNet, (_HipPatchNet, _HipHandCrafted))
+        if staged:
             r = self._staged_orientation(x, desc)
         else:
             r = self.enqueue(x, do_ori=do_ori, desc=desc)
@@ -173,8 +174,8 @@ class OnePassSIR(nn.Module):
         self.sigmas = [list(s) for s in ctx.plan.sigmas]
         self.pix_dists = [list(p) for p in ctx.plan.pix_dists]
         self.aff_maps = ctx.affmap_views()
-        ctx.read_counts()               # raises on capacity overflow / "no keypoints detected"
-        n = int(r["count"].item())
+        counts = ctx.read_counts()      # raises on capacity overflow / "no keypoints detected"; [1] = rows of the (single) image after the fused describe call
+        n = int(r["count"].item()) if staged else int(counts[1])
         self.last_ids = r["ids"][0, :n]
         dsc = r["descriptors"]
         return {"LAFs": r["LAFs"][0, :n], "responses": r["responses"][0, :n], "ids": r["ids"][0, :n],

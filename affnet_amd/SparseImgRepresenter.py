@@ -201,9 +201,9 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
         r = self.enqueue(x, do_ori=do_ori, desc=desc)
         ctx = self._ctx
         self._publish_pyramid(ctx)
-        ctx.read_counts()                   # the one host read-back: raises on capacity overflow and (AffnetEmptyError,
-                                            # "no keypoints detected") on an image without detections, like the reference
-        n = int(r["count"].item())
+        # the one host read-back: raises on capacity overflow and (AffnetEmptyError, "no keypoints detected") on an image without
+        # detections, like the reference; its second entry is the row count of the (single) image - no second synchronising .item()
+        n = int(ctx.read_counts()[1])
         self.last_ids = r["ids"][:n]
         dsc = r["descriptors"]
         return {"LAFs": r["LAFs"][:n], "responses": r["responses"][:n], "ids": r["ids"][:n],
@@ -334,6 +334,7 @@ class CapturedPath(object):
         self._mods = [m for m in (det.AffNet, det.OriNet if do_ori else None, desc) if m is not None and hasattr(m, "packed_weights")]
         self._blobs = [m.packed_weights(dev) for m in self._mods]
         self._stamps = [m._weights_stamp() for m in self._mods]
+        self._arith = ctx.arith                                # the graph bakes in the kernels of this arithmetic mode
         self._stream = torch.cuda.Stream(device=dev)           # capture needs an explicit stream; nothing executes on it
         torch.cuda.synchronize(dev)
         o = self.out
@@ -341,13 +342,18 @@ class CapturedPath(object):
                                                ptr(o["ids"]), ptr(o["descriptors"]), ptr(o["count"]), C.c_void_p(self._stream.cuda_stream)),
               ctx.handle, "affnet_graph_capture_extract")
 
-    def launch(self, x=None):
+    def launch(self, x=None, check_weights=True):
         """One graph launch on the current stream; no host synchronisation.  x (same shape as at capture) is copied into `.image` first.
         (The captured path contains only kernels of this library - its fills and copies are kernels too: hipMemsetAsync nodes of a
-        captured graph share blit state with eager null-stream memsets on ROCm 7.2 and faulted on replay.)"""
-        for m, stamp in zip(self._mods, self._stamps):
-            if m._weights_stamp() != stamp:
-                raise RuntimeError("the weights of %s changed after capture(): the graph holds the old packed weights - capture again" % type(m).__name__)
+        captured graph share blit state with eager null-stream memsets on ROCm 7.2 and faulted on replay.)
+        check_weights: compare the nets' parameter stamps with the ones at capture (walks every parameter and buffer of up to three nets:
+        ~50 us of Python per replay) and refuse to replay stale weights; latency-critical loops whose weights are frozen pass False."""
+        if check_weights:
+            for m, stamp in zip(self._mods, self._stamps):
+                if m._weights_stamp() != stamp:
+                    raise RuntimeError("the weights of %s changed after capture(): the graph holds the old packed weights - capture again" % type(m).__name__)
+        if self.ctx.arith != self._arith:
+            raise RuntimeError("the arithmetic mode of the extractor changed after capture(): the graph runs the mode it was captured with - capture again")
         if x is not None:
             self.image.copy_(x, non_blocking=True)
         busy = getattr(self.det, "_busy", None)
@@ -359,14 +365,13 @@ class CapturedPath(object):
             return {k: (v[0] if (v is not None and k not in ("count", "overflow", "_img")) else v) for k, v in out.items()}
         return out
 
-    def run(self, x=None):
+    def run(self, x=None, check_weights=True):
         """launch() + the one count read-back: dict(LAFs px (N,2,3), responses, ids, descriptors) of a single image."""
         if self.image.size(0) != 1:
             raise ValueError("run() is for single images; use launch() for batches")
-        r = self.launch(x)
+        r = self.launch(x, check_weights=check_weights)
         self.det._publish_pyramid(self.ctx)
-        self.ctx.read_counts()
-        n = int(r["count"].item())
+        n = int(self.ctx.read_counts()[1])
         dsc = r["descriptors"]
         return {"LAFs": r["LAFs"][:n], "responses": r["responses"][:n], "ids": r["ids"][:n], "descriptors": None if dsc is None else dsc[:n]}
 

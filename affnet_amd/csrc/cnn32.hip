@@ -451,7 +451,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
     // The first weight fragments of a loop are requested before the barriers / epilogue in front of it.
     // HardNet (one workgroup per CU): optionally (affnet_debug_split3_variant bit 0) the two waves of a SIMD take turns at the higher priority
     // inside the loops.  Round 3's tile-major loops gained 2.5 % from it; with the term-major loops it costs 1 % (default off).
-    const bool s3_alt = a.s3_alt != 0 && KIND == AFFNET_NET_HARDNET;
+    const bool s3_alt = (a.s3_alt & 1) != 0 && KIND == AFFNET_NET_HARDNET;
     if constexpr (S3 && KIND == AFFNET_NET_HARDNET) {
         typedef LayQ<16, 16, 18, 2 * CB> LQ2;                            // conv2 / conv3 outputs: 64 channels @16x16 (122 KB)
         typedef LayQ<8, 8, 16, 4 * CB, 128> LQ4;                         // conv4 output: 128 channels @8x8, row pitch 768 B (122 KB)
@@ -563,6 +563,9 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         static_assert(LQH::BYTES <= TrunkLds<CB>::ACT * 4 && LQH2::BYTES <= TrunkLds<CB>::ACT * 4 && LQ2::BYTES <= TrunkLds<CB>::ACT * 4 && LQ4::BYTES <= TrunkLds<CB>::ACT * 4,
                       "pre-split layouts must fit the activation buffer");
         char* base = reinterpret_cast<char*>(act);
+        // (tried in round 4: the phases outside the MFMA loops at a higher issue priority than the loops - with two workgroups per CU a young
+        // workgroup crawls through input / conv0 / epilogues next to an older one in its loops, conv0 of half a patch takes 9 - 10 k cycles for
+        // ~150 instructions per wave.  Zero-sum as in the exact path: 4.12 vs 4.10 - 4.13 ms per 48000 patches.  Removed.)
         f32x4 acc_a[4][1], acc_b[4][1];
         // (128 VGPRs at two workgroups per CU: a loop's first weight fragments are requested right in front of it here - held across the
         // previous epilogue like in the HardNet branch they cost 17 / 23 spilled registers)
@@ -1105,7 +1108,7 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
     // small-tile loops reach 85-90 % of the pipe rate with two waves per SIMD; 16-wave HardNet workgroups - slower too.)
 #define TRUNK_LAUNCH(K) do { if (a.dbg_time || dbg_layer >= 0) hipLaunchKernelGGL((cnn32_trunk_kernel<K, 8, true>), grid, dim3(512), 0, st, a, ps); \
                              else hipLaunchKernelGGL((cnn32_trunk_kernel<K, 8, false>), grid, dim3(512), 0, st, a, ps); } while (0)
-    a.s3_alt = ctx->split3_alt ? 1 : 0;
+    a.s3_alt = ctx->split3_variant;
     const bool split = ctx->arith == AFFNET_ARITH_FP32_SPLIT3;
     const bool s3 = split && !a.dbg_time && dbg_layer < 0;             // conv1 .. conv5 on split operands (affnet_set_arith)
     if (split && a.dbg_time && dbg_layer < 0 && kind == AFFNET_NET_HARDNET)      // phase stamps of the split-operand trunks (tuning aid)
@@ -1206,7 +1209,7 @@ int aff_hardnet_forward_pyr_marked(affnet_ctx* ctx, const float* packed, const f
 
 extern "C" int affnet_debug_split3_variant(affnet_ctx* ctx, int bits) {
     if (!ctx) return AFFNET_ERR_INVALID;
-    ctx->split3_alt = (bits & 1) != 0;      // bit 0: split-operand HardNet loops WITH alternating wave priorities (A/B aid; default off since round 4)
+    ctx->split3_variant = bits;             // bit 0: HardNet loops with alternating wave priorities (A/B aid; default off since round 4)
     return AFFNET_OK;
 }
 

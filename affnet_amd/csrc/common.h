@@ -106,8 +106,8 @@ struct affnet_ctx {
     // tuning aid (include/affnet_hip_debug.h): s_memtime stamp buffer of THIS context's CNN launches, or NULL
     unsigned long long* dbg_time = nullptr;
     int arith = AFFNET_ARITH_FP32_MFMA;   // arithmetic of the CNN contractions (cfg.arith / affnet_set_arith): exact fp32 MFMA or fp32 = 3 x bf16 split operands
-    bool split3_alt = false;           // tuning aid: alternating wave priorities in the split HardNet loops (affnet_debug_split3_variant bit 0 sets it).
-                                       // Round 3's tile-major loops gained 2.5 % from it, the term-major loops of round 4 lose 1 % (15.10 vs 15.26 ms per 48000 patches)
+    int split3_variant = 0;            // tuning aid (affnet_debug_split3_variant): bit 0 = alternating wave priorities in the split HardNet loops (round 3's
+                                       // tile-major loops gained 2.5 % from it, the term-major loops of round 4 lose 1 %: off)
     // the whole path captured as one HIP graph (affnet_graph_capture_extract): one launch instead of ~45 for latency-bound callers
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;

@@ -22,31 +22,17 @@ sed "s#gpurun_out/fetch_calibration.json#profiles/${T}_fetch_calibration.json#" 
 grep -E "passed|failed" gpurun_out/pytest_gpu.log | tail -n 1 > profiles/${T}_pytest_gpu_summary.txt
 grep -E "^(PASSED|FAILED)" gpurun_out/pytest_gpu.log >> profiles/${T}_pytest_gpu_summary.txt
 tail -n 1 gpurun_out/smoke.log >> profiles/${T}_pytest_gpu_summary.txt
-python tools/roofline_table.py profiles/${T} > profiles/${T}_roofline_table.md
-if [ -f gpurun_out/traffic_sampler.json ]; then
-  python - "$T" <<'PY'
-import csv, json, sys
-t = sys.argv[1]
-tr = json.load(open("gpurun_out/traffic_sampler.json"))["kernels"]
-rows = {r["Name"].split("(")[0]: r for r in csv.DictReader(open("gpurun_out/prof_sampler/run_kernel_stats.csv"))}
-out = {"what": "stand-alone grid_sample_kernel (bench.py secondary_rooflines section: 3000 + 2 x 2000 patches per image, 32 images per launch): "
-               "rocprofv3 mean duration and calibrated FETCH_SIZE / WRITE_SIZE per launch", "launches": []}
-for k, v in tr.items():
-    if "grid_sample_kernel" in k and k in rows:
-        ns = float(rows[k]["AverageNs"])
-        out["launches"].append({"kernel": k, "calls": int(rows[k]["Calls"]), "mean_us": ns / 1e3, "hbm_bytes_per_launch": v["hbm_bytes"],
-                                "fetch_bytes": v["fetch_bytes"], "write_bytes": v["write_bytes"], "calibration": v["calibration"],
-                                "pmc_GBs": v["hbm_bytes"] / ns, "frac_of_8TBs": v["hbm_bytes"] / ns / 8000.0})
-json.dump(out, open("profiles/%s_sampler_traffic.json" % t, "w"), indent=1)
-print(json.dumps(out["launches"], indent=1)[:600])
-PY
-fi
-# EXPLORATORY split-operand path
+# arith fp32_split3 (the other arithmetic mode of the boundary): its own bench lines, kernel stats, PMC summary, timings
 grep '^{' gpurun_out/bench_split3.log > profiles/${T}_split3_bench.json
-grep '^{' gpurun_out/bench_config2_split3.log > profiles/${T}_split3_bench_config2_latency.json
+for C in config2 config5 onepass; do [ -f gpurun_out/bench_${C}_split3.log ] && grep '^{' gpurun_out/bench_${C}_split3.log > profiles/${T}_split3_bench_${C}.json; done
 cp gpurun_out/prof_split3/run_kernel_stats.csv profiles/${T}_split3_kernel_stats.csv
 (cat gpurun_out/split3_phase_timing.txt; echo; cat gpurun_out/split3_net_timing.txt) | grep -v amdgpu.ids > profiles/${T}_split3_phase_and_net_timing.txt
 [ -f gpurun_out/pmc_split3_summary.txt ] && cp gpurun_out/pmc_split3_summary.txt profiles/${T}_split3_pmc_summary.txt
-cp gpurun_out/mfma_valu_overlap.txt profiles/${T}_mfma_valu_overlap_probe.txt
+[ -f gpurun_out/s3_loop_probe.txt ] && cp gpurun_out/s3_loop_probe.txt profiles/${T}_s3_loop_probe.txt
 grep -v "^ *value" gpurun_out/clock_watch.txt > profiles/${T}_clock_power_exact_vs_split3.txt; grep "value" gpurun_out/clock_watch.txt >> profiles/${T}_clock_power_exact_vs_split3.txt
+# BASELINE configs[4] counters
+[ -f gpurun_out/config5_traffic.json ] && sed "s#gpurun_out/fetch_calibration.json#profiles/${T}_fetch_calibration.json#" gpurun_out/config5_traffic.json > profiles/${T}_config5_traffic.json
+[ -f gpurun_out/pmc_config5_summary.txt ] && cp gpurun_out/pmc_config5_summary.txt profiles/${T}_config5_pmc_summary.txt
+python tools/kernel_resources.py > profiles/${T}_kernel_resources.md
+python tools/roofline_table.py profiles/${T} > profiles/${T}_roofline_table.md
 ls -la profiles/${T}_*

@@ -14,9 +14,9 @@ O = affnet_amd.OriNetFast(PS=32); O.load_state_dict(torch.load(os.path.join(ROOT
 H = affnet_amd.HardNet(); H.load_state_dict(affnet_amd.synthetic_hardnet_state(0)); H.to(dev)
 big = (torch.rand(48000, 1, 32, 32) * 255).to(dev)
 ctx = engine.utility_ctx(dev)        # the nets' stand-alone calls (arith "fp32") run on this context: switch IT for the A/B
-for split in (0, 1, 3, 1, 3):          # 0 exact, 1 split operands, 3 split WITH alternating wave priorities in the HardNet loops (A/B)
+for split in (0, 1, 3, 1, 3):          # 0 exact, 1 split operands, 3 split with the variant bits of AFFNET_S3_VARIANT (default 1: alternating wave priorities in the HardNet loops)
     lib.affnet_set_arith(ctx, 1 if split else 0)
-    lib.affnet_debug_split3_variant(ctx, 1 if split == 3 else 0)
+    lib.affnet_debug_split3_variant(ctx, int(os.environ.get("AFFNET_S3_VARIANT", "1")) if split == 3 else 0)
     row = []
     for nm, net in (("AffNet", A), ("OriNet", O), ("HardNet", H)):
         net(big); torch.cuda.synchronize()
@@ -26,5 +26,5 @@ for split in (0, 1, 3, 1, 3):          # 0 exact, 1 split operands, 3 split WITH
             e0.record(); net(big); e1.record(); torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1))
         row.append("%s %.3f ms" % (nm, best))
-    print({0: "exact        ", 1: "split3       ", 3: "split3 alt-pr"}[split], " | ".join(row))
+    print({0: "exact        ", 1: "split3       ", 3: "split3 variant"}[split], " | ".join(row))
 lib.affnet_set_arith(ctx, 0); lib.affnet_debug_split3_variant(ctx, 0)
