@@ -25,12 +25,17 @@ TARGET = "hipv4-amdgcn-amd-amdhsa--gfx950"
 
 
 def demangle(names):
-    try:
-        out = subprocess.run([os.path.join(LLVM, "llvm-cxxfilt")] + list(names), capture_output=True, text=True, check=True).stdout
-        out = out.strip().split("\n")
-        return out if len(out) == len(names) else list(names)
-    except Exception:
-        return list(names)
+    if not names:                 # (with no operands the demanglers would wait on stdin)
+        return []
+    for tool in ("/usr/bin/c++filt", os.path.join(LLVM, "llvm-cxxfilt")):
+        try:
+            out = subprocess.run([tool] + list(names), capture_output=True, text=True, check=True, stdin=subprocess.DEVNULL,
+                                 timeout=60).stdout.strip().split("\n")
+            if len(out) == len(names):
+                return out
+        except Exception:
+            pass
+    return list(names)
 
 
 def object_kernels(obj):
@@ -97,10 +102,45 @@ def workgroups_per_cu(k):
     return max(0, min(by_lds, by_regs, 32))
 
 
+# the kernels DESIGN.md section 4 quotes figures for (substring of the demangled name -> label)
+DESIGN_KERNELS = [
+    ("cnn32_trunk_kernel<2, 8, false, false>", "HardNet trunk, exact fp32 MFMA"),
+    ("cnn32_trunk_kernel<2, 8, false, true>", "HardNet trunk, arith fp32_split3"),
+    ("cnn32_trunk_kernel<0, 8, false, false>", "AffNet trunk, exact fp32 MFMA"),
+    ("cnn32_trunk_kernel<0, 8, false, true>", "AffNet trunk, arith fp32_split3"),
+    ("cnn32_trunk_kernel<1, 8, false, false>", "OriNet trunk, exact fp32 MFMA"),
+    ("cnn32_trunk_kernel<1, 8, false, true>", "OriNet trunk, arith fp32_split3"),
+    ("hardnet_head_kernel<64>", "HardNet head GEMM (64-patch tiles), exact"),
+    ("hardnet_head_s3_kernel<64>", "HardNet head GEMM (64-patch tiles), arith fp32_split3"),
+    ("hessian_nms_kernel<5>", "Hessian + 3-D NMS + centroid, 5 levels per octave"),
+    ("blur2d_kernel<13, 4>", "Gaussian blur 13 x 13, 64 x 64 tiles"),
+    ("blur2d_pair_kernel<15, 9, 4>", "paired blur 15 x 15 / 9 x 9"),
+    ("dense_conv_kernel<32, 32, 1", "dense AffNetFastFullConv conv3, exact"),
+    ("dense_conv_s3_kernel<32, 32, 1", "dense AffNetFastFullConv conv3, arith fp32_split3"),
+]
+
+
+def design_table(ks=None):
+    ks = ks or all_kernels()
+    lines = ["| kernel | role | VGPR | LDS bytes | scratch bytes | VGPR spills | workgroups / CU |", "|---|---|---|---|---|---|---|"]
+    for pat, label in DESIGN_KERNELS:
+        hit = [k for k in ks.values() if pat in k["demangled"]]
+        if not hit:
+            lines.append("| `%s` | %s | (not built) | | | | |" % (pat, label))
+            continue
+        k = hit[0]
+        lines.append("| `%s` | %s | %d | %d | %d | %d | %d |" % (k["demangled"], label, k.get("vgpr_count", 0) + k.get("agpr_count", 0), k.get("group_segment_fixed_size", 0),
+                                                             k.get("private_segment_fixed_size", 0), k.get("vgpr_spill_count", 0), workgroups_per_cu(k)))
+    return "\n".join(lines)
+
+
 def main():
     ks = all_kernels()
     if "--json" in sys.argv:
         print(json.dumps(ks, indent=1, sort_keys=True))
+        return
+    if "--design" in sys.argv:
+        print(design_table(ks))
         return
     print("| kernel | object | VGPR (+AGPR) | SGPR | LDS bytes | scratch bytes | VGPR spills | workgroups / CU (LDS, registers) |")
     print("|---|---|---|---|---|---|---|---|")
