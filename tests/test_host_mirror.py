@@ -135,6 +135,20 @@ def test_no_product_kernel_spills_registers():
     assert trunk["group_segment_fixed_size"] <= 160 * 1024 and kr.workgroups_per_cu(trunk) == 1
 
 
+def test_design_kernel_figures_match_the_built_objects():
+    """DESIGN.md section 4 quotes VGPR / LDS / scratch / occupancy figures per kernel; the table between the `kernel-resources` markers is the output
+    of tools/kernel_resources.py --design.  Round 3's DESIGN said "no scratch" for a kernel that shipped with 5 spilled registers: the
+    document and the built objects must not drift apart again."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources as kr
+    doc = open(os.path.join(ROOT, "DESIGN.md")).read()
+    m = re.search(r"<!-- kernel-resources:begin -->\n(.*?)\n<!-- kernel-resources:end -->", doc, flags=re.S)
+    assert m, "DESIGN.md lost its generated kernel-resources table"
+    want = kr.design_table()
+    assert "(not built)" not in want, want
+    assert m.group(1).strip() == want.strip(), "DESIGN.md section 4 differs from the built objects - regenerate with tools/kernel_resources.py --design:\n" + want
+
+
 def _unpack_trunk(kind, blob):
     """Rebuilds conv weights / biases from the packed blob (the layout cnn32.hip documents)."""
     cb = 32 if kind == 2 else 16
