@@ -116,7 +116,7 @@ def cpu_baseline(n_timed=3, n_keep=2, node=True):
     default_threads = torch.get_num_threads()
     # never more threads than physical cores: measured on the 128-core / 256-thread GPU box, one 1024x768 image takes 1.9 s on 8
     # threads, 3.5 s on 64, 7.2 s on 128 and 298 s (!) on 256 - the small convolutions of this path drown in OpenMP overhead
-    cand = sorted({t for t in (8, 16, 32) if 1 <= t <= phys} | ({phys} if phys < 8 else set()))
+    cand = sorted({t for t in (8, 16) if 1 <= t <= phys} | ({phys} if phys < 8 else set()))      # 32 threads never won on the 128-core boxes (1.46 - 1.5 s vs 1.5 s at 16)
     one(0)                                              # warm-up (allocator, oneDNN primitive caches)
     sweep = {}
     for t in cand:

@@ -441,6 +441,47 @@ def test_foreign_affnet_with_several_baumberg_iterations(amd, nets):
     assert not torch.equal(one(x, do_ori=True)[0], L1), "the iterations must change the frames"
 
 
+def test_shape_filter_select_on_caller_supplied_unsorted_rows(amd, nets):
+    """the public stage entry affnet_shape_filter_select promises the N largest responses among the rows that pass the shape
+    filter for ANY caller-supplied rows.  Its selection kernel has a shortcut for response-sorted rows that used to be taken on the strength
+    of a flag the context's LAST detector call left behind: shuffled rows handed to the entry after a sorted detection silently got the
+    first N good rows instead of the N best.  The kernel now verifies the order itself.  Reference: SparseImgRepresenter.py:147-156
+    (topk of response * good)."""
+    import ctypes as C
+    from affnet_amd._lib import lib, ptr, check
+    from affnet_amd import engine
+    A, O, H = nets
+    x = orc.synthetic_image(240, 320, 1).to(DEV)
+    det = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=1, AffNet=A, OriNet=O).to(DEV)
+    det.run(x, do_ori=False)                                 # leaves the context in "sorted detections" mode (450 candidates > C)
+    ctx = det._ctx
+    P, F = ctx.cap_pre, ctx.cap_final
+    st = engine.stream_of(torch.device(DEV))
+    resp = torch.empty(P, device=DEV); lafs = torch.empty(P, 2, 3, device=DEV); ids = torch.empty(P, 3, dtype=torch.int32, device=DEV)
+    cnt = torch.zeros(1, dtype=torch.int32, device=DEV)
+    check(lib.affnet_detected_list(ctx.handle, ptr(resp), ptr(lafs), ptr(ids), ptr(cnt), st), ctx.handle, "detected_list")
+    n = int(cnt.item())
+    assert n == P == 450
+    Amat = torch.eye(2, device=DEV).repeat(P, 1, 1).contiguous()          # identity shapes: the eigen-ratio test passes, the boundary test decides
+
+    def select(r, l, i):
+        r2 = torch.empty(F, device=DEV); l2 = torch.empty(F, 2, 3, device=DEV); i2 = torch.empty(F, 3, dtype=torch.int32, device=DEV)
+        c2 = torch.zeros(1, dtype=torch.int32, device=DEV)
+        check(lib.affnet_shape_filter_select(ctx.handle, ptr(r), ptr(l), ptr(i), ptr(Amat), ptr(cnt), ptr(r2), ptr(l2), ptr(i2), ptr(c2), st), ctx.handle,
+              "shape_filter_select")
+        k = int(c2.item())
+        return r2[:k].clone(), l2[:k].clone(), i2[:k].clone()
+
+    rs, ls, is_ = select(resp, lafs, ids)                    # sorted rows: the shortcut applies
+    assert rs.numel() == F == 300 and bool((rs[:-1] >= rs[1:]).all())
+    g = torch.Generator().manual_seed(11)
+    perm = torch.randperm(n, generator=g).to(DEV)
+    ru, lu, iu = select(resp[perm].contiguous(), lafs[perm].contiguous(), ids[perm].contiguous())
+    # the same SET of rows in the same (descending response) order, whatever order the caller supplied them in
+    assert torch.equal(ru, rs), "shuffled input rows: the selection is not the N largest responses"
+    assert torch.equal(iu, is_) and torch.equal(lu, ls)
+
+
 def test_two_stream_pipelining_gives_identical_results(amd, nets):
     """bench.py's throughput mode: detector on a second stream, two contexts alternating over an image stream."""
     A, O, H = nets
