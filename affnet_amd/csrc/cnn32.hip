@@ -278,7 +278,7 @@ struct CnnArgs {
     int n_max;
     float* out;            // AffNet/OriNet: (n,2,2); HardNet: trunk output (n,8192)
     int dbg_layer;         // >= 0: dump activations after this trunk layer of patch 0 and exit
-    int s3_alt;            // EXPLORATORY split path: the two waves of a SIMD alternate at the higher priority inside the MFMA loops
+    int s3_alt;            // tuning variant bits of the split-operand trunks (affnet_debug_split3_variant): bit 0 = the two waves of a SIMD alternate at the higher priority inside the HardNet loops
     float* dbg_out;
     unsigned long long* dbg_time;   // != NULL: s_memtime stamps [patch][wave][32] at the phase boundaries (tuning aid)
     // Row window [row_begin, row_begin + gridDim.x) of every image, and the lazy-evaluation predicate of the fused pipeline: when

@@ -44,7 +44,7 @@ H, W, NKP, BATCH = 768, 1024, 2000, 64
 FLOP_AFF, FLOP_ORI, FLOP_HARD = 19193856.0, 19316736.0, 78184448.0
 FLOP_HARD_HEAD = 2.0 * 8192 * 128
 PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
-PEAK_BF16_MFMA_TFLOPS = 16 * 157.3  # MI355X_MICROARCH.md: bf16 MFMA = 16x the fp32 matrix rate (~2.5 PF dense); EXPLORATORY --split3 line only
+PEAK_BF16_MFMA_TFLOPS = 16 * 157.3  # MI355X_MICROARCH.md: bf16 MFMA = 16x the fp32 matrix rate (~2.5 PF dense); rooflines of the fp32_split3 lines
 PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; ~6.3 TB/s achievable)
 GRAF = os.path.join(ROOT, "tests", "golden", "graf_img1.png")
 DTYPE_SPLIT3 = ("f32 (AFFNET_ARITH_FP32_SPLIT3: every fp32 operand of the CNN contractions as three bf16 terms, six v_mfma_f32_16x16x32_bf16 per "

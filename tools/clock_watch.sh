@@ -1,5 +1,5 @@
 #!/bin/bash
-# Shader clock and socket power while the batched bench runs (exact fp32 path, then the exploratory split-operand path): is the
+# Shader clock and socket power while the batched bench runs (exact fp32 path, then the split-operand arithmetic mode): is the
 # split path power limited?  Samples rocm-smi every ~0.25 s in the background; prints the median / max over the samples taken while
 # the GPU was busy (> 50 % of the peak power seen).
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0

@@ -1,5 +1,5 @@
 #!/bin/bash
-# quick check of the split-operand trunks: tests of both arithmetic modes at small sizes, net / phase timings, short bench
+# Quick check of the split-operand trunks (EXTRA_K adds a pytest -k expression): tests of both arithmetic modes at small sizes, net / phase timings, short bench
 mkdir -p gpurun_out; export HSA_ENABLE_IPC_MODE_LEGACY=0 TMPDIR=/tmp
 export AFFNET_PARITY_REPORT=$PWD/gpurun_out/parity_report_c.json
 timeout 900 python -m pytest tests -q -m gpu -p no:cacheprovider -k "split3 or jit or synthetic_golden or graf_img1_golden or batched_launches or graph_replay or trunk_layer or cnn_outputs or ${EXTRA_K:-zzzz}" > gpurun_out/pytest_gpu_c.log 2>&1; echo "pytest exit: $?"; tail -n 3 gpurun_out/pytest_gpu_c.log | cut -c1-300

@@ -36,7 +36,7 @@ def main(prefix):
     aff_eval = bench.get("roofline", {}).get("affnet_patches_evaluated_per_image")
     if aff_eval:
         FLOP["cnn32_trunk_kernel<0"] = aff_eval * 19193856.0
-    # one HardNet trunk launch per 32-image call; a run that also took the EXPLORATORY split-operand steps (bench.py without --no-split3)
+    # one HardNet trunk launch per 32-image call; a run that also took the arith fp32_split3 steps (bench.py without --no-split3)
     # has them under their own template instantiation <2, 8, false, true> - every other kernel is shared by both kinds of step
     calls_per_batch = sum(v[0] for k, v in stats.items() if k.startswith("void cnn32_trunk_kernel<2, 8, false"))
     P0, P = H * W, octave_pixels(H, W)
@@ -59,7 +59,7 @@ def main(prefix):
         for key, fl in FLOP.items():
             if key in name and split:
                 tf = fl * IMGS / (per_call * avg_ns * 1e-9) / 1e12
-                algs = ("EXPLORATORY split operands: %.1f TFLOP/s fp32-equivalent; executed bf16 products (6 per fp32 product) %.0f TFLOP/s = %.1f %% of "
+                algs = ("arith fp32_split3: %.1f TFLOP/s fp32-equivalent; executed bf16 products (6 per fp32 product) %.0f TFLOP/s = %.1f %% of "
                         "the 2517 bf16 MFMA peak" % (tf, 6 * tf, 100 * 6 * tf / 2516.8))
             elif key in name:
                 tf = fl * IMGS / (per_call * avg_ns * 1e-9) / 1e12            # all launches of the kernel in one 32-image call

@@ -17,7 +17,7 @@ from affnet_amd._lib import lib, ptr  # noqa: E402
 def main():
     dev = torch.device("cuda", 0)
     g = torch.Generator().manual_seed(0)
-    out = {"what": "exploratory: fp32 = 3 x bf16 split operands on v_mfma_f32_16x16x32_bf16 (not used by any product path)", "numerics": [], "rate": []}
+    out = {"what": "fp32 = 3 x bf16 split operands on v_mfma_f32_16x16x32_bf16: numerics and loop-rate probes (the product kernels of AFFNET_ARITH_FP32_SPLIT3 are the trunks)", "numerics": [], "rate": []}
     for name, K, sb in (("HardNet head GEMM, K = 8192", 8192, 0.02), ("3x3 conv over 128 channels, K = 1152", 1152, 0.05)):
         A = torch.clamp(torch.randn(256, K, generator=g), min=0).contiguous()
         Bt = (torch.randn(128, K, generator=g) * sb).contiguous()
