@@ -760,6 +760,10 @@ __device__ __forceinline__ void conv3x3_mfma_s3q(const float* act, const float* 
     };
     // one step: weights of step s_next requested first (spread between the first MFMAs), fragments of s_next as the terms retire
     const int wave_hi = __builtin_amdgcn_readfirstlane(wave >> 2);      // scalar: the priority switch below must not become a divergent branch
+    // (Tried in round 4, profiles/r04_s3_s3_loop_probe_fair_priorities.txt: "fair" priorities - the two waves of a SIMD publish the step they are in
+    // through LDS and the one that is AHEAD lowers its issue priority, so that the pair advances together instead of the older wave taking ~3/4 of the
+    // pipe and the younger one finishing alone.  Slower on every shape (conv3 87.9 % of the pipe floor vs 91.5 %, conv5 77.8 vs 87.0): the arbiter's
+    // oldest-first order wastes less than two waves that stall on the same things at the same time.  Removed.)
     auto step = [&](const S3W<TN>& wc, S3W<TN>& wn, int s_next, bool load_next) {
         if (alt_prio) {                       // the two waves of a SIMD (w, w + 4) take turns at the higher priority, one step each
             if ((s_next ^ wave_hi) & 1) __builtin_amdgcn_s_setprio(1);

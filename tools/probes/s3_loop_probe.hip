@@ -143,9 +143,9 @@ static void run(const float* dW, float* dout, unsigned long long* dcyc, int reps
     mean /= nb;
     const double flops = (double)blocks * reps * nwaves * mfma_per_wave * 2.0 * 16 * 16 * 32;
     const double tf = flops / (best * 1e-3) / 1e12;
-    static const char* vn[15] = {"old LayB tile-major", "NEW LayQ term-major", "NEW, no alt prio", "old, no alt prio", "NEW 4 waves (1/SIMD) A", "NEW 4 waves (1/SIMD) B",
+    static const char* vn[16] = {"old LayB tile-major", "NEW LayQ term-major", "NEW, no alt prio", "old, no alt prio", "NEW 4 waves (1/SIMD) A", "NEW 4 waves (1/SIMD) B",
                                 "4w A, no weight loads", "4w A, no frag reloads", "4w A, pure MFMA", "8w no w loads", "8w no frag reloads", "8w pure MFMA",
-                                "8w pace s_nop 0", "8w pace s_nop 2", "8w pace s_nop 5"};
+                                "8w pace s_nop 0", "8w pace s_nop 2", "8w pace s_nop 5", "(unused)"};
     printf("%-52s %-22s cycles/call %8.0f (max %8.0f) floor %7.0f -> %5.1f %% | launch %7.3f ms %7.1f TFLOP/s bf16 = %5.1f %% of 2516.8\n", S::name(), vn[VAR], mean, mx,
            floor_cyc, 100.0 * floor_cyc / mean, best, tf, 100.0 * tf / 2516.8);
 }
