@@ -952,7 +952,7 @@ def config5_traffic():
     d = json.load(open(files[-1]))
     ks = d.get("kernels", {})
     trunk = next((v for k, v in ks.items() if "cnn32_trunk_kernel<2, 8, false, false>" in k), None)
-    ss = {k.split("(")[0].replace("void ", "")[:60]: {"hbm_bytes_per_launch": v.get("hbm_bytes"), "launches": v.get("launches"), "avg_us": v.get("avg_us")}
+    ss = {k.split("(")[0].replace("void ", "")[:60]: {"hbm_bytes_per_launch": v.get("hbm_bytes"), "fetch_bytes": v.get("fetch_bytes"), "write_bytes": v.get("write_bytes")}
           for k, v in ks.items() if "blur2d" in k or "hessian_nms" in k}
     return {"trunk_hbm_bytes_per_launch": trunk.get("hbm_bytes") if trunk else None, "scale_space": ss,
             "source": "%s (%d images per launch; %s)" % (os.path.basename(files[-1]), d.get("images_per_launch", 0), d.get("correction", ""))}
