@@ -462,7 +462,9 @@ def test_shape_filter_select_on_caller_supplied_unsorted_rows(amd, nets):
     check(lib.affnet_detected_list(ctx.handle, ptr(resp), ptr(lafs), ptr(ids), ptr(cnt), st), ctx.handle, "detected_list")
     n = int(cnt.item())
     assert n == P == 450
-    Amat = torch.eye(2, device=DEV).repeat(P, 1, 1).contiguous()          # identity shapes: the eigen-ratio test passes, the boundary test decides
+    # a mildly anisotropic shape for every row (an isotropic frame has a zero discriminant in batch_eig2x2, Utils.py:168-175, and the
+    # reference's fallback then rejects it): the eigen-ratio test passes, the boundary test decides
+    Amat = torch.tensor([[1.2, 0.0], [0.1, 0.9]], device=DEV).repeat(P, 1, 1).contiguous()
 
     def select(r, l, i):
         r2 = torch.empty(F, device=DEV); l2 = torch.empty(F, 2, 3, device=DEV); i2 = torch.empty(F, 3, dtype=torch.int32, device=DEV)

@@ -13,7 +13,6 @@ cp gpurun_out/gap_table.md profiles/${T}_config2_gap_table.md
 cp gpurun_out/prof_c5/run_kernel_stats.csv profiles/${T}_config5_kernel_stats.csv
 tail -n 1 gpurun_out/bench_gpus2_refused.log > profiles/${T}_bench_gpus2_refused_on_1gpu_box.txt
 cp gpurun_out/prof/run_kernel_stats.csv profiles/${T}_kernel_stats.csv
-[ -f gpurun_out/prof_onepass/run_kernel_stats.csv ] && cp gpurun_out/prof_onepass/run_kernel_stats.csv profiles/${T}_onepass_kernel_stats.csv
 grep '^{' gpurun_out/bench_onepass.log > profiles/${T}_bench_onepass.json
 grep '^{' gpurun_out/bench_config5.log > profiles/${T}_bench_config5.json
 cp gpurun_out/fetch_calibration.json profiles/${T}_fetch_calibration.json
