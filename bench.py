@@ -38,6 +38,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+T_START = time.time()              # process start (after `import torch`): the JSON line carries the wall time of every section of the run
 
 H, W, NKP, BATCH = 768, 1024, 2000, 64
 # algorithmic work: 2*MAC per patch, dense, BN/ReLU/normalisation excluded
@@ -112,6 +113,7 @@ def cpu_baseline(n_timed=3, n_keep=2, node=True):
         return time.perf_counter() - t0, {"keys": ex.keys.numpy().copy(), "LAFs": L.numpy().copy(), "resp": r.numpy().copy(),
                                           "desc": D.numpy().copy(), "ori_norm": ex.ori_vec.norm(dim=1).numpy().copy()}
 
+    t_cpu0 = time.time()
     avail, phys = host_threads()
     default_threads = torch.get_num_threads()
     # never more threads than physical cores: measured on the 128-core / 256-thread GPU box, one 1024x768 image takes 1.9 s on 8
@@ -146,13 +148,16 @@ def cpu_baseline(n_timed=3, n_keep=2, node=True):
            "sample": "median of %d synthetic %dx%d images x %d kp (seeds 1..%d) after a thread-count sweep on seed 0 and 1 warm-up, "
                      "%.1f s of timed CPU work; oracle/affnet_oracle.py = the reference's torch-CPU operator sequence incl. its "
                      "discarded extra extraction (SparseImgRepresenter.py:178-179)" % (n_timed, W, H, NKP, n_timed, sum(times))}
+    rec["seconds_total_single_process"] = round(time.time() - t_cpu0, 1)
     if node:
+        t_node0 = time.time()
         try:
             # the whole host: cores/8 processes x 8 threads (the path's small convolutions stop scaling at 8-16 threads; round 3 measured
             # 16 x 8 ahead of 8 x 16 on the 128-core box: 2619 vs 1641 kp/s), one round after a warm-up image per process
             rec["node_throughput"] = cpu_node_throughput(phys, workers=max(1, min(16, phys // 8)), rounds=1)
         except Exception as e:                          # noqa: BLE001  (the single-process figure stands)
             rec["node_throughput"] = {"error": repr(e)[:300]}
+        rec["node_throughput"]["seconds_total"] = round(time.time() - t_node0, 1)
     return rec, kept
 
 
@@ -185,7 +190,7 @@ def cpu_node_throughput(phys, workers=8, rounds=2):
     rates = sorted(k / t for k, t in per_round)
     return {"value": rates[len(rates) // 2], "unit": "keypoints/s", "processes": workers, "threads_per_process": threads, "cores": workers * threads,
             "rounds_s": [round(t, 3) for _, t in per_round],
-            "sample": "%d processes x %d threads, one %dx%d image x %d kp each per round, %d rounds after a warm-up image per process, median" %
+            "sample": "%d processes x %d threads, one %dx%d image x %d kp each per round, %d round(s) after a small warm-up image (320x240) per process, median" %
                       (workers, threads, W, H, NKP, rounds)}
 
 
@@ -206,8 +211,12 @@ def cpu_worker(spec):
         L, r, P, D = orc.describe(imgs[seed], ex, hard, do_ori=True, ps=32)
         return int(L.shape[0])
 
-    imgs = {s: orc.synthetic_image(H, W, s) for s in range(seed0, seed0 + rounds + 1)}     # inputs resident before the timed rounds
-    one(seed0)
+    imgs = {s: orc.synthetic_image(H, W, s) for s in range(seed0 + 1, seed0 + rounds + 1)}     # inputs resident before the timed rounds
+    # warm-up on a SMALL image (thread pools, allocator, the oneDNN primitives of the 32 x 32 patch CNNs, which do not depend on the image
+    # size): a full-size warm-up image per process cost ~8 s of the run for a figure that is "never the target"
+    ex0 = orc.OracleExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=1, affnet_sd=sd["AffNet"], orinet_sd=sd["OriNet"],
+                              reproduce_wasted_extraction=True)
+    orc.describe(orc.synthetic_image(240, 320, seed0), ex0, hard, do_ori=True, ps=32)
     print("ready", flush=True)
     for k in range(rounds):
         if not sys.stdin.readline():
@@ -657,6 +666,7 @@ def run(args, world):
     ovf_dev.zero_()
     barrier()
     gpu_sections = []                  # wall-clock (unix seconds) start / end of every GPU section of this run: lets an outside sampler (rocm-smi) be lined up
+    wall = {"setup_and_warmup_s": round(time.time() - T_START, 1)}      # imports of this package, synthetic images, weights, contexts, warm-up steps
     w0 = time.time()
     t0 = time.perf_counter()
     last = None
@@ -845,15 +855,19 @@ def run(args, world):
         for d in dets.values():
             _lib.lib.affnet_profile_enable(d._ctx.handle, 0)
         # BASELINE configs[1] and configs[4] in the default line (short samples after the timed region; `--config2` / `--config5` are the full runs)
+        t_oc = time.time()
         if world == 1 and not ONEPASS and not args.config5 and not args.no_other_configs and args.batch == BATCH:
             try:
                 out["other_configs"] = other_configs((A, O, Hn), dev, args.arith, gpu_sections, with_cpu=not args.no_cpu_baseline)
             except Exception as e:                                   # noqa: BLE001
                 out["other_configs"] = {"error": repr(e)[:300]}
         out["gpu_sections_unix_s"] = gpu_sections
+        wall["other_configs_s"] = round(time.time() - t_oc, 1)          # incl. the one-image 4K CPU baseline
         if world == 1 and not args.no_cpu_baseline and not args.config5 and not ONEPASS:
+            t_cb = time.time()
             base, kept = cpu_baseline()
             out["cpu_baseline"] = base
+            wall["cpu_baseline_s"] = round(time.time() - t_cb, 1)
 
             def fetcher(results):
                 def fetch(seed):                                     # image `seed` of a step (rank 0, world 1: seed == index)
@@ -868,6 +882,8 @@ def run(args, world):
                 out["parity_check"] = parity_check(kept, fetcher(last))
                 if last_s3 is not None and "value" in out.get("arith_fp32_split3", {}):
                     out["arith_fp32_split3"]["parity_check"] = parity_check(kept, fetcher(last_s3))
+        wall["total_since_process_start_s"] = round(time.time() - T_START, 1)
+        out["wall_s"] = wall
         print(json.dumps(out), flush=True)
     if DIST:
         dist.destroy_process_group()
