@@ -461,7 +461,11 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         // conv0 + conv1 in two half-patch passes: the pre-split conv0 output of 32 channels @32x32 would be 222 KB, half of it (16 rows +
         // a halo row either side) is 115 KB
         f32x4 acc_a[4][2], acc_b[4][2];
-        S3W<2> wf1, wf2;
+        // register blockings per layer from tools/probes/s3_loop_probe (profiles/r04_s3_s3_loop_probe_tilings.txt): conv1 / conv3 4 pixel tiles x 2 channel
+        // tiles per wave; conv2 / conv4 / conv5 4 x 1 (one weight fragment feeds four pixel tiles: 85.0 / 86.0 / 89.0 % of the pipe floor vs 78.5 / 83.8 /
+        // 87.0 % for 2 x 2)
+        S3W<2> wf1;
+        S3W<1> wf2;
         s3_prefetch_w0<NW, CB, CB, 32, 4, 2>(a.packed + a.off.w_s3[1], wf1, wave, lane);
         prefetch_bias<NW, 32, 8, 2>(a.packed + a.off.b[1], bias1, wave, lane);
         conv0_half_split_q<NW, LQH, 2>(patch, w0, bias0, act, 0, wave, lane);
@@ -481,10 +485,9 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         conv3x3_mfma_s3q<NW, CB, CB, LQH, 1, 4, 2>(act, a.packed + a.off.w_s3[1], wf1, acc_b, wave, lane, s3_alt);
         if (PRIO) __builtin_amdgcn_s_setprio(3);
         CNN_STAMP(3);
-        s3_prefetch_w0<NW, CB, 2 * CB, 8, 2, 2>(a.packed + a.off.w_s3[2], wf2, wave, lane);
-        f32x4 acc2_a[2][2], acc2_b[2][2], bias2[2];
-#pragma unroll
-        for (int j = 0; j < 2; ++j) bias2[j] = *reinterpret_cast<const f32x4*>(&a.packed[a.off.b[2] + ((wave >> 2) * 2 + j) * 16 + 4 * (lane >> 4)]);
+        s3_prefetch_w0<NW, CB, 2 * CB, 8, 4, 1>(a.packed + a.off.w_s3[2], wf2, wave, lane);
+        f32x4 acc2_a[4][1], acc2_b[4][1], bias2[1];
+        bias2[0] = *reinterpret_cast<const f32x4*>(&a.packed[a.off.b[2] + (wave >> 1) * 16 + 4 * (lane >> 4)]);      // MG = 8 tiles / 4 = 2: channel tile = wave / 2
         __syncthreads();
         // conv1's output goes back into the same half layout, pre-split, and conv2 (stride 2: output rows 0 .. 7 read input rows
         // -1 .. 15, rows 8 .. 15 read 15 .. 31) runs in two passes as well
@@ -493,7 +496,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         __syncthreads();
         CNN_STAMP(4);
         if (PRIO) __builtin_amdgcn_s_setprio(0);
-        conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 2, 2>(act, a.packed + a.off.w_s3[2], wf2, acc2_a, wave, lane, s3_alt);
+        conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 4, 1>(act, a.packed + a.off.w_s3[2], wf2, acc2_a, wave, lane, s3_alt);
         if (PRIO) __builtin_amdgcn_s_setprio(3);
         __syncthreads();
         store_tiles_split_q<CB, LQH2, 4, 2>(act, bias1, acc_b, wave, lane);
@@ -504,17 +507,18 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         }
         __syncthreads();
         if (PRIO) __builtin_amdgcn_s_setprio(0);
-        conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 2, 2>(act, a.packed + a.off.w_s3[2], wf2, acc2_b, wave, lane, s3_alt);
+        conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 4, 1>(act, a.packed + a.off.w_s3[2], wf2, acc2_b, wave, lane, s3_alt);
         if (PRIO) __builtin_amdgcn_s_setprio(3);
         CNN_STAMP(5);
-        S3W<2> wf3, wf4, wf5;
-        f32x4 bias3[2], bias4[2], bias5s[2];
+        S3W<2> wf3;
+        S3W<1> wf4, wf5;
+        f32x4 bias3[2], bias4[1], bias5s[1];
         s3_prefetch_w0<NW, 2 * CB, 2 * CB, 16, 4, 2>(a.packed + a.off.w_s3[3], wf3, wave, lane);
         prefetch_bias<NW, 16, 4, 2>(a.packed + a.off.b[3], bias3, wave, lane);
         __syncthreads();
         zero_halo_q<LQ2, NTHR>(act);
-        store_tiles_split_q<2 * CB, LQ2, 2, 2, 8>(act, bias2, acc2_a, wave, lane, 0);
-        store_tiles_split_q<2 * CB, LQ2, 2, 2, 8>(act, bias2, acc2_b, wave, lane, 8);
+        store_tiles_split_q<2 * CB, LQ2, 4, 1, 8>(act, bias2, acc2_a, wave, lane, 0);
+        store_tiles_split_q<2 * CB, LQ2, 4, 1, 8>(act, bias2, acc2_b, wave, lane, 8);
         __syncthreads();
         CNN_STAMP(6);
         {
@@ -523,34 +527,34 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
             conv3x3_mfma_s3q<NW, 2 * CB, 2 * CB, LQ2, 1, 4, 2>(act, a.packed + a.off.w_s3[3], wf3, acc_, wave, lane, s3_alt);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
             CNN_STAMP(7);
-            s3_prefetch_w0<NW, 2 * CB, 4 * CB, 4, 2, 2>(a.packed + a.off.w_s3[4], wf4, wave, lane);
-            prefetch_bias<NW, 8, 2, 2>(a.packed + a.off.b[4], bias4, wave, lane);
+            s3_prefetch_w0<NW, 2 * CB, 4 * CB, 4, 4, 1>(a.packed + a.off.w_s3[4], wf4, wave, lane);
+            prefetch_bias<NW, 8, 4, 1>(a.packed + a.off.b[4], bias4, wave, lane);
             __syncthreads();
             store_tiles_split_q<2 * CB, LQ2, 4, 2>(act, bias3, acc_, wave, lane);      // same layout in place: the halo is still zero
             __syncthreads();
             CNN_STAMP(8);
         }
         {
-            f32x4 acc_[2][2];                                            // conv4: 64 -> 128, stride 2 -> 8x8
+            f32x4 acc_[4][1];                                            // conv4: 64 -> 128, stride 2 -> 8x8
             if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3q<NW, 2 * CB, 4 * CB, LQ2, 2, 2, 2>(act, a.packed + a.off.w_s3[4], wf4, acc_, wave, lane, s3_alt);
+            conv3x3_mfma_s3q<NW, 2 * CB, 4 * CB, LQ2, 2, 4, 1>(act, a.packed + a.off.w_s3[4], wf4, acc_, wave, lane, s3_alt);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
             CNN_STAMP(9);
-            s3_prefetch_w0<NW, 4 * CB, 4 * CB, 4, 2, 2>(a.packed + a.off.w_s3[5], wf5, wave, lane);
-            prefetch_bias<NW, 8, 2, 2>(a.packed + a.off.b[5], bias5s, wave, lane);
+            s3_prefetch_w0<NW, 4 * CB, 4 * CB, 4, 4, 1>(a.packed + a.off.w_s3[5], wf5, wave, lane);
+            prefetch_bias<NW, 8, 4, 1>(a.packed + a.off.b[5], bias5s, wave, lane);
             __syncthreads();
             zero_halo_q<LQ4, NTHR>(act);
-            store_tiles_split_q<4 * CB, LQ4, 2, 2>(act, bias4, acc_, wave, lane);
+            store_tiles_split_q<4 * CB, LQ4, 4, 1>(act, bias4, acc_, wave, lane);
             __syncthreads();
             CNN_STAMP(10);
         }
         {
-            f32x4 acc5[2][2];                                            // conv5: 128 -> 128 @8x8, conv5 tensor -> HBM for the head GEMM
+            f32x4 acc5[4][1];                                            // conv5: 128 -> 128 @8x8, conv5 tensor -> HBM for the head GEMM
             if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3q<NW, 4 * CB, 4 * CB, LQ4, 1, 2, 2>(act, a.packed + a.off.w_s3[5], wf5, acc5, wave, lane, s3_alt);
+            conv3x3_mfma_s3q<NW, 4 * CB, 4 * CB, LQ4, 1, 4, 1>(act, a.packed + a.off.w_s3[5], wf5, acc5, wave, lane, s3_alt);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
             CNN_STAMP(11);
-            store_tiles_global<4 * CB, 2, 2>(a.out + pidx * (64 * 4 * CB), bias5s, acc5, wave, lane);
+            store_tiles_global<4 * CB, 4, 1>(a.out + pidx * (64 * 4 * CB), bias5s, acc5, wave, lane);
         }
         return;
     }
@@ -610,36 +614,38 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         __syncthreads();
         conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 2, 1>(act, a.packed + a.off.w_s3[2], wf2, acc2_b, wave, lane, false);
         CNN_STAMP(5);
-        S3W<2> wf3, wf4;
-        f32x4 bias3[2], bias4[2];
+        // conv3 / conv4: four / two pixel tiles x ONE channel tile per wave (probe: conv3 64.8 % of the pipe floor vs 58.2 % for 2 x 2, conv4 60.6 % vs
+        // 39.4 % for 1 x 2 - a weight fragment that feeds a single pixel tile leaves the loop waiting on L2)
+        S3W<1> wf3, wf4;
+        f32x4 bias3[1], bias4[1];
         __syncthreads();
         zero_halo_q<LQ2, NTHR>(act);
         store_tiles_split_q<2 * CB, LQ2, 2, 1, 8>(act, bias2, acc2_a, wave, lane, 0);
         store_tiles_split_q<2 * CB, LQ2, 2, 1, 8>(act, bias2, acc2_b, wave, lane, 8);
-        s3_prefetch_w0<NW, 2 * CB, 2 * CB, 16, 2, 2>(a.packed + a.off.w_s3[3], wf3, wave, lane);
-        prefetch_bias_fresh<NW, 16, 2, 2>(a.packed + a.off.b[3], bias3, wave, lane);
+        s3_prefetch_w0<NW, 2 * CB, 2 * CB, 16, 4, 1>(a.packed + a.off.w_s3[3], wf3, wave, lane);
+        prefetch_bias_fresh<NW, 16, 4, 1>(a.packed + a.off.b[3], bias3, wave, lane);
         __syncthreads();
         CNN_STAMP(6);
         {
-            f32x4 acc_[2][2];                                            // conv3: 32 -> 32 @16x16
-            conv3x3_mfma_s3q<NW, 2 * CB, 2 * CB, LQ2, 1, 2, 2>(act, a.packed + a.off.w_s3[3], wf3, acc_, wave, lane, false);
+            f32x4 acc_[4][1];                                            // conv3: 32 -> 32 @16x16
+            conv3x3_mfma_s3q<NW, 2 * CB, 2 * CB, LQ2, 1, 4, 1>(act, a.packed + a.off.w_s3[3], wf3, acc_, wave, lane, false);
             CNN_STAMP(7);
             __syncthreads();
-            store_tiles_split_q<2 * CB, LQ2, 2, 2>(act, bias3, acc_, wave, lane);      // in place: the halo is still zero
-            s3_prefetch_w0<NW, 2 * CB, 4 * CB, 4, 1, 2>(a.packed + a.off.w_s3[4], wf4, wave, lane);
-            prefetch_bias_fresh<NW, 8, 1, 2>(a.packed + a.off.b[4], bias4, wave, lane);
+            store_tiles_split_q<2 * CB, LQ2, 4, 1>(act, bias3, acc_, wave, lane);      // in place: the halo is still zero
+            s3_prefetch_w0<NW, 2 * CB, 4 * CB, 4, 2, 1>(a.packed + a.off.w_s3[4], wf4, wave, lane);
+            prefetch_bias_fresh<NW, 8, 2, 1>(a.packed + a.off.b[4], bias4, wave, lane);
             __syncthreads();
             CNN_STAMP(8);
         }
         S3W<T4N> wf5;
         f32x4 bias5s[T4N];
         {
-            f32x4 acc_[1][2];                                            // conv4: 32 -> 64, stride 2 -> 8x8
-            conv3x3_mfma_s3q<NW, 2 * CB, 4 * CB, LQ2, 2, 1, 2>(act, a.packed + a.off.w_s3[4], wf4, acc_, wave, lane, false);
+            f32x4 acc_[2][1];                                            // conv4: 32 -> 64, stride 2 -> 8x8
+            conv3x3_mfma_s3q<NW, 2 * CB, 4 * CB, LQ2, 2, 2, 1>(act, a.packed + a.off.w_s3[4], wf4, acc_, wave, lane, false);
             CNN_STAMP(9);
             __syncthreads();
             zero_halo_q<LQ4, NTHR>(act);
-            store_tiles_split_q<4 * CB, LQ4, 1, 2>(act, bias4, acc_, wave, lane);
+            store_tiles_split_q<4 * CB, LQ4, 2, 1>(act, bias4, acc_, wave, lane);
             s3_prefetch_w0<NW, 4 * CB, 4 * CB, 4, T4M, T4N>(a.packed + a.off.w_s3[5], wf5, wave, lane);
             prefetch_bias_fresh<NW, 8, T4M, T4N>(a.packed + a.off.b[5], bias5s, wave, lane);
             __syncthreads();

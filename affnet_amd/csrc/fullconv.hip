@@ -434,6 +434,7 @@ int aff_fullconv_launch(affnet_ctx* ctx, const float* packed, const float* img, 
             layer(i, in, o, Hin, Win, Hout, Wout);
             a.W = packed + L.w_s3[i];
         };
+        // (register blockings as in the per-patch split trunks: one channel tile per wave for conv3 / conv4, tools/probes/s3_loop_probe)
         typedef LayQ<16, 32, 34, 16> Q1;          // conv1 input tile: 16 rows x 32 columns, 16 channels (59 KB)
         typedef LayQ<16, 32, 34, 16, 16> Q2;      // conv2 (stride 2) input tile
         typedef LayQ<16, 16, 18, 32> Q3;          // conv3 / conv4 input tiles (61 KB)
@@ -445,10 +446,10 @@ int aff_fullconv_launch(affnet_ctx* ctx, const float* packed, const float* img, 
         hipLaunchKernelGGL((dense_conv_s3_kernel<16, 32, 2, Q2, 2, 1>), dim3(aff_cdiv(g.Wp, 32), aff_cdiv(g.Hp, 16), B), dim3(512), 0, st, a);
         AFF_LAUNCH_CHECK(ctx);
         layer3(3, bufA, bufB, g.H2, g.W2, g.H2, g.W2);
-        hipLaunchKernelGGL((dense_conv_s3_kernel<32, 32, 1, Q3, 2, 2>), dim3(aff_cdiv(g.W2, 16), aff_cdiv(g.H2, 16), B), dim3(512), 0, st, a);
+        hipLaunchKernelGGL((dense_conv_s3_kernel<32, 32, 1, Q3, 4, 1>), dim3(aff_cdiv(g.W2, 16), aff_cdiv(g.H2, 16), B), dim3(512), 0, st, a);
         AFF_LAUNCH_CHECK(ctx);
         layer3(4, bufB, bufA, g.H2, g.W2, g.H4, g.W4);
-        hipLaunchKernelGGL((dense_conv_s3_kernel<32, 64, 2, Q3, 1, 2>), dim3(aff_cdiv(g.W2, 16), aff_cdiv(g.H2, 16), B), dim3(512), 0, st, a);
+        hipLaunchKernelGGL((dense_conv_s3_kernel<32, 64, 2, Q3, 2, 1>), dim3(aff_cdiv(g.W2, 16), aff_cdiv(g.H2, 16), B), dim3(512), 0, st, a);
         AFF_LAUNCH_CHECK(ctx);
         layer3(5, bufA, bufB, g.H4, g.W4, g.H4, g.W4);
         hipLaunchKernelGGL((dense_conv_s3_kernel<64, 64, 1, Q5, 2, 1>), dim3(aff_cdiv(g.W4, 8), aff_cdiv(g.H4, 8), B), dim3(512), 0, st, a);

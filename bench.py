@@ -79,6 +79,21 @@ def pmc_traffic(images_per_launch, split=False):
     return k["hbm_bytes"] * scale, note
 
 
+def gpu_state(tag):
+    """One rocm-smi sample (clock levels, socket power, power cap) for the JSON line: a run on a box that clocks or caps lower than its
+    peers (round 4 saw one box 12 % slower in EVERY stage, both arithmetic modes) can then be told from a regression."""
+    try:
+        out = subprocess.run(["rocm-smi", "--showclocks", "--showpower", "--showmaxpower", "--json"], capture_output=True, text=True, timeout=20,
+                             stdin=subprocess.DEVNULL).stdout
+        d = json.loads(out[out.index("{"):])
+        c = d.get("card0", {})
+        keep = {k: v for k, v in c.items() if any(t in k.lower() for t in ("sclk", "mclk", "power"))}
+        keep["when"] = tag
+        return keep
+    except Exception as e:                                   # noqa: BLE001
+        return {"when": tag, "error": repr(e)[:200]}
+
+
 def host_threads():
     try:
         avail = len(os.sched_getaffinity(0))
@@ -676,6 +691,7 @@ def run(args, world):
     barrier()
     dt = time.perf_counter() - t0
     gpu_sections.append({"what": "timed region (%d steps)" % args.steps, "unix_start_s": w0, "unix_end_s": time.time()})
+    smi = gpu_state("right after the timed region") if (rank == 0 and not DIST) else None
     kp = int(kp_dev.item())
     # a list that overflowed would have truncated the keypoint set the rate is computed on: fail instead of reporting it.  The
     # per-image flags are cleared at the start of every call, so they are summed on the device after each step (the contexts' own
@@ -862,6 +878,8 @@ def run(args, world):
             except Exception as e:                                   # noqa: BLE001
                 out["other_configs"] = {"error": repr(e)[:300]}
         out["gpu_sections_unix_s"] = gpu_sections
+        if smi is not None:
+            out["gpu_state"] = smi
         wall["other_configs_s"] = round(time.time() - t_oc, 1)          # incl. the one-image 4K CPU baseline
         if world == 1 and not args.no_cpu_baseline and not args.config5 and not ONEPASS:
             t_cb = time.time()

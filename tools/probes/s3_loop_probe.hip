@@ -33,6 +33,19 @@ template <> struct Tile4<2> { static constexpr int TM = 4, TN = 4; };
 template <> struct Tile4<3> { static constexpr int TM = 2, TN = 4; };
 template <> struct Tile4<4> { static constexpr int TM = 2, TN = 4; };
 
+// alternative register blockings of the HardNet shapes (8 waves): more pixel tiles per weight fragment
+template <> struct Shape<7> { static constexpr int CB = 32, CIN = 32, COUT = 32, STRIDE = 1, TM = 8, TN = 1; typedef LayB<16, 32, 34, 32> LB; typedef LayQ<16, 32, 34, 32> LQ; static const char* name() { return "HardNet conv1 (half) TM 8 x TN 1"; } };
+template <> struct Shape<8> { static constexpr int CB = 32, CIN = 64, COUT = 64, STRIDE = 1, TM = 8, TN = 1; typedef LayB<16, 16, 18, 64> LB; typedef LayQ<16, 16, 18, 64> LQ; static const char* name() { return "HardNet conv3 TM 8 x TN 1"; } };
+template <> struct Shape<9> { static constexpr int CB = 32, CIN = 64, COUT = 128, STRIDE = 2, TM = 4, TN = 1; typedef LayB<16, 16, 18, 64> LB; typedef LayQ<16, 16, 18, 64> LQ; static const char* name() { return "HardNet conv4 TM 4 x TN 1"; } };
+template <> struct Shape<10> { static constexpr int CB = 32, CIN = 128, COUT = 128, STRIDE = 1, TM = 4, TN = 1; typedef LayB<8, 8, 16, 128, 128> LB; typedef LayQ<8, 8, 16, 128, 128> LQ; static const char* name() { return "HardNet conv5 TM 4 x TN 1"; } };
+template <> struct Shape<11> { static constexpr int CB = 32, CIN = 128, COUT = 128, STRIDE = 1, TM = 1, TN = 4; typedef LayB<8, 8, 16, 128, 128> LB; typedef LayQ<8, 8, 16, 128, 128> LQ; static const char* name() { return "HardNet conv5 TM 1 x TN 4"; } };
+template <> struct Shape<12> { static constexpr int CB = 32, CIN = 32, COUT = 64, STRIDE = 2, TM = 4, TN = 1; typedef LayB<16, 32, 34, 32, 16> LB; typedef LayQ<16, 32, 34, 32, 16> LQ; static const char* name() { return "HardNet conv2 (half) TM 4 x TN 1"; } };
+
+template <> struct Shape<13> { static constexpr int CB = 16, CIN = 32, COUT = 32, STRIDE = 1, TM = 4, TN = 1; typedef LayB<16, 16, 18, 32> LB; typedef LayQ<16, 16, 18, 32> LQ; static const char* name() { return "AffNet conv3 TM 4 x TN 1"; } };
+template <> struct Shape<14> { static constexpr int CB = 16, CIN = 32, COUT = 64, STRIDE = 2, TM = 1, TN = 2; typedef LayB<16, 16, 18, 32> LB; typedef LayQ<16, 16, 18, 32> LQ; static const char* name() { return "AffNet conv4 32->64 stride 2, TM 1 x TN 2 (trunk)"; } };
+template <> struct Shape<15> { static constexpr int CB = 16, CIN = 32, COUT = 64, STRIDE = 2, TM = 2, TN = 1; typedef LayB<16, 16, 18, 32> LB; typedef LayQ<16, 16, 18, 32> LQ; static const char* name() { return "AffNet conv4 TM 2 x TN 1"; } };
+template <> struct Shape<16> { static constexpr int CB = 16, CIN = 64, COUT = 64, STRIDE = 1, TM = 1, TN = 2; typedef LayB<8, 8, 16, 64, 128> LB; typedef LayQ<8, 8, 16, 64, 128> LQ; static const char* name() { return "AffNet conv5 TM 1 x TN 2"; } };
+
 template <int SHAPE, int VAR> struct PB { static constexpr int v = 0; };
 // VAR 4: new loop, 4 waves per workgroup (one per SIMD), 5: the other tile split; 6 / 7 / 8: VAR 4 without weight loads / without fragment
 // reloads / without either (pure MFMA stream)
@@ -170,6 +183,12 @@ int main(int argc, char** argv) {
 #define DIAG(SH) run<SH, 6>(dW, dout, dcyc, reps, blocks, 2.4); run<SH, 7>(dW, dout, dcyc, reps, blocks, 2.4); run<SH, 8>(dW, dout, dcyc, reps, blocks, 2.4); \
     run<SH, 9>(dW, dout, dcyc, reps, blocks, 2.4); run<SH, 10>(dW, dout, dcyc, reps, blocks, 2.4); run<SH, 11>(dW, dout, dcyc, reps, blocks, 2.4); \
     run<SH, 12>(dW, dout, dcyc, reps, blocks, 2.4); run<SH, 13>(dW, dout, dcyc, reps, blocks, 2.4); run<SH, 14>(dW, dout, dcyc, reps, blocks, 2.4);
+    if (argc > 3 && argv[3][0] == 't') {       // alternative tilings (new loop, no alternating priorities) next to the trunk's
+#define ONE(SH) run<SH, 2>(dW, dout, dcyc, reps, blocks, 2.4);
+        ONE(0) ONE(7) ONE(1) ONE(12) ONE(2) ONE(8) ONE(3) ONE(9) ONE(4) ONE(10) ONE(11)
+        ONE(5) ONE(13) ONE(14) ONE(15) ONE(6) ONE(16)
+        return 0;
+    }
     if (argc > 3) { BOTH(2) FOUR(2) DIAG(2) BOTH(4) FOUR(4) DIAG(4) return 0; }
     BOTH(0) FOUR(0) BOTH(1) FOUR(1) BOTH(2) FOUR(2) BOTH(3) FOUR(3) BOTH(4) FOUR(4) BOTH(5) BOTH(6)
     return 0;
