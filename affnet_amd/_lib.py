@@ -12,20 +12,22 @@ LIB_PATH = os.path.join(_HERE, "libaffnet_hip.so")
 
 MAX_OCTAVES, MAX_LEVELS, MAX_TAPS = 16, 8, 37
 NET_AFFNET, NET_ORINET, NET_HARDNET, NET_AFFNET_FULLCONV = 0, 1, 2, 3
-ARITH_FP32_MFMA, ARITH_FP32_SPLIT3 = 0, 1        # include/affnet_hip.h AFFNET_ARITH_*
-ARITH_NAMES = {"fp32": ARITH_FP32_MFMA, "fp32_mfma": ARITH_FP32_MFMA, "fp32_split3": ARITH_FP32_SPLIT3, "split3": ARITH_FP32_SPLIT3}
+ARITH_FP32_MFMA, ARITH_FP32_SPLIT3, ARITH_FP32_SPLIT2H = 0, 1, 2        # include/affnet_hip.h AFFNET_ARITH_*
+ARITH_NAMES = {"fp32": ARITH_FP32_MFMA, "fp32_mfma": ARITH_FP32_MFMA, "fp32_split3": ARITH_FP32_SPLIT3, "split3": ARITH_FP32_SPLIT3,
+               "fp32_split2h": ARITH_FP32_SPLIT2H, "split2h": ARITH_FP32_SPLIT2H}
 
 
 def arith_code(arith):
-    """'fp32' (default: exact fp32 MFMA) / 'fp32_split3' (fp32 = 3 x bf16 split operands) or an AFFNET_ARITH_* integer -> the integer."""
+    """'fp32' (default: exact fp32 MFMA) / 'fp32_split3' (fp32 = 3 x bf16 split operands, six products) / 'fp32_split2h' (fp32 = 2 x fp16 split
+    operands, three products) or an AFFNET_ARITH_* integer -> the integer."""
     if arith is None:
         return ARITH_FP32_MFMA
     if isinstance(arith, str):
         if arith.lower() not in ARITH_NAMES:
             raise ValueError("arith must be one of %s" % sorted(ARITH_NAMES))
         return ARITH_NAMES[arith.lower()]
-    if int(arith) not in (ARITH_FP32_MFMA, ARITH_FP32_SPLIT3):
-        raise ValueError("arith must be AFFNET_ARITH_FP32_MFMA (0) or AFFNET_ARITH_FP32_SPLIT3 (1)")
+    if int(arith) not in (ARITH_FP32_MFMA, ARITH_FP32_SPLIT3, ARITH_FP32_SPLIT2H):
+        raise ValueError("arith must be AFFNET_ARITH_FP32_MFMA (0), AFFNET_ARITH_FP32_SPLIT3 (1) or AFFNET_ARITH_FP32_SPLIT2H (2)")
     return int(arith)
 OK, ERR_INVALID, ERR_HIP, ERR_CAPACITY, ERR_EMPTY = 0, -1, -2, -3, -4
 

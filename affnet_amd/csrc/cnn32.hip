@@ -80,8 +80,64 @@ extern "C" int affnet_cnn32_pack_weights(int kind, const float* const* conv_w, c
                 }
         }
     }
+    // two-term copies for AFFNET_ARITH_FP32_SPLIT2H: 2^e * w as hi = fp16(2^e w), lo = fp16(2^e w - hi) (nearest even), e per layer such that the
+    // largest |w| of the layer lands in [2^13, 2^14) - both terms of every weight down to 2^-15 of the largest then sit in fp16's normal range.
+    // Same fragment order with two terms; 2^-e (what the loop multiplies its sums with) follows the copy.
+    auto f16_bits = [](float x) -> uint16_t { const _Float16 h = (_Float16)x; uint16_t u; memcpy(&u, &h, 2); return u; };
+    auto f16_val = [](uint16_t u) -> float { _Float16 h; memcpy(&h, &u, 2); return (float)h; };
+    for (int i = 1; i < 6; ++i) {
+        if (!L.w_h2[i]) continue;
+        const int ci = L.cin[i], co = L.cout[i];
+        uint16_t* dst = reinterpret_cast<uint16_t*>(out + L.w_h2[i]);
+        float wmax = 0.0f;
+        for (int n = 0; n < co; ++n) {
+            const float sc = 1.0f / sqrtf(bn_var[i][n] + 1e-5f);
+            for (int k = 0; k < ci * 9; ++k) wmax = fmaxf(wmax, fabsf(conv_w[i][(size_t)n * ci * 9 + k] * sc));
+        }
+        const int e = (wmax > 0.0f && std::isfinite(wmax)) ? 13 - ilogbf(wmax) : 0;
+        out[L.w_h2[i] + s3_floats(ci, co, 2)] = ldexpf(1.0f, -e);
+        for (int n = 0; n < co; ++n) {
+            const float sc = 1.0f / sqrtf(bn_var[i][n] + 1e-5f);
+            for (int c = 0; c < ci; ++c)
+                for (int t9 = 0; t9 < 9; ++t9) {
+                    const float w = ldexpf(conv_w[i][((size_t)n * ci + c) * 9 + t9] * sc, e);      // the value the fp32 path uses, times 2^e (exact)
+                    const uint16_t hb = f16_bits(w), lb = f16_bits(w - f16_val(hb));
+                    for (int term = 0; term < 2; ++term) {
+                        const uint16_t v = term ? lb : hb;
+                        if (ci == 16) {
+                            const int st = t9 / 2, kq = (t9 % 2) * 2 + c / 8, j = c % 8;
+                            dst[((((size_t)st * 2 + term) * 4 + kq) * co + n) * 8 + j] = v;
+                        } else {
+                            const int G = c / 32, kq = (c % 32) / 8, j = c % 8;
+                            dst[(((((size_t)t9 * (ci / 32) + G) * 2 + term) * 4 + kq) * co + n) * 8 + j] = v;
+                        }
+                    }
+                }
+        }
+    }
     if (kind == AFFNET_NET_HARDNET) {
         if (!head_bn_mean || !head_bn_var) return AFFNET_ERR_INVALID;
+        {
+            uint16_t* hh2 = reinterpret_cast<uint16_t*>(out + L.head_h2);
+            float wmax = 0.0f;
+            for (int n = 0; n < 128; ++n) {
+                const float sc = 1.0f / sqrtf(head_bn_var[n] + 1e-5f);
+                for (int k = 0; k < HEAD_K; ++k) wmax = fmaxf(wmax, fabsf(head_w[(size_t)n * HEAD_K + k] * sc));
+            }
+            const int e = (wmax > 0.0f && std::isfinite(wmax)) ? 13 - ilogbf(wmax) : 0;
+            out[L.head_h2 + (size_t)HEAD_K * 128] = ldexpf(1.0f, -e);
+            for (int n = 0; n < 128; ++n) {
+                const float sc = 1.0f / sqrtf(head_bn_var[n] + 1e-5f);
+                for (int c = 0; c < 128; ++c)
+                    for (int pp = 0; pp < 64; ++pp) {
+                        const size_t k = (size_t)pp * 128 + c;
+                        const float w = ldexpf(head_w[(size_t)n * HEAD_K + c * 64 + pp] * sc, e);
+                        const uint16_t hb = f16_bits(w), lb = f16_bits(w - f16_val(hb));
+                        hh2[(((((k >> 5) * 2 + 0) * 4 + ((k & 31) >> 3)) * 128 + n) << 3) + (k & 7)] = hb;
+                        hh2[(((((k >> 5) * 2 + 1) * 4 + ((k & 31) >> 3)) * 128 + n) << 3) + (k & 7)] = lb;
+                    }
+            }
+        }
         uint16_t* hs3 = reinterpret_cast<uint16_t*>(out + L.head_s3);
         auto bf16_rne_h = [](float x) -> uint32_t { uint32_t u; memcpy(&u, &x, 4); return (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u; };
         for (int n = 0; n < 128; ++n) {
@@ -294,7 +350,7 @@ struct CnnArgs {
     int32_t* shape_cnt;
     int shape_op;
 };
-// (the split-operand variant is a template instantiation: cnn32_trunk_kernel<KIND, NW, STAMPS, S3>)
+// (the split-operand variants are template instantiations: cnn32_trunk_kernel<KIND, NW, STAMPS, S3>, S3 = 3 bf16 terms or 2 fp16 terms; 0 = exact)
 
 __device__ __forceinline__ bool lazy_skip(const int32_t* skip_cnt, int skip_n, int image, int which = CNT_SURVIVED1) {
     if (!skip_cnt) return false;
@@ -329,7 +385,7 @@ __device__ __forceinline__ void dump_planes(const float* act, float* dst) {
 // CU (2 waves / SIMD, 256 VGPRs).
 // STAMPS = debug instantiation: the s_memtime phase stamps of tools/cnn_phase_timing.py and the per-layer activation dumps
 // of affnet_cnn32_debug_layer exist only there (26 stamp sites = 26 predicated stores + branches in every wave otherwise).
-template <int KIND, int NW, bool STAMPS, bool S3 = false>
+template <int KIND, int NW, bool STAMPS, int S3 = 0>
 __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4) void cnn32_trunk_kernel(CnnArgs a, PyrSrc ps) {
     constexpr int CB = (KIND == AFFNET_NET_HARDNET) ? 32 : 16;
     constexpr int NTHR = NW * 64;
@@ -410,9 +466,11 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         const int y = e < 34 ? 0 : (e < 68 ? 33 : 1 + ((e - 68) >> 1)), x = e < 34 ? e : (e < 68 ? e - 34 : ((e - 68) & 1) * 33);
         patch[y * WP32 + x] = 0.0f;
     }
-    constexpr bool HALF = S3;                                     // split-operand arithmetic: conv0 .. conv2 in two half-patch passes
-    typedef LayQ<16, 32, 34, CB> LQH;                            // conv0 output of half a patch, pre-split (HALF only); read by conv1 (stride 1)
-    typedef LayQ<16, 32, 34, CB, 16> LQH2;                       // conv1 output of half a patch; read by conv2 at stride 2
+    constexpr bool HALF = S3 != 0;                                // split-operand arithmetic: conv0 .. conv2 in two half-patch passes
+    constexpr int TERMS = S3 ? S3 : 3;                            // terms per operand of the split arithmetic (3 bf16 / 2 fp16)
+    static_assert(S3 == 0 || S3 == 2 || S3 == 3, "S3 = number of terms of the split arithmetic");
+    typedef LayQ<16, 32, 34, CB, 0, TERMS> LQH;                  // conv0 output of half a patch, pre-split (HALF only); read by conv1 (stride 1)
+    typedef LayQ<16, 32, 34, CB, 16, TERMS> LQH2;                // conv1 output of half a patch; read by conv2 at stride 2
     if constexpr (HALF) zero_halo_q<LQH, NTHR>(act);
     else zero_halo<LayC0, NTHR>(act, CB);
     float sum = 0.f;
@@ -452,9 +510,9 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
     // HardNet (one workgroup per CU): optionally (affnet_debug_split3_variant bit 0) the two waves of a SIMD take turns at the higher priority
     // inside the loops.  Round 3's tile-major loops gained 2.5 % from it; with the term-major loops it costs 1 % (default off).
     const bool s3_alt = (a.s3_alt & 1) != 0 && KIND == AFFNET_NET_HARDNET;
-    if constexpr (S3 && KIND == AFFNET_NET_HARDNET) {
-        typedef LayQ<16, 16, 18, 2 * CB> LQ2;                            // conv2 / conv3 outputs: 64 channels @16x16 (122 KB)
-        typedef LayQ<8, 8, 16, 4 * CB, 128> LQ4;                         // conv4 output: 128 channels @8x8, row pitch 768 B (122 KB)
+    if constexpr (S3 != 0 && KIND == AFFNET_NET_HARDNET) {
+        typedef LayQ<16, 16, 18, 2 * CB, 0, TERMS> LQ2;                            // conv2 / conv3 outputs: 64 channels @16x16 (122 KB)
+        typedef LayQ<8, 8, 16, 4 * CB, 128, TERMS> LQ4;                         // conv4 output: 128 channels @8x8, row pitch 768 B (122 KB)
         static_assert(LQ2::BYTES <= TrunkLds<CB>::ACT * 4 && LQ4::BYTES <= TrunkLds<CB>::ACT * 4 && LQH::BYTES <= TrunkLds<CB>::ACT * 4 &&
                       LQH2::BYTES <= TrunkLds<CB>::ACT * 4, "pre-split layouts must fit the activation buffer");
         char* base = reinterpret_cast<char*>(act);
@@ -466,7 +524,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         // 87.0 % for 2 x 2)
         S3W<2> wf1;
         S3W<1> wf2;
-        s3_prefetch_w0<NW, CB, CB, 32, 4, 2>(a.packed + a.off.w_s3[1], wf1, wave, lane);
+        s3_prefetch_w0<NW, CB, CB, 32, 4, 2, TERMS>(a.packed + a.off.w_s3[1], wf1, wave, lane);
         prefetch_bias<NW, 32, 8, 2>(a.packed + a.off.b[1], bias1, wave, lane);
         conv0_half_split_q<NW, LQH, 2>(patch, w0, bias0, act, 0, wave, lane);
         __syncthreads();
@@ -485,7 +543,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         conv3x3_mfma_s3q<NW, CB, CB, LQH, 1, 4, 2>(act, a.packed + a.off.w_s3[1], wf1, acc_b, wave, lane, s3_alt);
         if (PRIO) __builtin_amdgcn_s_setprio(3);
         CNN_STAMP(3);
-        s3_prefetch_w0<NW, CB, 2 * CB, 8, 4, 1>(a.packed + a.off.w_s3[2], wf2, wave, lane);
+        s3_prefetch_w0<NW, CB, 2 * CB, 8, 4, 1, TERMS>(a.packed + a.off.w_s3[2], wf2, wave, lane);
         f32x4 acc2_a[4][1], acc2_b[4][1], bias2[1];
         bias2[0] = *reinterpret_cast<const f32x4*>(&a.packed[a.off.b[2] + (wave >> 1) * 16 + 4 * (lane >> 4)]);      // MG = 8 tiles / 4 = 2: channel tile = wave / 2
         __syncthreads();
@@ -513,7 +571,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         S3W<2> wf3;
         S3W<1> wf4, wf5;
         f32x4 bias3[2], bias4[1], bias5s[1];
-        s3_prefetch_w0<NW, 2 * CB, 2 * CB, 16, 4, 2>(a.packed + a.off.w_s3[3], wf3, wave, lane);
+        s3_prefetch_w0<NW, 2 * CB, 2 * CB, 16, 4, 2, TERMS>(a.packed + a.off.w_s3[3], wf3, wave, lane);
         prefetch_bias<NW, 16, 4, 2>(a.packed + a.off.b[3], bias3, wave, lane);
         __syncthreads();
         zero_halo_q<LQ2, NTHR>(act);
@@ -527,7 +585,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
             conv3x3_mfma_s3q<NW, 2 * CB, 2 * CB, LQ2, 1, 4, 2>(act, a.packed + a.off.w_s3[3], wf3, acc_, wave, lane, s3_alt);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
             CNN_STAMP(7);
-            s3_prefetch_w0<NW, 2 * CB, 4 * CB, 4, 4, 1>(a.packed + a.off.w_s3[4], wf4, wave, lane);
+            s3_prefetch_w0<NW, 2 * CB, 4 * CB, 4, 4, 1, TERMS>(a.packed + a.off.w_s3[4], wf4, wave, lane);
             prefetch_bias<NW, 8, 4, 1>(a.packed + a.off.b[4], bias4, wave, lane);
             __syncthreads();
             store_tiles_split_q<2 * CB, LQ2, 4, 2>(act, bias3, acc_, wave, lane);      // same layout in place: the halo is still zero
@@ -540,7 +598,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
             conv3x3_mfma_s3q<NW, 2 * CB, 4 * CB, LQ2, 2, 4, 1>(act, a.packed + a.off.w_s3[4], wf4, acc_, wave, lane, s3_alt);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
             CNN_STAMP(9);
-            s3_prefetch_w0<NW, 4 * CB, 4 * CB, 4, 4, 1>(a.packed + a.off.w_s3[5], wf5, wave, lane);
+            s3_prefetch_w0<NW, 4 * CB, 4 * CB, 4, 4, 1, TERMS>(a.packed + a.off.w_s3[5], wf5, wave, lane);
             prefetch_bias<NW, 8, 4, 1>(a.packed + a.off.b[5], bias5s, wave, lane);
             __syncthreads();
             zero_halo_q<LQ4, NTHR>(act);
@@ -559,11 +617,11 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         return;
     }
 
-    if constexpr (S3 && CB == 16) {
+    if constexpr (S3 != 0 && CB == 16) {
         // AffNet / OriNet on split operands, same structure as the HardNet branch: conv0 .. conv2 in two half-patch passes on pre-split
         // layouts (conv1 / conv2 have 16 input channels: two taps per k = 32 step), conv3 .. conv5 whole.
-        typedef LayQ<16, 16, 18, 2 * CB> LQ2;                            // conv2 / conv3 outputs: 32 channels @16x16 (61 KB)
-        typedef LayQ<8, 8, 16, 4 * CB, 128> LQ4;                         // conv4 output: 64 channels @8x8, row pitch 768 B (61 KB)
+        typedef LayQ<16, 16, 18, 2 * CB, 0, TERMS> LQ2;                            // conv2 / conv3 outputs: 32 channels @16x16 (61 KB)
+        typedef LayQ<8, 8, 16, 4 * CB, 128, TERMS> LQ4;                         // conv4 output: 64 channels @8x8, row pitch 768 B (61 KB)
         static_assert(LQH::BYTES <= TrunkLds<CB>::ACT * 4 && LQH2::BYTES <= TrunkLds<CB>::ACT * 4 && LQ2::BYTES <= TrunkLds<CB>::ACT * 4 && LQ4::BYTES <= TrunkLds<CB>::ACT * 4,
                       "pre-split layouts must fit the activation buffer");
         char* base = reinterpret_cast<char*>(act);
@@ -576,7 +634,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         S3W<1> wf1, wf2;
         prefetch_bias_fresh<NW, 32, 8, 1>(a.packed + a.off.b[1], bias1, wave, lane);
         conv0_half_split_q<NW, LQH, 1>(patch, w0, bias0, act, 0, wave, lane);
-        s3_prefetch_w0<NW, CB, CB, 32, 4, 1>(a.packed + a.off.w_s3[1], wf1, wave, lane);
+        s3_prefetch_w0<NW, CB, CB, 32, 4, 1, TERMS>(a.packed + a.off.w_s3[1], wf1, wave, lane);
         __syncthreads();
         CNN_STAMP(2);
         conv3x3_mfma_s3q<NW, CB, CB, LQH, 1, 4, 1>(act, a.packed + a.off.w_s3[1], wf1, acc_a, wave, lane, false);
@@ -586,7 +644,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
             *reinterpret_cast<f32x4*>(base + g * LQH::GS + (17 * LQH::WP + x + 1) * LQH::CELL + t * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
         conv0_half_split_q<NW, LQH, 1>(patch, w0, bias0, act, 1, wave, lane);
-        s3_prefetch_w0<NW, CB, CB, 32, 4, 1>(a.packed + a.off.w_s3[1], wf1, wave, lane);
+        s3_prefetch_w0<NW, CB, CB, 32, 4, 1, TERMS>(a.packed + a.off.w_s3[1], wf1, wave, lane);
         __syncthreads();
         conv3x3_mfma_s3q<NW, CB, CB, LQH, 1, 4, 1>(act, a.packed + a.off.w_s3[1], wf1, acc_b, wave, lane, false);
         CNN_STAMP(3);
@@ -599,7 +657,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         __syncthreads();
         zero_halo_q<LQH2, NTHR>(act);                                    // another group stride than LQH (bank conflicts of the stride-2 reader)
         store_tiles_split_q<CB, LQH2, 4, 1>(act, bias1, acc_a, wave, lane);
-        s3_prefetch_w0<NW, CB, 2 * CB, 8, 2, 1>(a.packed + a.off.w_s3[2], wf2, wave, lane);
+        s3_prefetch_w0<NW, CB, 2 * CB, 8, 2, 1, TERMS>(a.packed + a.off.w_s3[2], wf2, wave, lane);
         __syncthreads();
         CNN_STAMP(4);
         conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 2, 1>(act, a.packed + a.off.w_s3[2], wf2, acc2_a, wave, lane, false);
@@ -610,7 +668,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
 #pragma unroll
             for (int i = 2; i < 4; ++i) split_store_tile_q<LQH2, 1>(base, ((i - 2) * 16 + n + 1) * LQH2::CELL, 0, bias1, acc_a[i], lane >> 4);
         }
-        s3_prefetch_w0<NW, CB, 2 * CB, 8, 2, 1>(a.packed + a.off.w_s3[2], wf2, wave, lane);
+        s3_prefetch_w0<NW, CB, 2 * CB, 8, 2, 1, TERMS>(a.packed + a.off.w_s3[2], wf2, wave, lane);
         __syncthreads();
         conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 2, 1>(act, a.packed + a.off.w_s3[2], wf2, acc2_b, wave, lane, false);
         CNN_STAMP(5);
@@ -622,7 +680,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         zero_halo_q<LQ2, NTHR>(act);
         store_tiles_split_q<2 * CB, LQ2, 2, 1, 8>(act, bias2, acc2_a, wave, lane, 0);
         store_tiles_split_q<2 * CB, LQ2, 2, 1, 8>(act, bias2, acc2_b, wave, lane, 8);
-        s3_prefetch_w0<NW, 2 * CB, 2 * CB, 16, 4, 1>(a.packed + a.off.w_s3[3], wf3, wave, lane);
+        s3_prefetch_w0<NW, 2 * CB, 2 * CB, 16, 4, 1, TERMS>(a.packed + a.off.w_s3[3], wf3, wave, lane);
         prefetch_bias_fresh<NW, 16, 4, 1>(a.packed + a.off.b[3], bias3, wave, lane);
         __syncthreads();
         CNN_STAMP(6);
@@ -632,7 +690,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
             CNN_STAMP(7);
             __syncthreads();
             store_tiles_split_q<2 * CB, LQ2, 4, 1>(act, bias3, acc_, wave, lane);      // in place: the halo is still zero
-            s3_prefetch_w0<NW, 2 * CB, 4 * CB, 4, 2, 1>(a.packed + a.off.w_s3[4], wf4, wave, lane);
+            s3_prefetch_w0<NW, 2 * CB, 4 * CB, 4, 2, 1, TERMS>(a.packed + a.off.w_s3[4], wf4, wave, lane);
             prefetch_bias_fresh<NW, 8, 2, 1>(a.packed + a.off.b[4], bias4, wave, lane);
             __syncthreads();
             CNN_STAMP(8);
@@ -646,7 +704,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
             __syncthreads();
             zero_halo_q<LQ4, NTHR>(act);
             store_tiles_split_q<4 * CB, LQ4, 2, 1>(act, bias4, acc_, wave, lane);
-            s3_prefetch_w0<NW, 4 * CB, 4 * CB, 4, T4M, T4N>(a.packed + a.off.w_s3[5], wf5, wave, lane);
+            s3_prefetch_w0<NW, 4 * CB, 4 * CB, 4, T4M, T4N, TERMS>(a.packed + a.off.w_s3[5], wf5, wave, lane);
             prefetch_bias_fresh<NW, 8, T4M, T4N>(a.packed + a.off.b[5], bias5s, wave, lane);
             __syncthreads();
             CNN_STAMP(10);
@@ -954,8 +1012,10 @@ __global__ __launch_bounds__(256, 2) void hardnet_head_kernel(const float* __res
 // (row pitch 128 k * 6 B + 16 B: the 16 rows of an M-tile fall into 16 different 16-byte bank slots), B = the pre-split head weights
 // [k / 32][term][kq][n][8] straight from L2.  Six v_mfma_f32_16x16x32_bf16 per fp32 product in term-major order, fp32 accumulate; same
 // partial-sum scratch and finish kernel as the exact path.
+// TERMS = 2 (AFFNET_ARITH_FP32_SPLIT2H): two fp16 terms, three v_mfma_f32_16x16x32_f16 per product, the same cells with the third slot unused; the head
+// weights are packed times 2^e, the partial sums are multiplied by 2^-e (behind the weights) before they are stored.
 #define HEAD_S3_ROWB (HEAD_KC * 6 + 16)
-template <int MP>
+template <int MP, int TERMS = 3>
 __global__ __launch_bounds__(256, 2) void hardnet_head_s3_kernel(const float* __restrict__ trunk, const float* __restrict__ Bw3,
                                                                  const int32_t* __restrict__ count, int n_max, float* __restrict__ partial) {
     constexpr int MI = MP / 16;
@@ -969,7 +1029,7 @@ __global__ __launch_bounds__(256, 2) void hardnet_head_s3_kernel(const float* __
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int m = lane & 15, kq = lane >> 4;
     const __amdgpu_buffer_rsrc_t rA = weight_rsrc(trunk + (size_t)blockIdx.z * n_max * HEAD_K, n * HEAD_K);   // rows >= n -> 0
-    const __amdgpu_buffer_rsrc_t rB = weight_rsrc(Bw3, HEAD_K * 128 * 3 / 2);
+    const __amdgpu_buffer_rsrc_t rB = weight_rsrc(Bw3, HEAD_K * 128 * TERMS / 2);
     int offA[NA];
 #pragma unroll
     for (int r = 0; r < NA; ++r) {
@@ -992,47 +1052,49 @@ __global__ __launch_bounds__(256, 2) void hardnet_head_s3_kernel(const float* __
         for (int r = 0; r < NA; ++r) {
             const int f = tid + 256 * r, row = f >> 5, c4 = f & 31;
             char* dst = As + row * HEAD_S3_ROWB + (c4 >> 1) * 48 + (c4 & 1) * 8;      // cell = 8 consecutive k, this float4 = its lower / upper half
-            f32x2 lo = {stage[r].x, stage[r].y}, hi = {stage[r].z, stage[r].w};
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const unsigned u0 = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
-                const unsigned u1 = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
-                *reinterpret_cast<uint2*>(dst + t * 16) = make_uint2(u0, u1);
-                if (t < 2) { split_remainder(lo, u0); split_remainder(hi, u1); }
-            }
+            split_store4<TERMS>(dst, stage[r]);
         }
         __syncthreads();
         if (k0 + HEAD_KC < kbeg + HEAD_K / HEAD_KSPLIT) {
 #pragma unroll
             for (int r = 0; r < NA; ++r) stage[r] = buf_read4(rA, offA[r], (k0 + HEAD_KC) * 4);
         }
-        bf16x8 fb[2][3][2];                                           // [buffer][term][N-tile]
+        bf16x8 fb[2][TERMS][2];                                       // [buffer][term][N-tile]
         auto load_b = [&](int buf, int ks) {
 #pragma unroll
-            for (int t = 0; t < 3; ++t)
+            for (int t = 0; t < TERMS; ++t)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    fb[buf][t][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rB, offB + j * 256, ((ks * 3 + t) * 4 * 128) * 16, 0));
+                    fb[buf][t][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rB, offB + j * 256, ((ks * TERMS + t) * 4 * 128) * 16, 0));
         };
         load_b(0, k0 >> 5);
 #pragma unroll
         for (int s = 0; s < HEAD_KC / 32; ++s) {
             const int cur = s & 1;
             if (s + 1 < HEAD_KC / 32) load_b(cur ^ 1, (k0 >> 5) + s + 1);
-            bf16x8 fa[MI][3];
+            bf16x8 fa[MI][TERMS];
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
-                for (int t = 0; t < 3; ++t) fa[i][t] = __builtin_bit_cast(bf16x8, lds_read4(a_addr + i * 16 * HEAD_S3_ROWB + s * 192 + t * 16));
-            constexpr int TA[6] = {0, 0, 0, 1, 1, 2}, TB[6] = {0, 1, 2, 0, 1, 0};      // term pairs (a_i, b_j), i + j <= 2, term-major
+                for (int t = 0; t < TERMS; ++t) fa[i][t] = __builtin_bit_cast(bf16x8, lds_read4(a_addr + i * 16 * HEAD_S3_ROWB + s * 192 + t * 16));
+            // term pairs (a_i, b_j), i + j <= TERMS - 1, term-major
+            constexpr int NPAIR = TERMS == 3 ? 6 : 3;
+            constexpr int TA3[6] = {0, 0, 0, 1, 1, 2}, TB3[6] = {0, 1, 2, 0, 1, 0}, TA2[3] = {0, 0, 1}, TB2[3] = {0, 1, 0};
 #pragma unroll
-            for (int q = 0; q < 6; ++q)
+            for (int q = 0; q < NPAIR; ++q)
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][TA[q]], fb[cur][TB[q]][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = split_mfma<TERMS>(fa[i][TERMS == 3 ? TA3[q] : TA2[q]], fb[cur][TERMS == 3 ? TB3[q] : TB2[q]][j], acc[i][j]);
         }
+    }
+    if constexpr (TERMS == 2) {
+        const float osc = Bw3[(size_t)HEAD_K * 128];
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] *= osc;
     }
     // acc[i][j][r]: patch p0 + 16 i + 4 (lane>>4) + r, channel 32 wave + 16 j + (lane & 15)
     const int g = lane >> 4;
@@ -1115,17 +1177,19 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
 #define TRUNK_LAUNCH(K) do { if (a.dbg_time || dbg_layer >= 0) hipLaunchKernelGGL((cnn32_trunk_kernel<K, 8, true>), grid, dim3(512), 0, st, a, ps); \
                              else hipLaunchKernelGGL((cnn32_trunk_kernel<K, 8, false>), grid, dim3(512), 0, st, a, ps); } while (0)
     a.s3_alt = ctx->split3_variant;
-    const bool split = ctx->arith == AFFNET_ARITH_FP32_SPLIT3;
+    const bool h2 = ctx->arith == AFFNET_ARITH_FP32_SPLIT2H;
+    const bool split = ctx->arith == AFFNET_ARITH_FP32_SPLIT3 || h2;
+    a.off = to_offsets(L, ctx->arith);                                   // the split copy of the active mode
     const bool s3 = split && !a.dbg_time && dbg_layer < 0;             // conv1 .. conv5 on split operands (affnet_set_arith)
-    if (split && a.dbg_time && dbg_layer < 0 && kind == AFFNET_NET_HARDNET)      // phase stamps of the split-operand trunks (tuning aid)
-        hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_HARDNET, 8, true, true>), grid, dim3(512), 0, st, a, ps);
-    else if (split && a.dbg_time && dbg_layer < 0 && kind == AFFNET_NET_AFFNET)
-        hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_AFFNET, 8, true, true>), grid, dim3(512), 0, st, a, ps);
-    else if (split && a.dbg_time && dbg_layer < 0 && kind == AFFNET_NET_ORINET)
-        hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_ORINET, 8, true, true>), grid, dim3(512), 0, st, a, ps);
-    else if (s3 && kind == AFFNET_NET_AFFNET) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_AFFNET, 8, false, true>), grid, dim3(512), 0, st, a, ps);
-    else if (s3 && kind == AFFNET_NET_ORINET) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_ORINET, 8, false, true>), grid, dim3(512), 0, st, a, ps);
-    else if (s3) hipLaunchKernelGGL((cnn32_trunk_kernel<AFFNET_NET_HARDNET, 8, false, true>), grid, dim3(512), 0, st, a, ps);
+#define SPLIT_LAUNCH(K, ST) do { if (h2) hipLaunchKernelGGL((cnn32_trunk_kernel<K, 8, ST, 2>), grid, dim3(512), 0, st, a, ps); \
+                                 else hipLaunchKernelGGL((cnn32_trunk_kernel<K, 8, ST, 3>), grid, dim3(512), 0, st, a, ps); } while (0)
+    if (split && a.dbg_time && dbg_layer < 0 && kind == AFFNET_NET_HARDNET) SPLIT_LAUNCH(AFFNET_NET_HARDNET, true);      // phase stamps of the split-operand trunks (tuning aid)
+    else if (split && a.dbg_time && dbg_layer < 0 && kind == AFFNET_NET_AFFNET) SPLIT_LAUNCH(AFFNET_NET_AFFNET, true);
+    else if (split && a.dbg_time && dbg_layer < 0 && kind == AFFNET_NET_ORINET) SPLIT_LAUNCH(AFFNET_NET_ORINET, true);
+    else if (s3 && kind == AFFNET_NET_AFFNET) SPLIT_LAUNCH(AFFNET_NET_AFFNET, false);
+    else if (s3 && kind == AFFNET_NET_ORINET) SPLIT_LAUNCH(AFFNET_NET_ORINET, false);
+    else if (s3) SPLIT_LAUNCH(AFFNET_NET_HARDNET, false);
+#undef SPLIT_LAUNCH
     else if (kind == AFFNET_NET_AFFNET) TRUNK_LAUNCH(AFFNET_NET_AFFNET);
     else if (kind == AFFNET_NET_ORINET) TRUNK_LAUNCH(AFFNET_NET_ORINET);
     else TRUNK_LAUNCH(AFFNET_NET_HARDNET);
@@ -1150,13 +1214,14 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
         // patches per workgroup: the 64-patch shape once it gives every CU a workgroup, else 32 / 16 (same sums, more workgroups)
         int mp = (aff_cdiv(n_max, 64) * HEAD_KSPLIT * B >= 256) ? 64 : ((aff_cdiv(n_max, 32) * HEAD_KSPLIT * B >= 256) ? 32 : 16);
         if (const char* e = getenv("AFFNET_HEAD_MP")) { const int v = atoi(e); if (v == 16 || v == 32 || v == 64) mp = v; }   // tuning aid
-        if (split) {              // AFFNET_ARITH_FP32_SPLIT3: the head GEMM on split operands as well
-            if (mp == 64)
-                hipLaunchKernelGGL(hardnet_head_s3_kernel<64>, dim3(aff_cdiv(n_max, 64), HEAD_KSPLIT, B), dim3(256), 0, st, scratch, packed + L.head_s3, count, n_max, partial);
-            else if (mp == 32)
-                hipLaunchKernelGGL(hardnet_head_s3_kernel<32>, dim3(aff_cdiv(n_max, 32), HEAD_KSPLIT, B), dim3(256), 0, st, scratch, packed + L.head_s3, count, n_max, partial);
-            else
-                hipLaunchKernelGGL(hardnet_head_s3_kernel<16>, dim3(aff_cdiv(n_max, 16), HEAD_KSPLIT, B), dim3(256), 0, st, scratch, packed + L.head_s3, count, n_max, partial);
+        if (split) {              // AFFNET_ARITH_FP32_SPLIT3 / _SPLIT2H: the head GEMM on split operands as well
+            const float* hw = packed + (h2 ? L.head_h2 : L.head_s3);
+#define HEAD_LAUNCH(MPV) do { if (h2) hipLaunchKernelGGL((hardnet_head_s3_kernel<MPV, 2>), dim3(aff_cdiv(n_max, MPV), HEAD_KSPLIT, B), dim3(256), 0, st, scratch, hw, count, n_max, partial); \
+                              else hipLaunchKernelGGL((hardnet_head_s3_kernel<MPV, 3>), dim3(aff_cdiv(n_max, MPV), HEAD_KSPLIT, B), dim3(256), 0, st, scratch, hw, count, n_max, partial); } while (0)
+            if (mp == 64) HEAD_LAUNCH(64);
+            else if (mp == 32) HEAD_LAUNCH(32);
+            else HEAD_LAUNCH(16);
+#undef HEAD_LAUNCH
         } else if (mp == 64)
             hipLaunchKernelGGL(hardnet_head_kernel<64>, dim3(aff_cdiv(n_max, 64), HEAD_KSPLIT, B), dim3(256), 0, st, scratch, packed + L.head_w, count, n_max, partial);
         else if (mp == 32)

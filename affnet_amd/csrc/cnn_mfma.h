@@ -71,12 +71,16 @@ struct NetLayout {
     size_t head_w, head_b;  // head weights / bias (HardNet: BN-folded [8192][128] + bias[128])
     size_t w_s3[6];         // AFFNET_ARITH_FP32_SPLIT3 (0 = none): conv weights once more as three bf16 terms, [tap][cin/32][term][kq][cout][8]
     size_t head_s3;         // HardNet only: the BN-folded head weights as three bf16 terms, [k/32][term][kq][n 128][8]  (k = pixel * 128 + channel)
+    size_t w_h2[6];         // AFFNET_ARITH_FP32_SPLIT2H (0 = none): the same layers as TWO fp16 terms of 2^e * w (e per layer: the largest |w| of the layer lands in
+                            // [2^13, 2^14)), same fragment order with 2 terms, followed by 4 floats whose first is 2^-e (the loop's output scale)
+    size_t head_h2;         // HardNet only: the head weights as two fp16 terms, [k/32][term][kq][n 128][8] + 4 floats (2^-e first)
     size_t total;
 };
 
 // floats occupied by the split copy of a cin x cout 3x3 layer: 9 taps x (cin / 32) groups x 3 terms x 4 lane groups x cout x 8 bf16 (= 4 floats)
-constexpr size_t s3_floats(int cin, int cout) { return cin == 16 ? (size_t)5 * 3 * 4 * cout * 4      // 16 input channels: two taps per k = 32 step, 9 taps in 5 steps
-                                                                  : (size_t)9 * (cin / 32) * 3 * 4 * cout * 4; }
+constexpr size_t s3_floats(int cin, int cout, int terms = 3) { return cin == 16 ? (size_t)5 * terms * 4 * cout * 4      // 16 input channels: two taps per k = 32 step, 9 taps in 5 steps
+                                                                                 : (size_t)9 * (cin / 32) * terms * 4 * cout * 4; }
+#define H2_TAIL 4               // floats behind a two-term copy: [0] = 2^-e, the power of two that undoes the copy's scale (exact)
 #define S3_LAYER_MASK 0x3E      // which layers have a split copy / run on split operands (bit i = conv i): conv1 .. conv5 of HardNet
 
 static inline NetLayout net_layout(int kind) {
@@ -103,22 +107,29 @@ static inline NetLayout net_layout(int kind) {
     }
     L.head_s3 = 0;
     if (kind == AFFNET_NET_HARDNET) { L.head_s3 = off; off += (size_t)HEAD_K * 128 * 3 / 2; }
+    for (int i = 0; i < 6; ++i) {
+        L.w_h2[i] = 0;
+        if (L.w_s3[i]) { L.w_h2[i] = off; off += s3_floats(L.cin[i], L.cout[i], 2) + H2_TAIL; }
+    }
+    L.head_h2 = 0;
+    if (kind == AFFNET_NET_HARDNET) { L.head_h2 = off; off += (size_t)HEAD_K * 128 + H2_TAIL; }
     L.total = off;
     return L;
 }
 
 struct NetOffsets {        // device-side copy of the offsets (by-value kernel argument)
     int w[6], b[6], head_w, head_b;
-    int w_s3[6];
+    int w_s3[6];           // the split copy of the ACTIVE arithmetic mode (three bf16 terms or two fp16 terms)
     int head_s3;
 };
 
-static inline NetOffsets to_offsets(const NetLayout& L) {
+static inline NetOffsets to_offsets(const NetLayout& L, int arith = AFFNET_ARITH_FP32_SPLIT3) {
     NetOffsets o;
+    const bool h2 = arith == AFFNET_ARITH_FP32_SPLIT2H;
     for (int i = 0; i < 6; ++i) { o.w[i] = (int)L.w_off[i]; o.b[i] = (int)L.b_off[i]; }
     o.head_w = (int)L.head_w; o.head_b = (int)L.head_b;
-    for (int i = 0; i < 6; ++i) o.w_s3[i] = (int)L.w_s3[i];
-    o.head_s3 = (int)L.head_s3;
+    for (int i = 0; i < 6; ++i) o.w_s3[i] = (int)(h2 ? L.w_h2[i] : L.w_s3[i]);
+    o.head_s3 = (int)(h2 ? L.head_h2 : L.head_s3);
     return o;
 }
 
@@ -366,6 +377,53 @@ __device__ __forceinline__ void split_remainder(f32x2& v, unsigned u) {
     v.y = __builtin_amdgcn_fdot2_f32_bf16(b, __builtin_bit_cast(bf16x2, c1), v.y, false);
 }
 
+// ---- AFFNET_ARITH_FP32_SPLIT2H: fp32 = two fp16 terms, three products ------------------------------------------------------------------
+// x ~ h + l, h = fp16(x), l = fp16(x - h) (both round-to-nearest-even; x - h is exact in fp32): 11 + 11 bits + the remainder's sign = 23 of
+// fp32's 24 significand bits, |x - h - l| <= 2^-23 |x| (rms ~2^-25).  w a = w_h a_h + w_l a_h + w_h a_l (+ w_l a_l <= 2^-24, dropped) on v_mfma_f32_16x16x32_f16: every fp16 x fp16 product is exact
+// in the fp32 accumulator and subnormal fp16 inputs are honoured (tools/probes/f16_split_probe.hip), so small activations keep an ABSOLUTE
+// error of 2^-25.  Half the matrix instructions of the three-term bf16 scheme; the layouts, loops and epilogues are the same code with
+// TERMS = 2 (LayQ keeps its 48-byte cells, the third slot stays unused, so every bank-conflict property carries over).
+// Weights are packed times 2^e per layer (net_layout: w_h2) so that both terms sit in fp16's normal range; the loop multiplies its sums by
+// 2^-e (exact).  Activations are not scaled: |a| < 65504 required (include/affnet_hip.h).
+// The pair split is written in assembly: this compiler's own lowering of  <2 x float> -> <2 x half>  followed by element reads uses the LOW
+// half for both elements (v_cvt_pk_f16_f32, then v_perm / v_cvt_f32_f16 of the low half twice - found by the probe: every odd element wrong).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split_h2_pair(f32x2 v, unsigned& hi, unsigned& lo) {
+    float r0, r1;
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(hi) : "v"(v.x), "v"(v.y));
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "v"(v.x));                      // x - float(hi.lo16): exact
+    asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "v"(v.y));       // y - float(hi.hi16)
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lo) : "v"(r0), "v"(r1));
+}
+
+// Split four fp32 values (a lane's four consecutive channels) into TERMS terms and store term t at dst + 16 t (8 bytes each: half a cell)
+template <int TERMS>
+__device__ __forceinline__ void split_store4(char* dst, f32x4 v) {
+    f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
+    if constexpr (TERMS == 2) {
+        unsigned h0, l0, h1, l1;
+        split_h2_pair(lo, h0, l0);
+        split_h2_pair(hi, h1, l1);
+        *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2*>(dst + 16) = make_uint2(l0, l1);
+    } else {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const unsigned u0 = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
+            const unsigned u1 = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
+            *reinterpret_cast<uint2*>(dst + t * 16) = make_uint2(u0, u1);
+            if (t < 2) { split_remainder(lo, u0); split_remainder(hi, u1); }
+        }
+    }
+}
+
+// one matrix instruction of the split arithmetic: fragments travel as 16 bytes, the term count picks the operand type
+template <int TERMS>
+__device__ __forceinline__ f32x4 split_mfma(bf16x8 w, bf16x8 a, f32x4 c) {
+    if constexpr (TERMS == 2) return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, w), __builtin_bit_cast(f16x8, a), c, 0, 0, 0);
+    else return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, c, 0, 0, 0);
+}
+
 // ---- pre-split activations: a layer's output stored as three bf16 planes -------------------------------------------------------
 // Splitting in the reading loop is redundant: the NG waves that share a pixel tile (different output channels) each split the same
 // fragment - 4.5 VALU instructions per MFMA in the first version (PMC: 8.0e9 VALU vs 1.8e9 MFMA instructions per 32-image HardNet
@@ -599,9 +657,11 @@ __device__ __forceinline__ void conv3x3_mfma_s3p_c16(const float* act, const flo
 // GS = 16 (mod 256); two rows of 8 pixels with a 768 B row pitch (8-wide layers, WP = 16) with GS = 128 (mod 256).  Only the stride-2
 // reader of the 16-wide layers (conv4) keeps 2-way conflicts: its row pitch 2 * 18 * 48 B would have to be a multiple of 256 B (WP = 24:
 // 166 KB for the 64-channel layers).
-template <int H_, int W_, int WP_, int C_, int GREM_ = 0>
+template <int H_, int W_, int WP_, int C_, int GREM_ = 0, int TERMS_ = 3>
 struct LayQ {
     static constexpr int H = H_, W = W_, WP = WP_, C = C_;      // H rows x W columns (+ a one-cell halo), row stride WP cells of 48 bytes
+    static constexpr int GREM = GREM_;
+    static constexpr int TERMS = TERMS_;                        // 3 bf16 terms or 2 fp16 terms per element (the cell keeps three 16-byte slots either way)
     static constexpr int CELL = 48;
     static constexpr int GS = (((H_ + 2) * WP_ * CELL + 255) / 256) * 256 + GREM_;      // bytes per 8-channel group
     static constexpr int BYTES = (C_ / 8) * GS;
@@ -632,14 +692,7 @@ __device__ __forceinline__ void split_store_tile_q(char* base, int cell, int nt0
         v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
         const int c0 = (nt0 + j) * 16 + 4 * g;                           // first of this lane's 4 channels
         char* dst = base + (c0 >> 3) * LO::GS + cell + (c0 & 4) * 2;
-        f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const unsigned u0 = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
-            const unsigned u1 = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
-            *reinterpret_cast<uint2*>(dst + t * 16) = make_uint2(u0, u1);
-            if (t < 2) { split_remainder(lo, u0); split_remainder(hi, u1); }
-        }
+        split_store4<LO::TERMS>(dst, v);
     }
 }
 
@@ -658,7 +711,9 @@ __device__ __forceinline__ void store_tiles_split_q(float* act, const f32x4 (&bi
     }
 }
 
-// Weight fragments of one k = 32 step of a split layer: [term][channel tile]
+template <int N> struct IntC { static constexpr int v = N; };
+
+// Weight fragments of one k = 32 step of a split layer: [term][channel tile] (two-term arithmetic leaves w[2] unused: no registers)
 template <int TN>
 struct S3W {
     bf16x8 w[3][TN];
@@ -669,21 +724,21 @@ template <int NW, int COUT, int MG, int TN>
 __device__ __forceinline__ int s3_w_lane(int wave, int lane) {
     return (((lane >> 4) * COUT) + (wave / MG) * TN * 16 + (lane & 15)) * 16;
 }
-template <int COUT, int TN>
+template <int COUT, int TN, int TERMS = 3>
 __device__ __forceinline__ void s3_load_w(S3W<TN>& dst, __amdgpu_buffer_rsrc_t wrsrc, int w_lane, int s) {
 #pragma unroll
-    for (int t = 0; t < 3; ++t)
+    for (int t = 0; t < TERMS; ++t)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
-            dst.w[t][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_lane + j * 256, ((s * 3 + t) * 4 * COUT) * 16, 0));
+            dst.w[t][j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, w_lane + j * 256, ((s * TERMS + t) * 4 * COUT) * 16, 0));
 }
 // The first step's weights of a layer do not depend on the activations: requested BEFORE the barriers / epilogue of the previous layer
 // (1 - 2 k cycles of L2 latency under load, otherwise paid with an idle matrix pipe at the head of every loop).
-template <int NW, int CIN, int COUT, int HOUT_TILES, int TM, int TN>
+template <int NW, int CIN, int COUT, int HOUT_TILES, int TM, int TN, int TERMS = 3>
 __device__ __forceinline__ void s3_prefetch_w0(const float* __restrict__ Ws, S3W<TN>& w0, int wave, int lane) {
     constexpr int MG = HOUT_TILES / TM;
-    constexpr int WS_FLOATS = (CIN == 16 ? 5 : 9 * (CIN / 32)) * 3 * 4 * COUT * 4;
-    s3_load_w<COUT, TN>(w0, weight_rsrc(Ws, WS_FLOATS), s3_w_lane<NW, COUT, MG, TN>(wave, lane), 0);
+    constexpr int WS_FLOATS = (CIN == 16 ? 5 : 9 * (CIN / 32)) * TERMS * 4 * COUT * 4;
+    s3_load_w<COUT, TN, TERMS>(w0, weight_rsrc(Ws, WS_FLOATS), s3_w_lane<NW, COUT, MG, TN>(wave, lane), 0);
 }
 
 // The contraction on a term-interleaved pre-split input (LI = LayQ).  MFMA order is TERM-MAJOR: a term pair (w_i, a_j) runs over all
@@ -699,11 +754,12 @@ template <int NW, int CIN, int COUT, typename LI, int STRIDE, int TM, int TN, in
 __device__ __forceinline__ void conv3x3_mfma_s3q(const float* act, const float* __restrict__ Ws, const S3W<TN>& w_first, f32x4 (&acc)[TM][TN],
                                                  int wave, int lane, bool alt_prio) {
     constexpr bool C16 = (CIN == 16);
+    constexpr int TERMS = LI::TERMS;                                       // 3: bf16 terms, six products; 2: fp16 terms, three products (w_h a_h, w_l a_h, w_h a_l)
     constexpr int HOUT = LI::H / STRIDE, WOUT = LI::W / STRIDE;
     constexpr int MT = HOUT * WOUT / 16, NT = COUT / 16;
     constexpr int MG = MT / TM, NG = NT / TN;
     constexpr int NG32 = C16 ? 1 : CIN / 32, NS = C16 ? 5 : 9 * NG32;
-    static_assert(MG * NG == NW && (C16 || CIN % 32 == 0) && LI::C == CIN, "bad tiling for the split-operand loop");
+    static_assert(MG * NG == NW && (C16 || CIN % 32 == 0) && LI::C == CIN && (TERMS == 2 || TERMS == 3), "bad tiling for the split-operand loop");
     const int mg = wave % MG;
     const int m = lane & 15, kq = lane >> 4;
     int a_lane;                                                            // bytes
@@ -715,7 +771,7 @@ __device__ __forceinline__ void conv3x3_mfma_s3q(const float* act, const float* 
     const unsigned a_addr0 = lds_byte_addr(act) + a_lane;
     auto a_imm = [](int i) { return LI::CELL * (WOUT == 8 ? i * 2 * STRIDE * LI::WP : (((i * 16) / WOUT) * STRIDE * LI::WP + ((i * 16) % WOUT) * STRIDE)); };
     static_assert(LI::CELL * ((TM - 1) * 2 * STRIDE * LI::WP + 2 * STRIDE * LI::WP) + 32 < 65536, "tile immediates must fit the DS offset field");
-    constexpr int WS_FLOATS = (C16 ? 5 : 9 * NG32) * 3 * 4 * COUT * 4;
+    constexpr int WS_FLOATS = (C16 ? 5 : 9 * NG32) * TERMS * 4 * COUT * 4;
     const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(Ws, WS_FLOATS);
     const int w_lane = s3_w_lane<NW, COUT, MG, TN>(wave, lane);
 #pragma unroll
@@ -732,7 +788,7 @@ __device__ __forceinline__ void conv3x3_mfma_s3q(const float* act, const float* 
         const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
         return a_addr0 + 4 * G * LI::GS + (ky * LI::WP + kx) * LI::CELL;
     };
-    bf16x8 a[TM][3];
+    bf16x8 a[TM][TERMS];
     S3W<TN> wb[2];
     wb[0] = w_first;
     {
@@ -740,14 +796,14 @@ __device__ __forceinline__ void conv3x3_mfma_s3q(const float* act, const float* 
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int t = 0; t < 3; ++t) a[i][t] = __builtin_bit_cast(bf16x8, lds_read4(ab + a_imm(i) + t * 16));
+            for (int t = 0; t < TERMS; ++t) a[i][t] = __builtin_bit_cast(bf16x8, lds_read4(ab + a_imm(i) + t * 16));
     }
     auto pair_mfma = [&](const S3W<TN>& wc, int tw, int ta) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wc.w[tw][j], a[i][ta], acc[i][j], 0, 0, 0);
+                acc[i][j] = split_mfma<TERMS>(wc.w[tw][j], a[i][ta], acc[i][j]);
                 if constexpr ((PROBE >> 4) != 0) __builtin_amdgcn_sched_barrier(0);
                 if constexpr ((PROBE >> 4) != 0) asm volatile("s_nop %0" ::"n"((PROBE >> 4) - 1));
                 if constexpr ((PROBE >> 4) != 0) __builtin_amdgcn_sched_barrier(0);
@@ -757,6 +813,40 @@ __device__ __forceinline__ void conv3x3_mfma_s3q(const float* act, const float* 
         if constexpr (PROBE & 2) return;
 #pragma unroll
         for (int i = 0; i < TM; ++i) a[i][t] = __builtin_bit_cast(bf16x8, lds_read4(ab + a_imm(i) + t * 16));
+    };
+    constexpr int NT_ = TM * TN;
+    // the term pairs of one step in term-major order, every activation term reloaded (for the next step) right after its last use;
+    // then the pinned interleaving: NLEAD weight loads, one after each of the first MFMAs, and the fragment reads where their registers die
+    auto pairs = [&](const S3W<TN>& wc, unsigned ab, bool load_next) {
+        if constexpr (TERMS == 3) {
+            pair_mfma(wc, 0, 0); pair_mfma(wc, 1, 0); pair_mfma(wc, 2, 0);
+            if (load_next) reload(ab, 0);
+            pair_mfma(wc, 0, 1); pair_mfma(wc, 1, 1);
+            if (load_next) reload(ab, 1);
+            pair_mfma(wc, 0, 2);
+            if (load_next) reload(ab, 2);
+        } else {
+            pair_mfma(wc, 0, 0); pair_mfma(wc, 1, 0);
+            if (load_next) reload(ab, 0);
+            pair_mfma(wc, 0, 1);
+            if (load_next) reload(ab, 1);
+        }
+    };
+    auto pin = [&](auto n_lead_c) {
+        constexpr int n_lead = decltype(n_lead_c)::v;
+#pragma unroll
+        for (int l = 0; l < n_lead; ++l) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, TERMS * NT_ - n_lead, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+        if constexpr (TERMS == 3) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT_, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, NT_, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
     };
     // one step: weights of step s_next requested first (spread between the first MFMAs), fragments of s_next as the terms retire
     const int wave_hi = __builtin_amdgcn_readfirstlane(wave >> 2);      // scalar: the priority switch below must not become a divergent branch
@@ -772,31 +862,21 @@ __device__ __forceinline__ void conv3x3_mfma_s3q(const float* act, const float* 
         unsigned ab = frag_addr(s_next);
         asm("" : "+v"(ab));
         if constexpr (PROBE & 1) { if (load_next) wn = wc; }
-        else { if (load_next) s3_load_w<COUT, TN>(wn, wrsrc, w_lane, s_next); }
-        constexpr int NT_ = TM * TN;
-        pair_mfma(wc, 0, 0); pair_mfma(wc, 1, 0); pair_mfma(wc, 2, 0);
-        if (load_next) reload(ab, 0);
-        pair_mfma(wc, 0, 1); pair_mfma(wc, 1, 1);
-        if (load_next) reload(ab, 1);
-        pair_mfma(wc, 0, 2);
-        if (load_next) reload(ab, 2);
-        // pin the interleaving: one weight load after each of the first 3 TN MFMAs, the fragment reads where their registers die
-        if (load_next && PROBE == 0) {
-#pragma unroll
-            for (int l = 0; l < 3 * TN; ++l) {
-                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
-            }
-            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NT_ - 3 * TN, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT_, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, NT_, 0);
-            __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
-        }
+        else { if (load_next) s3_load_w<COUT, TN, TERMS>(wn, wrsrc, w_lane, s_next); }
+        pairs(wc, ab, load_next);
+        if (load_next && PROBE == 0) pin(IntC<TERMS * TN>{});
         __builtin_amdgcn_sched_barrier(0);
     };
-    static_assert(3 * TN <= 3 * TM * TN, "weight loads are spread over the first term pairs");
+    static_assert(TERMS * TN <= TERMS * TM * TN, "weight loads are spread over the first term pairs");
+    auto finish = [&]() {
+        if constexpr (TERMS == 2) {           // the two-term weights are packed times 2^e (fp16 range): undo it, exactly
+            const float osc = Ws[WS_FLOATS];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] *= osc;
+        }
+    };
     if constexpr (C16) {
         // 16 input channels (5 steps, fully unrolled; AffNet / OriNet conv1, conv2 at 128 VGPRs and four waves per SIMD): ONE weight set,
         // the next step's fragments are requested when the current step's last term pair has been issued - the other waves of the SIMD
@@ -806,26 +886,19 @@ __device__ __forceinline__ void conv3x3_mfma_s3q(const float* act, const float* 
             const bool more = s + 1 < NS;
             unsigned ab = frag_addr(more ? s + 1 : s);
             asm("" : "+v"(ab));
-            constexpr int NT_ = TM * TN;
-            pair_mfma(wb[0], 0, 0); pair_mfma(wb[0], 1, 0); pair_mfma(wb[0], 2, 0);
-            if (more) reload(ab, 0);
-            pair_mfma(wb[0], 0, 1); pair_mfma(wb[0], 1, 1);
-            if (more) reload(ab, 1);
-            pair_mfma(wb[0], 0, 2);
+            pairs(wb[0], ab, more);
             if (more) {
-                reload(ab, 2);
-                __builtin_amdgcn_sched_group_barrier(0x008, 3 * NT_, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, 2 * NT_, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
-                __builtin_amdgcn_sched_group_barrier(0x008, NT_, 0);
-                __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+                pin(IntC<0>{});
                 __builtin_amdgcn_sched_barrier(0);
-                s3_load_w<COUT, TN>(wb[0], wrsrc, w_lane, s + 1);
+                s3_load_w<COUT, TN, TERMS>(wb[0], wrsrc, w_lane, s + 1);
             }
         }
+        finish();
         return;
     }
+    // (Tried for the two-term loops, whose steps have half the matrix time to cover the L2 round trip of the weight fragments: weights requested TWO steps
+    // ahead through three rotating sets.  profiles/r04_s4_s3_loop_probe_split2h_prefetch_depth.txt: -4 .. +2.5 % per layer shape, HardNet trunk 9.08 vs 9.13 ms
+    // per 48000 patches at 255 instead of 190 VGPRs - the weights are not what these loops wait for.  Removed.)
 #pragma unroll 1
     for (int s = 0; s + 2 < NS; s += 2) {
         step(wb[0], wb[1], s + 1, true);
@@ -838,6 +911,7 @@ __device__ __forceinline__ void conv3x3_mfma_s3q(const float* act, const float* 
         step(wb[1], wb[0], NS - 1, false);
     }
     if (alt_prio) __builtin_amdgcn_s_setprio(0);
+    finish();
 }
 
 // The same into a term-interleaved layout (LayQ).

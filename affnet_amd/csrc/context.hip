@@ -113,7 +113,7 @@ extern "C" int affnet_host_base_grid(int ps, float* out) {  // exported for the 
 static int validate(affnet_ctx* ctx, const affnet_config* c) {
     if (c->height < 8 || c->width < 8) return aff_fail(ctx, AFFNET_ERR_INVALID, "image %dx%d too small", c->height, c->width);
     if (c->batch > 4096) return aff_fail(ctx, AFFNET_ERR_INVALID, "batch=%d (max 4096)", c->batch);
-    if (c->arith != AFFNET_ARITH_FP32_MFMA && c->arith != AFFNET_ARITH_FP32_SPLIT3) return aff_fail(ctx, AFFNET_ERR_INVALID, "arith=%d (AFFNET_ARITH_*)", c->arith);
+    if (c->arith < AFFNET_ARITH_FP32_MFMA || c->arith > AFFNET_ARITH_FP32_SPLIT2H) return aff_fail(ctx, AFFNET_ERR_INVALID, "arith=%d (AFFNET_ARITH_*)", c->arith);
     if (c->n_octaves < 1 || c->n_octaves > AFFNET_MAX_OCTAVES) return aff_fail(ctx, AFFNET_ERR_INVALID, "n_octaves=%d", c->n_octaves);
     if (c->levels_per_octave < 3 || c->levels_per_octave > AFFNET_MAX_LEVELS)
         return aff_fail(ctx, AFFNET_ERR_INVALID, "levels_per_octave=%d", c->levels_per_octave);
@@ -219,7 +219,7 @@ extern "C" void affnet_ctx_destroy(affnet_ctx* ctx) { delete ctx; }
 
 extern "C" int affnet_set_arith(affnet_ctx* ctx, int arith) {
     if (!ctx) return AFFNET_ERR_INVALID;
-    if (arith != AFFNET_ARITH_FP32_MFMA && arith != AFFNET_ARITH_FP32_SPLIT3) return aff_fail(ctx, AFFNET_ERR_INVALID, "arith=%d (AFFNET_ARITH_*)", arith);
+    if (arith < AFFNET_ARITH_FP32_MFMA || arith > AFFNET_ARITH_FP32_SPLIT2H) return aff_fail(ctx, AFFNET_ERR_INVALID, "arith=%d (AFFNET_ARITH_*)", arith);
     ctx->arith = arith;
     ctx->cfg.arith = arith;
     return AFFNET_OK;

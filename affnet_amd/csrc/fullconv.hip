@@ -254,7 +254,7 @@ __global__ __launch_bounds__(512, 4) void dense_conv_s3_kernel(DenseArgs a) {
     const int X0 = blockIdx.x * TWD, Y0 = blockIdx.y * TH;              // input-tile origin
     S3W<TN> w0;
     f32x4 bias[TN];
-    s3_prefetch_w0<NW, CIN, COUT, HOUT * WOUT / 16, TM, TN>(a.W, w0, wave, lane);
+    s3_prefetch_w0<NW, CIN, COUT, HOUT * WOUT / 16, TM, TN, LQ::TERMS>(a.W, w0, wave, lane);
     {
         constexpr int MG = (HOUT * WOUT / 16) / TM;                       // rectangular tile: the wave's N-tile group is wave / MG
 #pragma unroll
@@ -270,14 +270,7 @@ __global__ __launch_bounds__(512, 4) void dense_conv_s3_kernel(DenseArgs a) {
         f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (Y >= 0 && Y < a.Hin && X >= 0 && X < a.Win) v = *reinterpret_cast<const f32x4*>(in + g * plane + ((size_t)Y * a.Win + X) * 4);
         char* dst = actb + (g >> 1) * LQ::GS + (ty * LQ::WP + tx) * LQ::CELL + (g & 1) * 8;
-        f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
-#pragma unroll
-        for (int t = 0; t < 3; ++t) {
-            const unsigned u0 = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
-            const unsigned u1 = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
-            *reinterpret_cast<uint2*>(dst + t * 16) = make_uint2(u0, u1);
-            if (t < 2) { split_remainder(lo, u0); split_remainder(hi, u1); }
-        }
+        split_store4<LQ::TERMS>(dst, v);
     }
     __syncthreads();
     f32x4 acc[TM][TN];
@@ -428,32 +421,33 @@ int aff_fullconv_launch(affnet_ctx* ctx, const float* packed, const float* img, 
     layer(0, norm, bufA, g.Hp, g.Wp, g.Hp, g.Wp);
     hipLaunchKernelGGL(dense_conv0_kernel, dim3(aff_cdiv(g.Wp, 32), aff_cdiv(g.Hp, 32), B), dim3(512), 0, st, a);
     AFF_LAUNCH_CHECK(ctx);
-    if (ctx->arith == AFFNET_ARITH_FP32_SPLIT3) {
-        // conv1 .. conv5 on split operands (three bf16 terms per fp32 operand, six bf16 MFMAs per product, fp32 accumulate)
+    if (ctx->arith == AFFNET_ARITH_FP32_SPLIT3 || ctx->arith == AFFNET_ARITH_FP32_SPLIT2H) {
+        // conv1 .. conv5 on split operands: three bf16 terms per fp32 operand and six bf16 MFMAs per product, or (SPLIT2H) two fp16 terms and three
+        // fp16 MFMAs; fp32 accumulate
+        const bool h2 = ctx->arith == AFFNET_ARITH_FP32_SPLIT2H;
         auto layer3 = [&](int i, const float* in, float* o, int Hin, int Win, int Hout, int Wout) {
             layer(i, in, o, Hin, Win, Hout, Wout);
-            a.W = packed + L.w_s3[i];
+            a.W = packed + (h2 ? L.w_h2[i] : L.w_s3[i]);
         };
         // (register blockings as in the per-patch split trunks: one channel tile per wave for conv3 / conv4, tools/probes/s3_loop_probe)
-        typedef LayQ<16, 32, 34, 16> Q1;          // conv1 input tile: 16 rows x 32 columns, 16 channels (59 KB)
-        typedef LayQ<16, 32, 34, 16, 16> Q2;      // conv2 (stride 2) input tile
-        typedef LayQ<16, 16, 18, 32> Q3;          // conv3 / conv4 input tiles (61 KB)
-        typedef LayQ<8, 8, 16, 64, 128> Q5;       // conv5 input tile (61 KB)
+        // Q1: conv1 input tile, 16 rows x 32 columns, 16 channels (59 KB); Q2: conv2 (stride 2); Q3: conv3 / conv4 input tiles (61 KB); Q5: conv5 (61 KB)
+#define DENSE_S3(CI, CO, STR, H_, W_, WP_, GREM, TM_, TN_, GX, GY)                                                                                 \
+        do {                                                                                                                                     \
+            if (h2) hipLaunchKernelGGL((dense_conv_s3_kernel<CI, CO, STR, LayQ<H_, W_, WP_, CI, GREM, 2>, TM_, TN_>), dim3(GX, GY, B), dim3(512), 0, st, a); \
+            else hipLaunchKernelGGL((dense_conv_s3_kernel<CI, CO, STR, LayQ<H_, W_, WP_, CI, GREM, 3>, TM_, TN_>), dim3(GX, GY, B), dim3(512), 0, st, a);  \
+            AFF_LAUNCH_CHECK(ctx);                                                                                                               \
+        } while (0)
         layer3(1, bufA, bufB, g.Hp, g.Wp, g.Hp, g.Wp);
-        hipLaunchKernelGGL((dense_conv_s3_kernel<16, 16, 1, Q1, 4, 1>), dim3(aff_cdiv(g.Wp, 32), aff_cdiv(g.Hp, 16), B), dim3(512), 0, st, a);
-        AFF_LAUNCH_CHECK(ctx);
+        DENSE_S3(16, 16, 1, 16, 32, 34, 0, 4, 1, aff_cdiv(g.Wp, 32), aff_cdiv(g.Hp, 16));
         layer3(2, bufB, bufA, g.Hp, g.Wp, g.H2, g.W2);
-        hipLaunchKernelGGL((dense_conv_s3_kernel<16, 32, 2, Q2, 2, 1>), dim3(aff_cdiv(g.Wp, 32), aff_cdiv(g.Hp, 16), B), dim3(512), 0, st, a);
-        AFF_LAUNCH_CHECK(ctx);
+        DENSE_S3(16, 32, 2, 16, 32, 34, 16, 2, 1, aff_cdiv(g.Wp, 32), aff_cdiv(g.Hp, 16));
         layer3(3, bufA, bufB, g.H2, g.W2, g.H2, g.W2);
-        hipLaunchKernelGGL((dense_conv_s3_kernel<32, 32, 1, Q3, 4, 1>), dim3(aff_cdiv(g.W2, 16), aff_cdiv(g.H2, 16), B), dim3(512), 0, st, a);
-        AFF_LAUNCH_CHECK(ctx);
+        DENSE_S3(32, 32, 1, 16, 16, 18, 0, 4, 1, aff_cdiv(g.W2, 16), aff_cdiv(g.H2, 16));
         layer3(4, bufB, bufA, g.H2, g.W2, g.H4, g.W4);
-        hipLaunchKernelGGL((dense_conv_s3_kernel<32, 64, 2, Q3, 2, 1>), dim3(aff_cdiv(g.W2, 16), aff_cdiv(g.H2, 16), B), dim3(512), 0, st, a);
-        AFF_LAUNCH_CHECK(ctx);
+        DENSE_S3(32, 64, 2, 16, 16, 18, 0, 2, 1, aff_cdiv(g.W2, 16), aff_cdiv(g.H2, 16));
         layer3(5, bufA, bufB, g.H4, g.W4, g.H4, g.W4);
-        hipLaunchKernelGGL((dense_conv_s3_kernel<64, 64, 1, Q5, 2, 1>), dim3(aff_cdiv(g.W4, 8), aff_cdiv(g.H4, 8), B), dim3(512), 0, st, a);
-        AFF_LAUNCH_CHECK(ctx);
+        DENSE_S3(64, 64, 1, 8, 8, 16, 128, 2, 1, aff_cdiv(g.W4, 8), aff_cdiv(g.H4, 8));
+#undef DENSE_S3
     } else {
     layer(1, bufA, bufB, g.Hp, g.Wp, g.Hp, g.Wp);
     hipLaunchKernelGGL((dense_conv_kernel<16, 16, 1, LayC0, 8, 1, 1, true>), dim3(aff_cdiv(g.Wp, 32), aff_cdiv(g.Hp, 32), B), dim3(512), 0, st, a);

@@ -50,6 +50,11 @@ PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; ~6
 GRAF = os.path.join(ROOT, "tests", "golden", "graf_img1.png")
 DTYPE_SPLIT3 = ("f32 (AFFNET_ARITH_FP32_SPLIT3: every fp32 operand of the CNN contractions as three bf16 terms, six v_mfma_f32_16x16x32_bf16 per "
                 "product, fp32 accumulate; conv0, the AffNet / OriNet heads and everything outside the CNNs plain fp32)")
+DTYPE_SPLIT2H = ("f32 (AFFNET_ARITH_FP32_SPLIT2H: every fp32 operand of the CNN contractions as two fp16 terms (|x - h - l| <= 2^-23 |x|), three "
+                 "v_mfma_f32_16x16x32_f16 per product, fp32 accumulate; conv0, the AffNet / OriNet heads and everything outside the CNNs plain fp32)")
+# the split arithmetic modes of the boundary (include/affnet_hip.h): matrix instructions per fp32 product, labels
+SPLIT = {"fp32_split3": {"products": 6.0, "dtype": DTYPE_SPLIT3, "label": "CNN contractions on 3 x bf16 split operands", "insn": "6 x v_mfma_f32_16x16x32_bf16"},
+         "fp32_split2h": {"products": 3.0, "dtype": DTYPE_SPLIT2H, "label": "CNN contractions on 2 x fp16 split operands", "insn": "3 x v_mfma_f32_16x16x32_f16"}}
 
 
 # ----------------------------------------------------------------------------------------------------------------------
@@ -62,8 +67,8 @@ def pmc_traffic(images_per_launch, split=False):
     d = k = None
     for f in reversed(files):                  # newest evidence set that has the exact-fp32 HardNet trunk (its name gained template arguments over the rounds)
         d = json.load(open(f))
-        names = ("void cnn32_trunk_kernel<2, 8, false, true>",) if split else \
-                ("void cnn32_trunk_kernel<2, 8, false, false>", "void cnn32_trunk_kernel<2, 8, false>", "void cnn32_trunk_kernel<2, 8>")
+        names = ("void cnn32_trunk_kernel<2, 8, false, 3>", "void cnn32_trunk_kernel<2, 8, false, true>") if split else \
+                ("void cnn32_trunk_kernel<2, 8, false, 0>", "void cnn32_trunk_kernel<2, 8, false, false>", "void cnn32_trunk_kernel<2, 8, false>", "void cnn32_trunk_kernel<2, 8>")
         for name in names:
             k = d["kernels"].get(name)
             if k:
@@ -369,12 +374,13 @@ def main():
                          "seeds) and compares them bit for bit with what arrived through the exchange: right content, count and global order. "
                          "Default for N > 1: 'sample' (first and last image of every rank); 'all' checks every record; N = 1 with "
                          "AFFNET_BENCH_SELF_GATHER=1 checks the 1-rank RCCL path")
-    ap.add_argument("--arith", choices=("fp32", "fp32_split3"), default="fp32",
+    ap.add_argument("--arith", choices=("fp32", "fp32_split3", "fp32_split2h"), default="fp32",
                     help="arithmetic of the CNN contractions (include/affnet_hip.h AFFNET_ARITH_*): fp32 = exact fp32 MFMA (default, the headline "
-                         "`value`); fp32_split3 = fp32 operands as three bf16 terms on the bf16 matrix cores, fp32 accumulate - a separately "
-                         "labelled line with its own roofline against the bf16 peak")
+                         "`value`); fp32_split3 = fp32 operands as three bf16 terms (six products) on the bf16 matrix cores, fp32_split2h = two fp16 "
+                         "terms (three products) on the fp16 matrix cores, fp32 accumulate - separately labelled lines with their own roofline "
+                         "against the bf16 / fp16 peak")
     ap.add_argument("--split3", action="store_true", help="same as --arith fp32_split3")
-    ap.add_argument("--no-split3", action="store_true", help="skip the co-reported `arith_fp32_split3` steps of the default line")
+    ap.add_argument("--no-split3", action="store_true", help="skip the co-reported `arith_fp32_split3` / `arith_fp32_split2h` steps of the default line")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short BASELINE configs[1] (single-image latency) and configs[4] (4K) samples behind `other_configs`")
     ap.add_argument("--cpu-worker", default=None, help=argparse.SUPPRESS)        # child process of cpu_node_throughput()
@@ -384,7 +390,7 @@ def main():
     args = ap.parse_args()
     if args.split3:
         args.arith = "fp32_split3"
-    args.split3 = args.arith == "fp32_split3"
+    args.split3 = args.arith in SPLIT          # a split-operand mode is the line's arithmetic
     if args.cpu_worker:
         return cpu_worker(args.cpu_worker)
     if args.gpus < 1:
@@ -434,7 +440,7 @@ def config2_latency(args):
 
 def config2_measure(det, Hn, host, dev, n_lat, arith):
     """Warm single-image latency of `det` on the pinned host image `host` (eager calls, then the same call replayed as one HIP graph)."""
-    split3 = arith == "fp32_split3"
+    split3 = arith in SPLIT
     x = host.to(dev, non_blocking=True)
     r = det.run(x, do_ori=True, desc=Hn)
     torch.cuda.synchronize()
@@ -466,10 +472,10 @@ def config2_measure(det, Hn, host, dev, n_lat, arith):
     except Exception as e:                                      # noqa: BLE001  (reported in the line, the eager figures stand)
         gerr, same = repr(e), False
     out = {"metric": "latency per image (hesaffnet.py test-graf/img1.png, 2000 kp, detect+AffNet+OriNet+HardNet, B=1, H2D included)" +
-                     (" [arith fp32_split3: CNN contractions on 3 x bf16 split operands]" if split3 else ""),
+                     (" [arith %s: %s]" % (arith, SPLIT[arith]["label"]) if split3 else ""),
            "value": warm * 1e3, "unit": "ms", "n_gpus": 1, "steps": len(lat), "warmup": 1, "ms_per_step": warm * 1e3,
            "higher_is_better": False, "scaling": "weak", "vs_baseline": None,
-           "dtype": DTYPE_SPLIT3 if split3 else "f32",
+           "dtype": SPLIT[arith]["dtype"] if split3 else "f32",
            "data": "tests/golden/graf_img1.png (byte copy of test-graf/img1.png)",
            "config": {"workload": "BASELINE.json configs[1]: hesaffnet.py test-graf/img1.png 2000 kp, full path on 1 MI355X, single-image API "
                                   "(ScaleSpaceAffinePatchExtractor.run), %dx%d, pinned host image uploaded inside the timed call" % (host.size(3), host.size(2)),
@@ -771,14 +777,14 @@ def run(args, world):
         if H2D:
             metric += " [PCIe-inclusive: images uploaded from pinned host memory every step]"
         if args.split3:
-            metric += " [arith fp32_split3: CNN contractions on 3 x bf16 split operands]"
+            metric += " [arith %s: %s]" % (args.arith, SPLIT[args.arith]["label"])
         if ONEPASS:
             metric = "keypoints/sec (OnePassSIR: detect + dense AffNetFastFullConv per octave + OriNet + HardNet) per image, %d kp @%dx%d" % (NKP, W, H)
         out = {
             "metric": metric,
             "value": kps / tmax, "unit": "keypoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": tmax / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": DTYPE_SPLIT3 if args.split3 else "f32", "data": "synthetic",
+            "dtype": SPLIT[args.arith]["dtype"] if args.split3 else "f32", "data": "synthetic",
             "config": {"workload": "BASELINE.json configs[%d]: batch of %d synthetic %dx%d grayscale images per GPU per step, "
                                    "%d kp each, full path detect+AffNet+OriNet+HardNet; AffNet/OriNet shipped weights, "
                                    "HardNet seeded synthetic weights (HardNet++.pth is a missing blob)%s"
@@ -808,20 +814,21 @@ def run(args, world):
                          "affnet_tflops": aff_eval_per_img * FLOP_AFF / (max(stage_ms[2], 1e-9) * 1e-3) / 1e12,
                          "orinet_tflops": kp_per_img * FLOP_ORI / (max(stage_ms[4], 1e-9) * 1e-3) / 1e12},
         }
-        def split_roofline(launch_ms, fl_launch):
-            """HardNet trunk on split operands: SIX bf16 MFMA products per fp32 product (conv0 stays fp32) - priced against the bf16 peak."""
+        def split_roofline(launch_ms, fl_launch, mode):
+            """HardNet trunk on split operands: SIX bf16 / THREE fp16 MFMA products per fp32 product (conv0 stays fp32) - priced against the bf16 = fp16 peak."""
+            prod = SPLIT[mode]["products"]
             f_conv0 = kp_per_img * img_per_launch * 2.0 * 1024 * 9 * 32
-            bf16_tf = 6.0 * (fl_launch - f_conv0) / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
+            bf16_tf = prod * (fl_launch - f_conv0) / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
             eq = fl_launch / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
             tr, tr_note = pmc_traffic(img_per_launch, split=True)
-            return {"kernel": "cnn32_trunk_kernel<HardNet, split operands> (conv1..conv5: 6 x v_mfma_f32_16x16x32_bf16 per fp32 product, fp32 accumulate; conv0 fp32 MFMA)",
+            return {"kernel": "cnn32_trunk_kernel<HardNet, split operands> (conv1..conv5: %s per fp32 product, fp32 accumulate; conv0 fp32 MFMA)" % SPLIT[mode]["insn"],
                     "bound": "mfma", "achieved": bf16_tf, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": bf16_tf / PEAK_BF16_MFMA_TFLOPS,
                     "traffic": tr, "traffic_source": tr_note, "flops_per_launch": fl_launch, "launch_ms": launch_ms,
                     "fp32_equivalent_tflops": eq, "fp32_equivalent_vs_fp32_mfma_peak": eq / PEAK_FP32_MFMA_TFLOPS,
-                    "note": "executed bf16 matrix FLOPs (6 per algorithmic fp32 FLOP) against the dense bf16 MFMA peak"}
+                    "note": "executed 16-bit matrix FLOPs (%d per algorithmic fp32 FLOP) against the dense bf16 / fp16 MFMA peak" % int(prod)}
         if args.split3:
             keep = {k: out["roofline"][k] for k in ("all_cnn_tflops", "affnet_patches_evaluated_per_image", "affnet_tflops", "orinet_tflops")}
-            out["roofline"] = dict(split_roofline(trunk_ms, flops_launch), **keep)
+            out["roofline"] = dict(split_roofline(trunk_ms, flops_launch, args.arith), **keep)
         if exchange is not None:
             out["exchange"] = exchange
         if gather_check is not None:
@@ -835,39 +842,42 @@ def run(args, world):
         # Co-reported, NOT `value`: the same step in the other arithmetic mode of the boundary (AFFNET_ARITH_FP32_SPLIT3: every CNN contraction
         # on split operands, fp32 = three bf16 terms on the bf16 matrix cores, fp32 accumulate) - a few steps on the same contexts after
         # the timed region, with its own stage events, roofline (bf16 peak), dtype and parity_check
-        last_s3 = None
+        last_split = {}
         if world == 1 and not ONEPASS and not args.split3 and not args.no_split3:
-            try:
-                for d in dets.values():
-                    d.arith = "fp32_split3"                          # the extractor switches its context on the next call (same buffers)
-                n3 = 8
-                step(); step(); drain()
-                read_profile(keep_on=True)                           # discard the warm-up steps' events
-                kp_dev.zero_()
-                torch.cuda.synchronize()
-                w1, t1 = time.time(), time.perf_counter()
-                for _ in range(n3):
-                    last_s3 = step()
-                drain()
-                dt3 = time.perf_counter() - t1
-                gpu_sections.append({"what": "arith_fp32_split3 (%d steps)" % n3, "unix_start_s": w1, "unix_end_s": time.time()})
-                s3_sums, s3_calls, s3_imgs = read_profile(keep_on=True)
-                s3_stage = [v / max(s3_imgs, 1) for v in s3_sums]
-                out["arith_fp32_split3"] = {
-                    "value": int(kp_dev.item()) / dt3, "unit": "keypoints/s", "steps": n3, "ms_per_image": dt3 / (n3 * args.batch) * 1e3,
-                    "dtype": DTYPE_SPLIT3, "vs_value": int(kp_dev.item()) / dt3 / (kps / tmax),
-                    "stage_ms_per_image": dict(zip(names, [round(v, 4) for v in s3_stage])),
-                    "roofline": split_roofline(s3_sums[6] / max(s3_calls, 1), flops_launch),
-                    "note": "the other arithmetic mode of the boundary (affnet_config.arith / affnet_set_arith), never the headline: exact fp32 operands "
-                            "as three bf16 terms, six v_mfma_f32_16x16x32_bf16 per product; differs from the default path like one fp32 summation "
-                            "order from another (every full-path GPU test runs in both modes with the same bars)"}
-            except Exception as e:                                   # noqa: BLE001  (never at the expense of the main line)
-                out["arith_fp32_split3"] = {"error": repr(e)[:300]}
-                last_s3 = None
-            finally:
-                for d in dets.values():
-                    d.arith = args.arith
-                    d._ctx.set_arith(args.arith)
+            for mode in SPLIT:
+                key = "arith_" + mode
+                try:
+                    for d in dets.values():
+                        d.arith = mode                                   # the extractor switches its context on the next call (same buffers)
+                    n3 = 8
+                    step(); step(); drain()
+                    read_profile(keep_on=True)                           # discard the warm-up steps' events
+                    kp_dev.zero_()
+                    torch.cuda.synchronize()
+                    w1, t1 = time.time(), time.perf_counter()
+                    for _ in range(n3):
+                        last_split[mode] = step()
+                    drain()
+                    dt3 = time.perf_counter() - t1
+                    gpu_sections.append({"what": "%s (%d steps)" % (key, n3), "unix_start_s": w1, "unix_end_s": time.time()})
+                    s3_sums, s3_calls, s3_imgs = read_profile(keep_on=True)
+                    s3_stage = [v / max(s3_imgs, 1) for v in s3_sums]
+                    out[key] = {
+                        "value": int(kp_dev.item()) / dt3, "unit": "keypoints/s", "steps": n3, "ms_per_image": dt3 / (n3 * args.batch) * 1e3,
+                        "dtype": SPLIT[mode]["dtype"], "vs_value": int(kp_dev.item()) / dt3 / (kps / tmax),
+                        "stage_ms_per_image": dict(zip(names, [round(v, 4) for v in s3_stage])),
+                        "roofline": split_roofline(s3_sums[6] / max(s3_calls, 1), flops_launch, mode),
+                        "note": "another arithmetic mode of the boundary (affnet_config.arith / affnet_set_arith), never the headline: fp32 operands as "
+                                "%s, %s per product, fp32 accumulate; differs from the default path like one fp32 summation order from another (every "
+                                "full-path GPU test runs in all modes with the same bars)"
+                                % ("three bf16 terms (exact)" if mode == "fp32_split3" else "two fp16 terms (to 2^-23 relative)", SPLIT[mode]["insn"])}
+                except Exception as e:                                   # noqa: BLE001  (never at the expense of the main line)
+                    out[key] = {"error": repr(e)[:300]}
+                    last_split.pop(mode, None)
+                finally:
+                    for d in dets.values():
+                        d.arith = args.arith
+                        d._ctx.set_arith(args.arith)
         for d in dets.values():
             _lib.lib.affnet_profile_enable(d._ctx.handle, 0)
         # BASELINE configs[1] and configs[4] in the default line (short samples after the timed region; `--config2` / `--config5` are the full runs)
@@ -898,8 +908,9 @@ def run(args, world):
             kept = [(s, w) for s, w in kept if s < args.batch]
             if kept:
                 out["parity_check"] = parity_check(kept, fetcher(last))
-                if last_s3 is not None and "value" in out.get("arith_fp32_split3", {}):
-                    out["arith_fp32_split3"]["parity_check"] = parity_check(kept, fetcher(last_s3))
+                for mode, res_m in last_split.items():
+                    if "value" in out.get("arith_" + mode, {}):
+                        out["arith_" + mode]["parity_check"] = parity_check(kept, fetcher(res_m))
         wall["total_since_process_start_s"] = round(time.time() - T_START, 1)
         out["wall_s"] = wall
         print(json.dumps(out), flush=True)
@@ -957,9 +968,9 @@ def other_configs(nets, dev, arith, gpu_sections, with_cpu=True):
     fl = kp * (FLOP_HARD - FLOP_HARD_HEAD)
     tf = fl / (trunk_ms * 1e-3) / 1e12 if trunk_ms > 0 else 0.0
     traffic = config5_traffic()
-    split3 = arith == "fp32_split3"
+    split3 = arith in SPLIT
     peak = PEAK_BF16_MFMA_TFLOPS if split3 else PEAK_FP32_MFMA_TFLOPS
-    ach = 6.0 * (fl - kp * 2.0 * 1024 * 9 * 32) / (trunk_ms * 1e-3) / 1e12 if (split3 and trunk_ms > 0) else tf
+    ach = SPLIT[arith]["products"] * (fl - kp * 2.0 * 1024 * 9 * 32) / (trunk_ms * 1e-3) / 1e12 if (split3 and trunk_ms > 0) else tf
     out["config5_kp_s"] = kp * steps5 / dt
     out["config5_ms_per_image"] = dt / (steps5 * b5) * 1e3
     out["config5_stage_ms"] = dict(zip(names, [round(v, 4) for v in stage]))
@@ -985,7 +996,7 @@ def config5_traffic():
         return None
     d = json.load(open(files[-1]))
     ks = d.get("kernels", {})
-    trunk = next((v for k, v in ks.items() if "cnn32_trunk_kernel<2, 8, false, false>" in k), None)
+    trunk = next((v for k, v in ks.items() if "cnn32_trunk_kernel<2, 8, false, false>" in k or "cnn32_trunk_kernel<2, 8, false, 0>" in k), None)
     ss = {k.split("(")[0].replace("void ", "")[:60]: {"hbm_bytes_per_launch": v.get("hbm_bytes"), "fetch_bytes": v.get("fetch_bytes"), "write_bytes": v.get("write_bytes")}
           for k, v in ks.items() if "blur2d" in k or "hessian_nms" in k}
     return {"trunk_hbm_bytes_per_launch": trunk.get("hbm_bytes") if trunk else None, "scale_space": ss,

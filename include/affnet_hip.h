@@ -68,9 +68,23 @@ extern "C" {
  *                 fp32 accumulator), accumulated in fp32.  Operands stay fp32 at every interface (weights, activations between layers,
  *                 outputs); the dropped terms are <= 2^-24 relative per product, i.e. this is another fp32 summation, not narrower
  *                 arithmetic (K = 8192 dot product: 2.6e-7 of sum|a||b| vs 2.1e-7 for the fmaf chain).  Results
- *                 differ from FP32_MFMA by summation order only (descriptors ~1e-6); the parity bars are the same for both modes. */
+ *                 differ from FP32_MFMA by summation order only (descriptors ~1e-6); the parity bars are the same for both modes.
+ *   FP32_SPLIT2H: every fp32 operand x is carried as x ~ h + l with h = fp16(x), l = fp16(x - h) (round to nearest even both; x - h is
+ *                 exact): 11 + 11 significand bits + the sign of the remainder = 23 of fp32's 24 bits, |x - h - l| <= 2^-23 |x| (rms
+ *                 ~2^-25).  A product w * a is the THREE fp16 products w_h a_h + w_l a_h + w_h a_l on v_mfma_f32_16x16x32_f16 (each exact
+ *                 in the fp32 accumulator; the dropped w_l a_l is <= 2^-24 relative), accumulated in fp32 - half the matrix instructions
+ *                 of FP32_SPLIT3.  NOT bit-faithful fp32 operands like FP32_SPLIT3, but the same error class as an fp32 summation: a
+ *                 K-term dot product against fp64 on the same data: 2.0e-8 rms of sum|w||a| vs 3.6e-8 for the fmaf chain of FP32_MFMA
+ *                 and 2.4e-8 for FP32_SPLIT3 (the accumulation roundings dominate all three).  fp16 has a 5-bit
+ *                 exponent, so the weights of a layer are packed times a power of two 2^e that puts the layer's largest |w| into
+ *                 [2^13, 2^14) and the layer's sums are multiplied by 2^-e (both exact); activations are used as they are: |a| < 65504
+ *                 is REQUIRED (the reference's nets are BatchNorm-ed, |a| stays below ~50; a larger value becomes inf and the output
+ *                 NaN - it does not pass silently) and an activation below 2^-14 keeps an ABSOLUTE error of 2^-25 instead of a relative
+ *                 one (subnormal fp16 operands are honoured by the MFMA, tools/probes/f16_split_probe.hip).  Same interfaces (fp32
+ *                 everywhere), same parity bars. */
 #define AFFNET_ARITH_FP32_MFMA 0
 #define AFFNET_ARITH_FP32_SPLIT3 1
+#define AFFNET_ARITH_FP32_SPLIT2H 2
 
 typedef struct affnet_ctx affnet_ctx;
 
@@ -132,7 +146,7 @@ const char* affnet_last_error(const affnet_ctx* ctx);
 /* Library / build identification, e.g. "affnet_hip 0.1 gfx950". */
 const char* affnet_version(void);
 /* Arithmetic mode (AFFNET_ARITH_*) of the CNN contractions launched through this context from now on (utility contexts too).  The
- * packed weight blobs serve both modes; switching back to AFFNET_ARITH_FP32_MFMA restores the default path bit for bit.  A graph
+ * packed weight blobs serve all modes; switching back to AFFNET_ARITH_FP32_MFMA restores the default path bit for bit.  A graph
  * captured earlier (affnet_graph_capture_extract) keeps the mode it was captured with. */
 int affnet_set_arith(affnet_ctx* ctx, int arith);
 int affnet_get_arith(const affnet_ctx* ctx);

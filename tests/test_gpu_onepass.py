@@ -70,7 +70,7 @@ def test_local_norm_exact(amd, golden_dir):
 _DENSE_ORACLE = {}
 
 
-@pytest.mark.parametrize("arith", ["fp32", "fp32_split3"])
+@pytest.mark.parametrize("arith", ["fp32", "fp32_split3", "fp32_split2h"])
 def test_dense_affnet_map(amd, nets, weights, golden_dir, arith):
     FC = nets[0]
     g = np.load(os.path.join(golden_dir, "onepass_synth.npz"))
@@ -112,7 +112,7 @@ def test_nms2d(amd):
         assert int((got > 0).sum()) > 10
 
 
-ARITH = ["fp32", "fp32_split3"]        # include/affnet_hip.h AFFNET_ARITH_*: both modes run the end-to-end cases with the same bars
+ARITH = ["fp32", "fp32_split3", "fp32_split2h"]        # include/affnet_hip.h AFFNET_ARITH_*: all modes run the end-to-end cases with the same bars
 _ORACLE_RUNS = {}
 
 

@@ -29,7 +29,7 @@ from conftest import load_gray, record_parity
 pytestmark = pytest.mark.gpu
 
 DEV = "cuda:0"
-ARITH = ["fp32", "fp32_split3"]        # include/affnet_hip.h AFFNET_ARITH_FP32_MFMA (default) / AFFNET_ARITH_FP32_SPLIT3
+ARITH = ["fp32", "fp32_split3", "fp32_split2h"]        # include/affnet_hip.h AFFNET_ARITH_FP32_MFMA (default) / AFFNET_ARITH_FP32_SPLIT3 / AFFNET_ARITH_FP32_SPLIT2H
 
 
 def _laf_bar(Lw, ori_norm=None):
@@ -1132,18 +1132,23 @@ def test_many_exact_ties_stay_cheap_and_deterministic(amd):
         assert c.max() >= 8 and dt < 0.5, (int(c.max()), dt)       # groups of equal responses inside the selection; the cut falls inside one
 
 
-def test_split3_mode_vs_the_exact_path_and_back(amd, nets):
-    """AFFNET_ARITH_FP32_SPLIT3 (include/affnet_hip.h; the extractor's `arith` kwarg): the contractions of conv1 .. conv5 of the three trunks
-    and of the HardNet head as six bf16 MFMAs per fp32 product, fp32 accumulate.  Distance of the whole path to the exact-fp32 path on one
-    image, and the switch itself: the same extractor object, flipped to split3 and back, returns the exact path's bits again."""
+SPLIT_MODES = [("fp32_split3", 1), ("fp32_split2h", 2)]
+
+
+@pytest.mark.parametrize("mode,code", SPLIT_MODES)
+def test_split_modes_vs_the_exact_path_and_back(amd, nets, mode, code):
+    """AFFNET_ARITH_FP32_SPLIT3 / AFFNET_ARITH_FP32_SPLIT2H (include/affnet_hip.h; the extractor's `arith` kwarg): the contractions of conv1 ..
+    conv5 of the three trunks and of the HardNet head as six bf16 MFMAs (three bf16 terms per operand) or three fp16 MFMAs (two fp16 terms) per
+    fp32 product, fp32 accumulate.  Distance of the whole path to the exact-fp32 path on one image, and the switch itself: the same extractor
+    object, flipped to the split mode and back, returns the exact path's bits again."""
     A, O, H = nets
     x = orc.synthetic_image(240, 320, 1).to(DEV)
     det = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=1, AffNet=A, OriNet=O).to(DEV)
     exact = det.run(x, do_ori=True, desc=H)
     ctx0 = det._ctx
-    det.arith = "fp32_split3"
+    det.arith = mode
     split = det.run(x, do_ori=True, desc=H)
-    assert det._ctx is ctx0 and det._ctx.arith == 1, "switching the arithmetic must not rebuild the context"
+    assert det._ctx is ctx0 and det._ctx.arith == code, "switching the arithmetic must not rebuild the context"
     det.arith = "fp32"
     again = det.run(x, do_ori=True, desc=H)
     for k in ("LAFs", "responses", "descriptors", "ids"):
@@ -1151,15 +1156,16 @@ def test_split3_mode_vs_the_exact_path_and_back(amd, nets):
     gi, wi = _match(split["ids"].cpu().numpy(), exact["ids"].cpu().numpy())
     dl = float((split["LAFs"][gi] - exact["LAFs"][wi]).abs().max())
     dd = float((split["descriptors"][gi] - exact["descriptors"][wi]).abs().max())
-    record_parity("arith fp32_split3 vs the exact-fp32 path, 320x240, 300 kp", matched=int(len(gi)), rows=int(exact["LAFs"].shape[0]), laf_max_px=dl, desc_max=dd)
-    print("split3 vs exact fp32 path: %d / %d rows, LAF max %.3g px, descriptor max %.3g" % (len(gi), exact["LAFs"].shape[0], dl, dd))
+    record_parity("arith %s vs the exact-fp32 path, 320x240, 300 kp" % mode, matched=int(len(gi)), rows=int(exact["LAFs"].shape[0]), laf_max_px=dl, desc_max=dd)
+    print("%s vs exact fp32 path: %d / %d rows, LAF max %.3g px, descriptor max %.3g" % (mode, len(gi), exact["LAFs"].shape[0], dl, dd))
     assert len(gi) >= 299 and dd > 0.0 and dd < 1e-4 and dl < 1e-3
     with pytest.raises(ValueError):
         amd.ScaleSpaceAffinePatchExtractor(arith="bf16")
 
 
-def test_split3_trunks_vs_exact_trunks(amd, nets):
-    """Each net alone on random patches (incl. a ragged count), arith fp32_split3 vs the exact fp32 MFMA path: the two differ like one fp32
+@pytest.mark.parametrize("mode,code", SPLIT_MODES)
+def test_split_trunks_vs_exact_trunks(amd, nets, mode, code):
+    """Each net alone on random patches (incl. a ragged count), split arithmetic vs the exact fp32 MFMA path: the two differ like one fp32
     summation order from another.  Catches layout slips of the pre-split / half-patch layers (halo rows, the conv1 row kept for the second
     conv2 pass) and of the split head GEMM that a loose end-to-end bar could hide."""
     A, O, H = nets
@@ -1170,7 +1176,7 @@ def test_split3_trunks_vs_exact_trunks(amd, nets):
             p[0, 0, :16] = 0.0                                            # a half-constant patch: exact zeros through ReLU in one half
             exact = [net(p).clone() for net in (A, O, H)]
             for net in (A, O, H):
-                net.arith = "fp32_split3"
+                net.arith = mode
             split = [net(p).clone() for net in (A, O, H)]
             for net in (A, O, H):
                 net.arith = "fp32"
@@ -1178,7 +1184,7 @@ def test_split3_trunks_vs_exact_trunks(amd, nets):
             # OriNet returns the rotation of atan2(o): a short output vector o amplifies a 1e-7 difference (same effect as in the parity report)
             for nm, e, s_, a2, bar in zip(("AffNet", "OriNet", "HardNet"), exact, split, again, (2e-5, 5e-3, 1e-5)):
                 d = float((e - s_).abs().max())
-                record_parity("arith fp32_split3 vs exact: %s alone, %d random patches" % (nm, n), max_abs=d)
+                record_parity("arith %s vs exact: %s alone, %d random patches" % (mode, nm, n), max_abs=d)
                 assert torch.equal(e, a2), "switching the arithmetic back must restore the exact path bit for bit"
                 assert 0.0 < d < bar or (n == 1 and d < bar), (nm, n, d)
     finally:

@@ -89,7 +89,12 @@ def test_arith_mode_is_part_of_the_boundary():
     from affnet_amd.host_plan import PyramidPlan
     hdr = open(os.path.join(ROOT, "include", "affnet_hip.h")).read()
     assert re.search(r"#define AFFNET_ARITH_FP32_MFMA 0\b", hdr) and re.search(r"#define AFFNET_ARITH_FP32_SPLIT3 1\b", hdr)
-    assert (_lib.ARITH_FP32_MFMA, _lib.ARITH_FP32_SPLIT3) == (0, 1)
+    assert re.search(r"#define AFFNET_ARITH_FP32_SPLIT2H 2\b", hdr)
+    assert (_lib.ARITH_FP32_MFMA, _lib.ARITH_FP32_SPLIT3, _lib.ARITH_FP32_SPLIT2H) == (0, 1, 2)
+    h = C.c_void_p()
+    assert _lib.lib.affnet_ctx_create(C.byref(h), 0, C.byref(PyramidPlan(240, 320).fill_config(5.192, 0.0, 300, 450, arith=2))) == 0
+    assert _lib.lib.affnet_get_arith(h) == 2 and _lib.lib.affnet_set_arith(h, 0) == 0 and _lib.lib.affnet_set_arith(h, 2) == 0 and _lib.lib.affnet_get_arith(h) == 2
+    _lib.lib.affnet_ctx_destroy(h)
     for cfg_arith in (0, 1):
         cfg = PyramidPlan(240, 320).fill_config(5.192, 0.0, 300, 450, arith=cfg_arith)
         h = C.c_void_p()
@@ -107,7 +112,7 @@ def test_arith_mode_is_part_of_the_boundary():
     u = C.c_void_p()                                                      # utility context (cfg == NULL): default exact fp32
     assert _lib.lib.affnet_ctx_create(C.byref(u), 0, None) == 0 and _lib.lib.affnet_get_arith(u) == 0
     _lib.lib.affnet_ctx_destroy(u)
-    assert _lib.arith_code("fp32") == 0 and _lib.arith_code("fp32_split3") == 1 and _lib.arith_code(None) == 0
+    assert _lib.arith_code("fp32") == 0 and _lib.arith_code("fp32_split3") == 1 and _lib.arith_code("fp32_split2h") == 2 and _lib.arith_code(None) == 0
     with pytest.raises(ValueError):
         _lib.arith_code("bf16")
     with pytest.raises(ValueError):
@@ -131,7 +136,7 @@ def test_no_product_kernel_spills_registers():
     assert not bad, bad
     h5 = [k for k in ks.values() if "hessian_nms_kernelILi5E" in k["name"]][0]
     assert h5["group_segment_fixed_size"] == 52520 and kr.workgroups_per_cu(h5) == 3, h5      # three workgroups per CU by LDS AND by registers
-    trunk = [k for k in ks.values() if "cnn32_trunk_kernelILi2ELi8ELb0ELb0E" in k["name"]][0]
+    trunk = [k for k in ks.values() if "cnn32_trunk_kernelILi2ELi8ELb0ELi0E" in k["name"]][0]
     assert trunk["group_segment_fixed_size"] <= 160 * 1024 and kr.workgroups_per_cu(trunk) == 1
 
 
@@ -338,6 +343,40 @@ def test_split_weight_copies_are_exact(kind, name, weights):
         mag = np.abs(t)
         assert np.all(mag[1] <= mag[0] * 2.0 ** -8 + 1e-45) and np.all(mag[2] <= mag[1] * 2.0 ** -8 + 1e-45)
         off += n_fl
+    # AFFNET_ARITH_FP32_SPLIT2H: the same layers once more as TWO fp16 terms of 2^e w, e per layer such that the largest |w| lands in [2^13, 2^14);
+    # same fragment orders with two terms, then 4 floats whose first is 2^-e.  hi + lo must reproduce 2^e w to 2^-23 relative (23 of fp32's
+    # 24 significand bits), hi must be the nearest fp16 of 2^e w, lo at most half an ulp of hi (a remainder below 2^-14 is a subnormal fp16: absolute error 2^-25, which the scale
+    # makes 2^-38 of the layer's largest weight).
+    halves = blob.numpy().view(np.float16)
+
+    def check_h2(W, t, inv_scale, what):
+        scale = 1.0 / float(inv_scale)
+        assert scale == 2.0 ** round(np.log2(scale)), (what, scale)
+        Ws = W * scale
+        assert 2.0 ** 13 <= np.abs(Ws).max() < 2.0 ** 14, (what, float(np.abs(Ws).max()))
+        assert np.array_equal(t[0], Ws.astype(np.float32).astype(np.float16).astype(np.float64)), what + ": hi is not fp16(2^e w)"
+        err = np.abs(t[0] + t[1] - Ws)
+        assert np.all(err <= np.abs(Ws) * 2.0 ** -23 + 2.0 ** -25), (what, float((err / np.maximum(np.abs(Ws), 1e-30)).max()))
+        assert np.all(np.abs(t[1]) <= np.abs(t[0]) * 2.0 ** -11 + 2.0 ** -24), what    # lo is at most half an ulp of hi
+
+    for i in range(1, 6):
+        W = layers[i][0].numpy().astype(np.float64)
+        co, ci = W.shape[:2]
+        n_fl = (5 if ci == 16 else 9 * (ci // 32)) * 2 * 4 * co * 4
+        terms = halves[2 * off: 2 * (off + n_fl)].astype(np.float64)
+        if ci == 16:
+            t = terms.reshape(5, 2, 2, 2, co, 8).transpose(1, 4, 3, 5, 0, 2).reshape(2, co, 16, 10)
+            assert np.all(t[..., 9] == 0.0), "the pad half-step must multiply zeros"
+            t = t[..., :9]
+        else:
+            t = terms.reshape(9, ci // 32, 2, 4, co, 8).transpose(2, 4, 1, 3, 5, 0).reshape(2, co, ci, 9)
+        check_h2(W, t.reshape(2, co, ci, 3, 3), blob.numpy()[off + n_fl], "%s conv%d" % (name, i))
+        off += n_fl + 4
+    if kind == 2:
+        n_fl = K * 128
+        t = halves[2 * off: 2 * (off + n_fl)].astype(np.float64).reshape(K // 32, 2, 4, 128, 8).transpose(1, 0, 2, 4, 3).reshape(2, K, 128)
+        check_h2(Wf, t, blob.numpy()[off + n_fl], "HardNet head")
+        off += n_fl + 4
     assert off == blob.numel(), (off, blob.numel())
 
 

@@ -104,19 +104,24 @@ def workgroups_per_cu(k):
 
 # the kernels DESIGN.md section 4 quotes figures for (substring of the demangled name -> label)
 DESIGN_KERNELS = [
-    ("cnn32_trunk_kernel<2, 8, false, false>", "HardNet trunk, exact fp32 MFMA"),
-    ("cnn32_trunk_kernel<2, 8, false, true>", "HardNet trunk, arith fp32_split3"),
-    ("cnn32_trunk_kernel<0, 8, false, false>", "AffNet trunk, exact fp32 MFMA"),
-    ("cnn32_trunk_kernel<0, 8, false, true>", "AffNet trunk, arith fp32_split3"),
-    ("cnn32_trunk_kernel<1, 8, false, false>", "OriNet trunk, exact fp32 MFMA"),
-    ("cnn32_trunk_kernel<1, 8, false, true>", "OriNet trunk, arith fp32_split3"),
+    ("cnn32_trunk_kernel<2, 8, false, 0>", "HardNet trunk, exact fp32 MFMA"),
+    ("cnn32_trunk_kernel<2, 8, false, 3>", "HardNet trunk, arith fp32_split3"),
+    ("cnn32_trunk_kernel<2, 8, false, 2>", "HardNet trunk, arith fp32_split2h"),
+    ("cnn32_trunk_kernel<0, 8, false, 0>", "AffNet trunk, exact fp32 MFMA"),
+    ("cnn32_trunk_kernel<0, 8, false, 3>", "AffNet trunk, arith fp32_split3"),
+    ("cnn32_trunk_kernel<0, 8, false, 2>", "AffNet trunk, arith fp32_split2h"),
+    ("cnn32_trunk_kernel<1, 8, false, 0>", "OriNet trunk, exact fp32 MFMA"),
+    ("cnn32_trunk_kernel<1, 8, false, 3>", "OriNet trunk, arith fp32_split3"),
+    ("cnn32_trunk_kernel<1, 8, false, 2>", "OriNet trunk, arith fp32_split2h"),
     ("hardnet_head_kernel<64>", "HardNet head GEMM (64-patch tiles), exact"),
-    ("hardnet_head_s3_kernel<64>", "HardNet head GEMM (64-patch tiles), arith fp32_split3"),
+    ("hardnet_head_s3_kernel<64, 3>", "HardNet head GEMM (64-patch tiles), arith fp32_split3"),
+    ("hardnet_head_s3_kernel<64, 2>", "HardNet head GEMM (64-patch tiles), arith fp32_split2h"),
     ("hessian_nms_kernel<5>", "Hessian + 3-D NMS + centroid, 5 levels per octave"),
     ("blur2d_kernel<13, 4>", "Gaussian blur 13 x 13, 64 x 64 tiles"),
     ("blur2d_pair_kernel<15, 9, 4>", "paired blur 15 x 15 / 9 x 9"),
     ("dense_conv_kernel<32, 32, 1", "dense AffNetFastFullConv conv3, exact"),
-    ("dense_conv_s3_kernel<32, 32, 1", "dense AffNetFastFullConv conv3, arith fp32_split3"),
+    ("dense_conv_s3_kernel<32, 32, 1, LayQ<16, 16, 18, 32, 0, 3>", "dense AffNetFastFullConv conv3, arith fp32_split3"),
+    ("dense_conv_s3_kernel<32, 32, 1, LayQ<16, 16, 18, 32, 0, 2>", "dense AffNetFastFullConv conv3, arith fp32_split2h"),
 ]
 
 

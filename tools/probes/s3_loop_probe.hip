@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, 1) void probe4_kernel(const float* __restrict_
     if (threadIdx.x == 0 && blockIdx.x == 0) out[1] = sink;
 }
 
-template <int SHAPE, int VAR>      // VAR 0 = old loop (LayB), 1 = new loop (LayQ), 2 = new loop without alternating priorities, 3 = old without
+template <int SHAPE, int VAR>      // VAR 0 = old loop (LayB), 1 = new loop (LayQ), 2 = new loop without alternating priorities, 3 = old without, 15 = VAR 2 on TWO fp16 terms
 __global__ __launch_bounds__(512, (Shape<SHAPE>::CB == 32) ? 2 : 4) void probe_kernel(const float* __restrict__ Ws, int reps, float* __restrict__ out,
                                                                                      unsigned long long* __restrict__ cyc) {
     typedef Shape<SHAPE> S;
@@ -109,6 +109,11 @@ __global__ __launch_bounds__(512, (Shape<SHAPE>::CB == 32) ? 2 : 4) void probe_k
             S3W<S::TN> w0;
             s3_prefetch_w0<NW, S::CIN, S::COUT, MT, S::TM, S::TN>(Ws, w0, wave, lane);
             constexpr int PBITS = VAR == 9 ? 1 : (VAR == 10 ? 2 : (VAR == 11 ? 3 : (VAR == 12 ? (1 << 4) : (VAR == 13 ? (3 << 4) : (VAR == 14 ? (6 << 4) : 0)))));
+            if constexpr (VAR == 15) {          // AFFNET_ARITH_FP32_SPLIT2H: the same cells and loop with two fp16 terms, three products
+                typedef LayQ<S::LQ::H, S::LQ::W, S::LQ::WP, S::LQ::C, S::LQ::GREM, 2> LQ2T;
+                s3_prefetch_w0<NW, S::CIN, S::COUT, MT, S::TM, S::TN, 2>(Ws, w0, wave, lane);
+                conv3x3_mfma_s3q<NW, S::CIN, S::COUT, LQ2T, S::STRIDE, S::TM, S::TN, 0>(lds, Ws, w0, acc, wave, lane, alt);
+            } else
             conv3x3_mfma_s3q<NW, S::CIN, S::COUT, typename S::LQ, S::STRIDE, S::TM, S::TN, PBITS>(lds, Ws, w0, acc, wave, lane, alt);
         }
 #pragma unroll
@@ -128,7 +133,7 @@ static void run(const float* dW, float* dout, unsigned long long* dcyc, int reps
     typedef Shape<SHAPE> S;
     constexpr int NS = 9 * (S::CIN / 32);
     const int nwaves = (VAR >= 4 && VAR <= 8) ? 4 : 8;
-    const double mfma_per_wave = (double)NS * 6 * S::TM * S::TN * (8 / nwaves);
+    const double mfma_per_wave = (double)NS * (VAR >= 15 ? 3 : 6) * S::TM * S::TN * (8 / nwaves);
     const double floor_cyc = mfma_per_wave * 16.0 * (nwaves / 4);         // the waves of a SIMD share its matrix pipe
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -156,9 +161,9 @@ static void run(const float* dW, float* dout, unsigned long long* dcyc, int reps
     mean /= nb;
     const double flops = (double)blocks * reps * nwaves * mfma_per_wave * 2.0 * 16 * 16 * 32;
     const double tf = flops / (best * 1e-3) / 1e12;
-    static const char* vn[16] = {"old LayB tile-major", "NEW LayQ term-major", "NEW, no alt prio", "old, no alt prio", "NEW 4 waves (1/SIMD) A", "NEW 4 waves (1/SIMD) B",
+    static const char* vn[17] = {"old LayB tile-major", "NEW LayQ term-major", "NEW, no alt prio", "old, no alt prio", "NEW 4 waves (1/SIMD) A", "NEW 4 waves (1/SIMD) B",
                                 "4w A, no weight loads", "4w A, no frag reloads", "4w A, pure MFMA", "8w no w loads", "8w no frag reloads", "8w pure MFMA",
-                                "8w pace s_nop 0", "8w pace s_nop 2", "8w pace s_nop 5", "(unused)"};
+                                "8w pace s_nop 0", "8w pace s_nop 2", "8w pace s_nop 5", "NEW, two fp16 terms", "(unused)"};
     printf("%-52s %-22s cycles/call %8.0f (max %8.0f) floor %7.0f -> %5.1f %% | launch %7.3f ms %7.1f TFLOP/s bf16 = %5.1f %% of 2516.8\n", S::name(), vn[VAR], mean, mx,
            floor_cyc, 100.0 * floor_cyc / mean, best, tf, 100.0 * tf / 2516.8);
 }
@@ -187,6 +192,11 @@ int main(int argc, char** argv) {
 #define ONE(SH) run<SH, 2>(dW, dout, dcyc, reps, blocks, 2.4);
         ONE(0) ONE(7) ONE(1) ONE(12) ONE(2) ONE(8) ONE(3) ONE(9) ONE(4) ONE(10) ONE(11)
         ONE(5) ONE(13) ONE(14) ONE(15) ONE(6) ONE(16)
+        return 0;
+    }
+    if (argc > 3 && argv[3][0] == 'h') {       // two fp16 terms (AFFNET_ARITH_FP32_SPLIT2H) next to three bf16 terms: the trunks' blockings and the 2 x 2 alternatives
+#define TWO(SH) run<SH, 2>(dW, dout, dcyc, reps, blocks, 2.4); run<SH, 15>(dW, dout, dcyc, reps, blocks, 2.4);
+        TWO(0) TWO(7) TWO(12) TWO(1) TWO(2) TWO(8) TWO(9) TWO(3) TWO(10) TWO(4) TWO(13) TWO(5) TWO(15) TWO(14) TWO(6) TWO(16)
         return 0;
     }
     if (argc > 3) { BOTH(2) FOUR(2) DIAG(2) BOTH(4) FOUR(4) DIAG(4) return 0; }

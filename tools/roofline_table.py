@@ -27,6 +27,19 @@ def octave_pixels(h, w, border=5):
         h, w = nh, nw
 
 
+def split_terms(name):
+    """Arithmetic of a cnn32_trunk_kernel instantiation from its last template argument: 0 = exact fp32 MFMA, 3 = three bf16 terms (round 3 / early
+    round 4 builds print it as `true`), 2 = two fp16 terms."""
+    n = name.rstrip()
+    if "cnn32_trunk_kernel" not in n:
+        return 0
+    if n.endswith("true>") or n.endswith(", 3>"):
+        return 3
+    if n.endswith(", 2>"):
+        return 2
+    return 0
+
+
 def main(prefix):
     stats = {}
     for r in csv.DictReader(open(prefix + "_kernel_stats.csv")):
@@ -37,7 +50,7 @@ def main(prefix):
     if aff_eval:
         FLOP["cnn32_trunk_kernel<0"] = aff_eval * 19193856.0
     # one HardNet trunk launch per 32-image call; a run that also took the arith fp32_split3 steps (bench.py without --no-split3)
-    # has them under their own template instantiation <2, 8, false, true> - every other kernel is shared by both kinds of step
+    # has them under their own template instantiations <2, 8, false, 3> / <2, 8, false, 2> - every other kernel is shared by all kinds of step
     calls_per_batch = sum(v[0] for k, v in stats.items() if k.startswith("void cnn32_trunk_kernel<2, 8, false"))
     P0, P = H * W, octave_pixels(H, W)
     alg = {"blur2d_kernel": (P0 + 9 * P) * 4.0 * IMGS, "hessian_nms_kernel": 5 * P * 4.0 * IMGS}
@@ -52,15 +65,17 @@ def main(prefix):
         hbm = t["hbm_bytes"] if t else None
         gbs = hbm / avg_ns if hbm else None                                  # bytes / ns = GB/s
         algs = ""
-        split = "cnn32_trunk_kernel" in name and name.rstrip().endswith("true>")
+        split = split_terms(name)
         if "cnn32_trunk_kernel" in name:                                     # exact and split instantiations: launches of their own steps only
-            own = sum(v[0] for k, v in stats.items() if k.startswith("void cnn32_trunk_kernel<2, 8, false") and k.rstrip().endswith("true>") == split)
+            own = sum(v[0] for k, v in stats.items() if k.startswith("void cnn32_trunk_kernel<2, 8, false") and split_terms(k) == split)
             per_call = calls / float(max(1, own))
         for key, fl in FLOP.items():
             if key in name and split:
                 tf = fl * IMGS / (per_call * avg_ns * 1e-9) / 1e12
-                algs = ("arith fp32_split3: %.1f TFLOP/s fp32-equivalent; executed bf16 products (6 per fp32 product) %.0f TFLOP/s = %.1f %% of "
-                        "the 2517 bf16 MFMA peak" % (tf, 6 * tf, 100 * 6 * tf / 2516.8))
+                prod = 6 if split == 3 else 3
+                algs = ("arith %s: %.1f TFLOP/s fp32-equivalent; executed %s products (%d per fp32 product) %.0f TFLOP/s = %.1f %% of "
+                        "the 2517 bf16 / fp16 MFMA peak" % ("fp32_split3" if split == 3 else "fp32_split2h", tf, "bf16" if split == 3 else "fp16", prod, prod * tf,
+                                                          100 * prod * tf / 2516.8))
             elif key in name:
                 tf = fl * IMGS / (per_call * avg_ns * 1e-9) / 1e12            # all launches of the kernel in one 32-image call
                 algs = "%.1f TFLOP/s = %.1f %% of 157.3" % (tf, 100 * tf / 157.3)

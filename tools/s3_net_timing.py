@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Wall time of each trunk alone on 48000 patches, arith fp32 (exact fp32 MFMA) vs arith fp32_split3 (split operands) (min of 5 launches each)."""
+"""Wall time of each trunk alone on 48000 patches: arith fp32 (exact fp32 MFMA), fp32_split3 and fp32_split2h (split operands); min of 5 launches each."""
 import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -14,9 +14,8 @@ O = affnet_amd.OriNetFast(PS=32); O.load_state_dict(torch.load(os.path.join(ROOT
 H = affnet_amd.HardNet(); H.load_state_dict(affnet_amd.synthetic_hardnet_state(0)); H.to(dev)
 big = (torch.rand(48000, 1, 32, 32) * 255).to(dev)
 ctx = engine.utility_ctx(dev)        # the nets' stand-alone calls (arith "fp32") run on this context: switch IT for the A/B
-for split in (0, 1, 3, 1, 3):          # 0 exact, 1 split operands, 3 split with the variant bits of AFFNET_S3_VARIANT (default 1: alternating wave priorities in the HardNet loops)
-    lib.affnet_set_arith(ctx, 1 if split else 0)
-    lib.affnet_debug_split3_variant(ctx, int(os.environ.get("AFFNET_S3_VARIANT", "1")) if split == 3 else 0)
+for arith in (0, 1, 2, 1, 2):          # AFFNET_ARITH_*: 0 exact, 1 three bf16 terms, 2 two fp16 terms
+    lib.affnet_set_arith(ctx, arith)
     row = []
     for nm, net in (("AffNet", A), ("OriNet", O), ("HardNet", H)):
         net(big); torch.cuda.synchronize()
@@ -26,5 +25,5 @@ for split in (0, 1, 3, 1, 3):          # 0 exact, 1 split operands, 3 split with
             e0.record(); net(big); e1.record(); torch.cuda.synchronize()
             best = min(best, e0.elapsed_time(e1))
         row.append("%s %.3f ms" % (nm, best))
-    print({0: "exact        ", 1: "split3       ", 3: "split3 variant"}[split], " | ".join(row))
-lib.affnet_set_arith(ctx, 0); lib.affnet_debug_split3_variant(ctx, 0)
+    print({0: "exact        ", 1: "fp32_split3  ", 2: "fp32_split2h "}[arith], " | ".join(row))
+lib.affnet_set_arith(ctx, 0)

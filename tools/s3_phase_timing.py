@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Phase breakdown (s_memtime stamps) of the split-operand (arith fp32_split3) HardNet trunk next to the exact fp32 one (tuning aid)."""
+"""Phase breakdown (s_memtime stamps) of the split-operand trunks (arith fp32_split3 / fp32_split2h) next to the exact fp32 HardNet trunk (tuning aid)."""
 import os, sys
 import numpy as np
 import torch
@@ -18,7 +18,8 @@ O = affnet_amd.OriNetFast(PS=32); O.load_state_dict(torch.load(os.path.join(ROOT
 names = ["input+norm", "conv0", "conv1 mfma", "conv1 store", "conv2 mfma", "conv2 store", "conv3 mfma", "conv3 store",
          "conv4 mfma", "conv4 store", "conv5 mfma"]
 ctx = engine.utility_ctx(dev)
-nets = [("HardNet", H, (0, 1))] + ([("AffNet", A, (1,)), ("OriNet", O, (1,))] if os.environ.get("PHASE_ALL", "1") == "1" else [])
+SPLIT_MODES = tuple(int(v) for v in os.environ.get("PHASE_ARITH", "1,2").split(","))      # AFFNET_ARITH_* codes of the split modes to stamp
+nets = [("HardNet", H, (0,) + SPLIT_MODES)] + ([("AffNet", A, SPLIT_MODES), ("OriNet", O, SPLIT_MODES)] if os.environ.get("PHASE_ALL", "1") == "1" else [])
 for nm, net, modes in nets:
   for split in modes:
     lib.affnet_set_arith(ctx, split)
@@ -29,7 +30,7 @@ for nm, net, modes in nets:
     lib.affnet_cnn32_debug_timing(ctx, None)
     t = st.cpu().numpy().reshape(n, nw, 32).astype(np.float64)
     d = np.diff(t[:, :, :12], axis=2)
-    print("== %s %s: mean ticks per phase per wave (shader cycles)" % (nm, "split operands (arith fp32_split3)" if split else "exact fp32"))
+    print("== %s %s: mean ticks per phase per wave (shader cycles)" % (nm, {0: "exact fp32", 1: "split operands (arith fp32_split3)", 2: "split operands (arith fp32_split2h)"}[split]))
     for i in range(11):
         print("  %-12s mean %8.0f  max-over-waves %8.0f" % (names[i], d[:, :, i].mean(), d[:, :, i].max(axis=1).mean()))
     last = 13 if nm != "HardNet" else 11
