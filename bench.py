@@ -59,6 +59,7 @@ SPLIT = {"fp32_split3": {"products": 6.0, "dtype": DTYPE_SPLIT3, "label": "CNN c
 
 # ----------------------------------------------------------------------------------------------------------------------
 def pmc_traffic(images_per_launch, split=False):
+    # split: False = the exact-fp32 HardNet trunk, "fp32_split3" / "fp32_split2h" (True = fp32_split3) = that mode's instantiation
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE
     in separate passes, tools/gpu_full.sh + tools/pmc_traffic.py; counters cannot be read from inside this process)."""
     import glob
@@ -67,7 +68,8 @@ def pmc_traffic(images_per_launch, split=False):
     d = k = None
     for f in reversed(files):                  # newest evidence set that has the exact-fp32 HardNet trunk (its name gained template arguments over the rounds)
         d = json.load(open(f))
-        names = ("void cnn32_trunk_kernel<2, 8, false, 3>", "void cnn32_trunk_kernel<2, 8, false, true>") if split else \
+        names = ("void cnn32_trunk_kernel<2, 8, false, 2>",) if split == "fp32_split2h" else \
+                ("void cnn32_trunk_kernel<2, 8, false, 3>", "void cnn32_trunk_kernel<2, 8, false, true>") if split else \
                 ("void cnn32_trunk_kernel<2, 8, false, 0>", "void cnn32_trunk_kernel<2, 8, false, false>", "void cnn32_trunk_kernel<2, 8, false>", "void cnn32_trunk_kernel<2, 8>")
         for name in names:
             k = d["kernels"].get(name)
@@ -771,7 +773,7 @@ def run(args, world):
         kp_per_img = kps / max(1, args.steps * args.batch * world)
         flops_launch = kp_per_img * img_per_launch * (FLOP_HARD - FLOP_HARD_HEAD)
         achieved = flops_launch / (trunk_ms * 1e-3) / 1e12 if trunk_ms > 0 else 0.0
-        traffic, traffic_note = pmc_traffic(img_per_launch, split=args.split3)
+        traffic, traffic_note = pmc_traffic(img_per_launch, split=args.arith if args.split3 else False)
         cfg_idx = 4 if args.config5 else 2
         metric = "keypoints/sec (detect+AffNet+OriNet+HardNet) per image, %d kp @%dx%d" % (NKP, W, H)
         if H2D:
@@ -820,7 +822,7 @@ def run(args, world):
             f_conv0 = kp_per_img * img_per_launch * 2.0 * 1024 * 9 * 32
             bf16_tf = prod * (fl_launch - f_conv0) / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
             eq = fl_launch / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
-            tr, tr_note = pmc_traffic(img_per_launch, split=True)
+            tr, tr_note = pmc_traffic(img_per_launch, split=mode)
             return {"kernel": "cnn32_trunk_kernel<HardNet, split operands> (conv1..conv5: %s per fp32 product, fp32 accumulate; conv0 fp32 MFMA)" % SPLIT[mode]["insn"],
                     "bound": "mfma", "achieved": bf16_tf, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": bf16_tf / PEAK_BF16_MFMA_TFLOPS,
                     "traffic": tr, "traffic_source": tr_note, "flops_per_launch": fl_launch, "launch_ms": launch_ms,

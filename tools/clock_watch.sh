@@ -1,14 +1,14 @@
 #!/bin/bash
-# Shader clock and socket power while the batched bench runs (exact fp32 path, then the split-operand arithmetic mode): is the
+# Shader clock and socket power while the batched bench runs (exact fp32 path, then the two split-operand arithmetic modes): is the
 # split path power limited?  Samples rocm-smi every ~0.25 s in the background; prints the median / max over the samples taken while
 # the GPU was busy (> 50 % of the peak power seen).
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 mkdir -p gpurun_out
-for mode in exact split3; do
-  flag=""; [ $mode = split3 ] && flag="--split3"
+for mode in exact split3 split2h; do
+  flag=""; [ $mode = split3 ] && flag="--arith fp32_split3"; [ $mode = split2h ] && flag="--arith fp32_split2h"
   ( while true; do rocm-smi --showclocks --showpower --json 2>/dev/null | tr -d '\n'; echo; sleep 0.25; done ) > gpurun_out/clock_$mode.jsonl &
   W=$!
-  timeout 300 python bench.py $flag --steps 40 --warmup 3 --no-cpu-baseline --no-secondary > gpurun_out/clock_bench_$mode.log 2>&1
+  timeout 300 python bench.py $flag --steps 40 --warmup 3 --no-cpu-baseline --no-secondary --no-other-configs --no-split3 > gpurun_out/clock_bench_$mode.log 2>&1
   kill $W; wait $W 2>/dev/null
   python - "$mode" <<'PY'
 import json, sys, re, statistics

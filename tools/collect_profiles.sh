@@ -27,8 +27,15 @@ for C in config2 config5 onepass; do [ -f gpurun_out/bench_${C}_split3.log ] && 
 cp gpurun_out/prof_split3/run_kernel_stats.csv profiles/${T}_split3_kernel_stats.csv
 (cat gpurun_out/split3_phase_timing.txt; echo; cat gpurun_out/split3_net_timing.txt) | grep -v amdgpu.ids > profiles/${T}_split3_phase_and_net_timing.txt
 [ -f gpurun_out/pmc_split3_summary.txt ] && cp gpurun_out/pmc_split3_summary.txt profiles/${T}_split3_pmc_summary.txt
+# arith fp32_split2h
+grep '^{' gpurun_out/bench_split2h.log > profiles/${T}_split2h_bench.json
+for C in config2 config5 onepass; do [ -f gpurun_out/bench_${C}_split2h.log ] && grep '^{' gpurun_out/bench_${C}_split2h.log > profiles/${T}_split2h_bench_${C}.json; done
+[ -f gpurun_out/prof_split2h/run_kernel_stats.csv ] && cp gpurun_out/prof_split2h/run_kernel_stats.csv profiles/${T}_split2h_kernel_stats.csv
+[ -f gpurun_out/pmc_split2h_summary.txt ] && cp gpurun_out/pmc_split2h_summary.txt profiles/${T}_split2h_pmc_summary.txt
+[ -f gpurun_out/f16_split_probe.txt ] && cp gpurun_out/f16_split_probe.txt profiles/${T}_f16_split_probe.txt
+[ -f gpurun_out/s3_loop_probe_h.txt ] && cp gpurun_out/s3_loop_probe_h.txt profiles/${T}_s3_loop_probe_split2h.txt
 [ -f gpurun_out/s3_loop_probe.txt ] && cp gpurun_out/s3_loop_probe.txt profiles/${T}_s3_loop_probe.txt
-grep -v "^ *value" gpurun_out/clock_watch.txt > profiles/${T}_clock_power_exact_vs_split3.txt; grep "value" gpurun_out/clock_watch.txt >> profiles/${T}_clock_power_exact_vs_split3.txt
+grep -v "^ *value" gpurun_out/clock_watch.txt > profiles/${T}_clock_power_exact_vs_split.txt; grep "value" gpurun_out/clock_watch.txt >> profiles/${T}_clock_power_exact_vs_split.txt
 # BASELINE configs[4] counters
 [ -f gpurun_out/config5_traffic.json ] && sed "s#gpurun_out/fetch_calibration.json#profiles/${T}_fetch_calibration.json#" gpurun_out/config5_traffic.json > profiles/${T}_config5_traffic.json
 [ -f gpurun_out/pmc_config5_summary.txt ] && cp gpurun_out/pmc_config5_summary.txt profiles/${T}_config5_pmc_summary.txt
