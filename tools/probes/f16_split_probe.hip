@@ -116,7 +116,7 @@ int main(int argc, char** argv) {
         uint32_t s = 12345;
         for (int i = 0; i < n; ++i) {
             s = s * 1664525u + 1013904223u;
-            const uint32_t mant = s & 0x007fffffu, sign = s & 0x80000000u;
+            const uint32_t mant = (s >> 8) & 0x007fffffu, sign = s & 0x80000000u;      // high bits: the low bits of an LCG have short periods (bit 0 alternates)
             s = s * 1664525u + 1013904223u;
             const uint32_t ex = 127 - 30 + (s >> 8) % 46;                // 2^-30 .. 2^15
             const uint32_t u = sign | (ex << 23) | mant;
