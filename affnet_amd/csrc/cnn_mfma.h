@@ -871,10 +871,18 @@ __device__ __forceinline__ void conv3x3_mfma_s3q(const float* act, const float* 
     auto finish = [&]() {
         if constexpr (TERMS == 2) {           // the two-term weights are packed times 2^e (fp16 range): undo it, exactly
             const float osc = Ws[WS_FLOATS];
+            // An activation beyond fp16's range (|a| >= 65520) splits into (inf, -inf) and its products sum to NaN - which the ReLU of every epilogue
+            // (v_max_f32 returns the non-NaN operand) would turn into a plausible 0.  NaN -> +inf here: +inf survives bias + ReLU, splits into (inf, NaN)
+            // in the next layer and arrives at the outputs as inf / NaN (HardNet: NaN descriptors) instead of passing silently.
+            const float pinf = __builtin_inff();
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] *= osc;
+                for (int j = 0; j < TN; ++j) {
+                    f32x4 v = acc[i][j] * osc;
+                    v.x = (v.x == v.x) ? v.x : pinf; v.y = (v.y == v.y) ? v.y : pinf; v.z = (v.z == v.z) ? v.z : pinf; v.w = (v.w == v.w) ? v.w : pinf;
+                    acc[i][j] = v;
+                }
         }
     };
     if constexpr (C16) {

@@ -79,7 +79,7 @@ extern "C" {
  *                 exponent, so the weights of a layer are packed times a power of two 2^e that puts the layer's largest |w| into
  *                 [2^13, 2^14) and the layer's sums are multiplied by 2^-e (both exact); activations are used as they are: |a| < 65504
  *                 is REQUIRED (the reference's nets are BatchNorm-ed, |a| stays below ~50; a larger value becomes inf and the output
- *                 NaN - it does not pass silently) and an activation below 2^-14 keeps an ABSOLUTE error of 2^-25 instead of a relative
+ *                 non-finite - HardNet descriptors NaN, AffNet / OriNet outputs NaN or saturated - it does not pass as a plausible number) and an activation below 2^-14 keeps an ABSOLUTE error of 2^-25 instead of a relative
  *                 one (subnormal fp16 operands are honoured by the MFMA, tools/probes/f16_split_probe.hip).  Same interfaces (fp32
  *                 everywhere), same parity bars. */
 #define AFFNET_ARITH_FP32_MFMA 0

@@ -1192,6 +1192,35 @@ def test_split_trunks_vs_exact_trunks(amd, nets, mode, code):
             net.arith = "fp32"
 
 
+def test_split2h_activation_range_is_loud_not_silent(amd):
+    """include/affnet_hip.h, AFFNET_ARITH_FP32_SPLIT2H: activations are carried as fp16 pairs, so |a| < 65504 is required.  The reference's nets are
+    BatchNorm-ed (|a| < 50 on every test input); a net whose activations leave the range must NOT return plausible numbers: with conv1's weights times 1e6
+    (activations ~1e6 from conv1 on) the exact and the three-bf16-term modes still return finite unit descriptors, the two-fp16-term mode returns non-finite
+    values for every patch - visible to any caller - and is unaffected once the weights are back."""
+    sd = amd.synthetic_hardnet_state(0)
+    big = {k: v.clone() for k, v in sd.items()}
+    big["features.3.weight"] *= 1.0e6
+    p = (torch.rand(64, 1, 32, 32, generator=torch.Generator().manual_seed(3)) * 255).to(DEV)
+    H = amd.HardNet(); H.load_state_dict(big); H.to(DEV)
+    try:
+        for mode, finite in (("fp32", True), ("fp32_split3", True), ("fp32_split2h", False)):
+            H.arith = mode
+            d = H(p)
+            ok = torch.isfinite(d).all(dim=1)
+            if finite:
+                assert bool(ok.all()) and float((d.norm(dim=1) - 1).abs().max()) < 1e-4, mode
+            else:
+                assert not bool(ok.any()), "out-of-range activations must surface as non-finite descriptors in arith %s (%d of %d rows finite)" % (mode, int(ok.sum()), ok.numel())
+    finally:
+        H.arith = "fp32"
+    H2 = amd.HardNet(); H2.load_state_dict(sd); H2.to(DEV)
+    H2.arith = "fp32_split2h"
+    try:
+        assert bool(torch.isfinite(H2(p)).all())
+    finally:
+        H2.arith = "fp32"
+
+
 @pytest.mark.parametrize("arith", ARITH)
 def test_cnn_raw_outputs_vs_the_reference_jit_traces(amd, nets, weights, golden_dir, arith):
     """Second CNN oracle: the reference's own TorchScript traces convertJIT/AffNetJIT.pt / OriNetJIT.pt return the RAW
