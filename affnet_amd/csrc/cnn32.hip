@@ -509,7 +509,7 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
     // The first weight fragments of a loop are requested before the barriers / epilogue in front of it.
     // HardNet (one workgroup per CU): optionally (affnet_debug_split3_variant bit 0) the two waves of a SIMD take turns at the higher priority
     // inside the loops.  Round 3's tile-major loops gained 2.5 % from it; with the term-major loops it costs 1 % (default off).
-    const bool s3_alt = (a.s3_alt & 1) != 0 && KIND == AFFNET_NET_HARDNET;
+    const int s3_alt = KIND == AFFNET_NET_HARDNET ? a.s3_alt : 0;       // variant bits for the loops (conv3x3_mfma_s3q)
     if constexpr (S3 != 0 && KIND == AFFNET_NET_HARDNET) {
         typedef LayQ<16, 16, 18, 2 * CB, 0, TERMS> LQ2;                            // conv2 / conv3 outputs: 64 channels @16x16 (122 KB)
         typedef LayQ<8, 8, 16, 4 * CB, 128, TERMS> LQ4;                         // conv4 output: 128 channels @8x8, row pitch 768 B (122 KB)

@@ -752,7 +752,8 @@ __device__ __forceinline__ void s3_prefetch_w0(const float* __restrict__ Ws, S3W
 // PROBE (tools/probes/s3_loop_probe.hip only): bit 0 = no weight loads inside the loop, bit 1 = no fragment reloads, bits 4.. = s_nop pacing
 template <int NW, int CIN, int COUT, typename LI, int STRIDE, int TM, int TN, int PROBE = 0>
 __device__ __forceinline__ void conv3x3_mfma_s3q(const float* act, const float* __restrict__ Ws, const S3W<TN>& w_first, f32x4 (&acc)[TM][TN],
-                                                 int wave, int lane, bool alt_prio) {
+                                                 int wave, int lane, int variant) {
+    const bool alt_prio = (variant & 1) != 0;      // affnet_debug_split3_variant bits: 0 = alternating wave priorities, 1 = (A/B only) skip the NaN -> inf step of the two-term loops
     constexpr bool C16 = (CIN == 16);
     constexpr int TERMS = LI::TERMS;                                       // 3: bf16 terms, six products; 2: fp16 terms, three products (w_h a_h, w_l a_h, w_h a_l)
     constexpr int HOUT = LI::H / STRIDE, WOUT = LI::W / STRIDE;
@@ -874,15 +875,30 @@ __device__ __forceinline__ void conv3x3_mfma_s3q(const float* act, const float* 
             // An activation beyond fp16's range (|a| >= 65520) splits into (inf, -inf) and its products sum to NaN - which the ReLU of every epilogue
             // (v_max_f32 returns the non-NaN operand) would turn into a plausible 0.  NaN -> +inf here: +inf survives bias + ReLU, splits into (inf, NaN)
             // in the next layer and arrives at the outputs as inf / NaN (HardNet: NaN descriptors) instead of passing silently.
-            const float pinf = __builtin_inff();
+            if (variant & 2) {                                             // (A/B of this step's cost: tools/ab_nan_step.py)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] *= osc;
+                return;
+            }
+            f32x4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    f32x4 v = acc[i][j] * osc;
-                    v.x = (v.x == v.x) ? v.x : pinf; v.y = (v.y == v.y) ? v.y : pinf; v.z = (v.z == v.z) ? v.z : pinf; v.w = (v.w == v.w) ? v.w : pinf;
-                    acc[i][j] = v;
-                }
+                for (int j = 0; j < TN; ++j) { acc[i][j] *= osc; sum += acc[i][j]; }
+            const float s1 = (sum.x + sum.y) + (sum.z + sum.w);            // NaN iff a NaN (or +inf and -inf) is among the wave's sums: rare path below
+            if (__builtin_amdgcn_ballot_w64(s1 != s1) != 0) {
+                const float pinf = __builtin_inff();
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        f32x4 v = acc[i][j];
+                        v.x = (v.x == v.x) ? v.x : pinf; v.y = (v.y == v.y) ? v.y : pinf; v.z = (v.z == v.z) ? v.z : pinf; v.w = (v.w == v.w) ? v.w : pinf;
+                        acc[i][j] = v;
+                    }
+            }
         }
     };
     if constexpr (C16) {

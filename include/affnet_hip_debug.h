@@ -56,7 +56,9 @@ int affnet_debug_stream(const void* d_src, void* d_dst, size_t n_bytes, int widt
  *     x (16 x 16 x 32) multiply-adds.  d_out: 2 floats (sink). */
 /* Tuning aid for AFFNET_ARITH_FP32_SPLIT3 (include/affnet_hip.h: affnet_set_arith is the product switch): variant bits of the
  * split-operand trunk launches of this context.  bit 0 (value 1): alternating wave priorities in the HardNet loops (A/B aid of
- * tools/s3_net_timing.py; results identical; default off).  Does not change the arithmetic mode. */
+ * tools/s3_net_timing.py; results identical; default off).  bit 1 (value 2): the HardNet loops of AFFNET_ARITH_FP32_SPLIT2H skip their
+ * NaN -> +inf step (A/B of its cost only, tools/ab_nan_step.py: an out-of-range activation could then be hidden by a ReLU).  Does not
+ * change the arithmetic mode. */
 int affnet_debug_split3_variant(affnet_ctx* ctx, int bits);
 int affnet_split3_gemm(const float* d_A, const float* d_Bt, int M, int N, int K, int mode, float* d_C, void* stream);
 int affnet_split3_rate(int reps, int terms, int n_blocks, float* d_out, void* stream);
