@@ -27,7 +27,7 @@ class OnePassSIR(nn.Module):
     def __init__(self, border=16, num_features=500, patch_size=32, mrSize=3.0, nlevels=3, th=None, num_Baum_iters=0, init_sigma=1.6,
                  RespNet=None, OriNet=None, AffNet=None, arith="fp32"):
         super(OnePassSIR, self).__init__()
-        self.arith = arith           # "fp32" (exact fp32 MFMA, default) / "fp32_split3": see ScaleSpaceAffinePatchExtractor
+        self.arith = arith           # "fp32" (exact fp32 MFMA, default) / "fp32_split3" / "fp32_split2h": see ScaleSpaceAffinePatchExtractor
         _lib.arith_code(arith)
         self.mrSize, self.PS, self.b = mrSize, patch_size, border
         self.num, self.th = num_features, th

@@ -30,7 +30,8 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
                  init_sigma=1.6, th=None, RespNet=None, OriNet=None, AffNet=None, arith="fp32"):
         super(ScaleSpaceAffinePatchExtractor, self).__init__()
         self.arith = arith           # arithmetic of the native CNN slots' contractions: "fp32" = exact fp32 MFMA (default), "fp32_split3" = fp32 as
-                                     # three bf16 terms on the bf16 MFMA, fp32 accumulate (include/affnet_hip.h AFFNET_ARITH_*; same parity bars)
+                                     # three bf16 terms (exact), six products on the bf16 MFMA, "fp32_split2h" = two fp16 terms (23 of 24 bits), three
+                                     # products on the fp16 MFMA; fp32 accumulate (include/affnet_hip.h AFFNET_ARITH_*; same parity bars)
         _lib.arith_code(arith)       # raises on an unknown mode
         self.mrSize, self.PS, self.b = mrSize, patch_size, border
         self.num, self.nlevels = num_features, nlevels

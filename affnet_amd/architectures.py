@@ -28,8 +28,8 @@ class _HipPatchNet(nn.Module):
     def __init__(self):
         super(_HipPatchNet, self).__init__()
         self._packed = None            # BN-folded, MFMA-ordered blob on the device
-        self.arith = "fp32"            # stand-alone calls of this net: "fp32" (exact fp32 MFMA, default) or "fp32_split3" (fp32 = 3 x bf16 split
-                                       # operands; include/affnet_hip.h AFFNET_ARITH_*).  Inside an extractor the extractor's `arith` decides.
+        self.arith = "fp32"            # stand-alone calls of this net: "fp32" (exact fp32 MFMA, default), "fp32_split3" (fp32 = 3 x bf16 split
+                                       # operands) or "fp32_split2h" (fp32 = 2 x fp16 split operands; include/affnet_hip.h AFFNET_ARITH_*).  Inside an extractor the extractor's `arith` decides.
         self._packed_version = None    # _weights_stamp() it was built from
 
     def _weights_stamp(self):
