@@ -23,6 +23,8 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 #include "cnn_mfma.h"
@@ -469,9 +471,20 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
     constexpr bool HALF = S3 != 0;                                // split-operand arithmetic: conv0 .. conv2 in two half-patch passes
     constexpr int TERMS = S3 ? S3 : 3;                            // terms per operand of the split arithmetic (3 bf16 / 2 fp16)
     static_assert(S3 == 0 || S3 == 2 || S3 == 3, "S3 = number of terms of the split arithmetic");
-    typedef LayQ<16, 32, 34, CB, 0, TERMS> LQH;                  // conv0 output of half a patch, pre-split (HALF only); read by conv1 (stride 1)
-    typedef LayQ<16, 32, 34, CB, 16, TERMS> LQH2;                // conv1 output of half a patch; read by conv2 at stride 2
-    if constexpr (HALF) zero_halo_q<LQH, NTHR>(act);
+    // three bf16 terms: term-interleaved 48-byte cells (LayQ), conv0 .. conv2 in two half-patch passes; two fp16 terms: 16-byte pixels, the two terms of a row side by
+    // side (LayR; per-reader row pitch / group stride), conv0 once for the whole patch
+    typedef LayQ<16, 32, 34, CB, 0, 3> LQH;                      // three terms: conv0 output of half a patch, pre-split; read by conv1 (stride 1)
+    typedef LayQ<16, 32, 34, CB, 16, 3> LQH2;                    // three terms: conv1 output of half a patch; read by conv2 at stride 2
+    // two-term arithmetic: LayR's 16-byte pixels hold conv0's / conv1's output of the WHOLE patch (145 KB for 32 channels, 72.5 KB for 16), so conv0 runs once; conv1 / conv2
+    // keep their two half-patch LOOPS (same register blockings) on 16-row views of the whole layouts - no second conv0 pass, no halo-row fix-ups between the halves
+    using LR0 = LayR<32, 32, 34, CB, 0>;                          // conv0 output, read by conv1 (stride 1)
+    using LR0H = LayR<16, 32, 34, CB, 0, 34>;                     // its 16-row view
+    using LR1 = LayR<32, 32, 34, CB, 16>;                         // conv1 output, read by conv2 at stride 2
+    using LR1H = LayR<16, 32, 34, CB, 16, 34>;
+    constexpr bool WHOLE = (TERMS == 2) && HALF;
+    static_assert(!WHOLE || (LR0::BYTES <= TrunkLds<CB>::ACT * 4 && LR1::BYTES <= TrunkLds<CB>::ACT * 4 && LR0H::GS == LR0::GS && LR1H::GS == LR1::GS), "whole-patch split layouts");
+    if constexpr (WHOLE) zero_halo_q<LR0, NTHR>(act);
+    else if constexpr (HALF) zero_halo_q<LQH, NTHR>(act);
     else zero_halo<LayC0, NTHR>(act, CB);
     float sum = 0.f;
 #pragma unroll
@@ -511,62 +524,90 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
     // inside the loops.  Round 3's tile-major loops gained 2.5 % from it; with the term-major loops it costs 1 % (default off).
     const int s3_alt = KIND == AFFNET_NET_HARDNET ? a.s3_alt : 0;       // variant bits for the loops (conv3x3_mfma_s3q)
     if constexpr (S3 != 0 && KIND == AFFNET_NET_HARDNET) {
-        typedef LayQ<16, 16, 18, 2 * CB, 0, TERMS> LQ2;                            // conv2 / conv3 outputs: 64 channels @16x16 (122 KB)
-        typedef LayQ<8, 8, 16, 4 * CB, 128, TERMS> LQ4;                         // conv4 output: 128 channels @8x8, row pitch 768 B (122 KB)
+        // conv2 / conv3 outputs, 64 channels @16x16 (122 KB / 90 KB): read at stride 1 (conv3) and, conv3's output written in place, at stride 2 (conv4).  LayR: the group
+        // stride is conv4's (GS = 16 mod 256, conflict free); conv3's one-row reader then has one doubled slot per 16 lanes (5 instead of 4 LDS cycles per fragment read,
+        // no measurable cost at 8 reads per 24 MFMAs) - a second layout with GS = 0 for conv3 cost 0.8 k cycles per patch for zeroing its halo again (measured)
+        using LQ2 = std::conditional_t<TERMS == 2, LayR<16, 16, 20, 2 * CB, 16>, LayQ<16, 16, 18, 2 * CB, 0, 3>>;
+        using LQ4 = std::conditional_t<TERMS == 2, LayR<8, 8, 12, 4 * CB, 0>, LayQ<8, 8, 16, 4 * CB, 128, 3>>;        // conv4 output: 128 channels @8x8 (122 KB / 60 KB)
         static_assert(LQ2::BYTES <= TrunkLds<CB>::ACT * 4 && LQ4::BYTES <= TrunkLds<CB>::ACT * 4 && LQH::BYTES <= TrunkLds<CB>::ACT * 4 &&
                       LQH2::BYTES <= TrunkLds<CB>::ACT * 4, "pre-split layouts must fit the activation buffer");
         char* base = reinterpret_cast<char*>(act);
-        // conv0 + conv1 in two half-patch passes: the pre-split conv0 output of 32 channels @32x32 would be 222 KB, half of it (16 rows +
-        // a halo row either side) is 115 KB
+        // three terms: conv0 + conv1 in two half-patch passes - the pre-split conv0 output of 32 channels @32x32 would be 222 KB, half of it (16 rows +
+        // a halo row either side) is 115 KB; two terms (WHOLE): 145 KB, conv0 runs once and the two half loops of conv1 / conv2 read 16-row views
         f32x4 acc_a[4][2], acc_b[4][2];
         // register blockings per layer from tools/probes/s3_loop_probe (profiles/r04_s3_s3_loop_probe_tilings.txt): conv1 / conv3 4 pixel tiles x 2 channel
         // tiles per wave; conv2 / conv4 / conv5 4 x 1 (one weight fragment feeds four pixel tiles: 85.0 / 86.0 / 89.0 % of the pipe floor vs 78.5 / 83.8 /
         // 87.0 % for 2 x 2)
         S3W<2> wf1;
         S3W<1> wf2;
-        s3_prefetch_w0<NW, CB, CB, 32, 4, 2, TERMS>(a.packed + a.off.w_s3[1], wf1, wave, lane);
-        prefetch_bias<NW, 32, 8, 2>(a.packed + a.off.b[1], bias1, wave, lane);
-        conv0_half_split_q<NW, LQH, 2>(patch, w0, bias0, act, 0, wave, lane);
-        __syncthreads();
-        CNN_STAMP(2);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        conv3x3_mfma_s3q<NW, CB, CB, LQH, 1, 4, 2>(act, a.packed + a.off.w_s3[1], wf1, acc_a, wave, lane, s3_alt);
-        if (PRIO) __builtin_amdgcn_s_setprio(3);
-        __syncthreads();
-        if (tid < 12 * 32) {                                         // pass 0 left conv0 row 16 in the bottom halo row: zero again (3 terms x 4 groups x 32 cells)
-            const int t = tid / 128, g = (tid >> 5) & 3, x = tid & 31;
-            *reinterpret_cast<f32x4*>(base + g * LQH::GS + (17 * LQH::WP + x + 1) * LQH::CELL + t * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        conv0_half_split_q<NW, LQH, 2>(patch, w0, bias0, act, 1, wave, lane);
-        __syncthreads();
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        conv3x3_mfma_s3q<NW, CB, CB, LQH, 1, 4, 2>(act, a.packed + a.off.w_s3[1], wf1, acc_b, wave, lane, s3_alt);
-        if (PRIO) __builtin_amdgcn_s_setprio(3);
-        CNN_STAMP(3);
-        s3_prefetch_w0<NW, CB, 2 * CB, 8, 4, 1, TERMS>(a.packed + a.off.w_s3[2], wf2, wave, lane);
         f32x4 acc2_a[4][1], acc2_b[4][1], bias2[1];
-        bias2[0] = *reinterpret_cast<const f32x4*>(&a.packed[a.off.b[2] + (wave >> 1) * 16 + 4 * (lane >> 4)]);      // MG = 8 tiles / 4 = 2: channel tile = wave / 2
-        __syncthreads();
-        // conv1's output goes back into the same half layout, pre-split, and conv2 (stride 2: output rows 0 .. 7 read input rows
-        // -1 .. 15, rows 8 .. 15 read 15 .. 31) runs in two passes as well
-        zero_halo_q<LQH2, NTHR>(act);                                // another group stride than LQH (bank conflicts of the stride-2 reader)
-        store_tiles_split_q<CB, LQH2, 4, 2>(act, bias1, acc_a, wave, lane);
-        __syncthreads();
-        CNN_STAMP(4);
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 4, 1>(act, a.packed + a.off.w_s3[2], wf2, acc2_a, wave, lane, s3_alt);
-        if (PRIO) __builtin_amdgcn_s_setprio(3);
-        __syncthreads();
-        store_tiles_split_q<CB, LQH2, 4, 2>(act, bias1, acc_b, wave, lane);
-        if (wave == 7) {                                             // conv1 row 15 (tiles 2, 3 of wave 7 in pass 0) = the top halo row of pass 1
-            const int n = lane & 15;
+        if constexpr (WHOLE) {
+            s3_prefetch_w0<NW, CB, CB, 32, 4, 2, TERMS>(a.packed + a.off.w_s3[1], wf1, wave, lane);
+            prefetch_bias<NW, 32, 8, 2>(a.packed + a.off.b[1], bias1, wave, lane);
+            conv0_whole_split_q<NW, LR0, 2>(patch, w0, bias0, act, wave, lane);
+            __syncthreads();
+            CNN_STAMP(2);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            conv3x3_mfma_s3q<NW, CB, CB, LR0H, 1, 4, 2>(act, a.packed + a.off.w_s3[1], wf1, acc_a, wave, lane, s3_alt);
+            conv3x3_mfma_s3q<NW, CB, CB, LR0H, 1, 4, 2>(act + LR0::at(16, 0) / 4, a.packed + a.off.w_s3[1], wf1, acc_b, wave, lane, s3_alt);
+            if (PRIO) __builtin_amdgcn_s_setprio(3);
+            CNN_STAMP(3);
+            s3_prefetch_w0<NW, CB, 2 * CB, 8, 4, 1, TERMS>(a.packed + a.off.w_s3[2], wf2, wave, lane);
+            bias2[0] = *reinterpret_cast<const f32x4*>(&a.packed[a.off.b[2] + (wave >> 1) * 16 + 4 * (lane >> 4)]);      // MG = 8 tiles / 4 = 2: channel tile = wave / 2
+            __syncthreads();
+            zero_halo_q<LR1, NTHR>(act);                                 // another group stride than LR0 (the stride-2 reader's): the halo cells move
+            store_tiles_split_q<CB, LR1, 4, 2, 16>(act, bias1, acc_a, wave, lane, 0);
+            store_tiles_split_q<CB, LR1, 4, 2, 16>(act, bias1, acc_b, wave, lane, 16);
+            __syncthreads();
+            CNN_STAMP(4);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            conv3x3_mfma_s3q<NW, CB, 2 * CB, LR1H, 2, 4, 1>(act, a.packed + a.off.w_s3[2], wf2, acc2_a, wave, lane, s3_alt);
+            conv3x3_mfma_s3q<NW, CB, 2 * CB, LR1H, 2, 4, 1>(act + LR1::at(16, 0) / 4, a.packed + a.off.w_s3[2], wf2, acc2_b, wave, lane, s3_alt);
+            if (PRIO) __builtin_amdgcn_s_setprio(3);
+        } else {
+            s3_prefetch_w0<NW, CB, CB, 32, 4, 2, TERMS>(a.packed + a.off.w_s3[1], wf1, wave, lane);
+            prefetch_bias<NW, 32, 8, 2>(a.packed + a.off.b[1], bias1, wave, lane);
+            conv0_half_split_q<NW, LQH, 2>(patch, w0, bias0, act, 0, wave, lane);
+            __syncthreads();
+            CNN_STAMP(2);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            conv3x3_mfma_s3q<NW, CB, CB, LQH, 1, 4, 2>(act, a.packed + a.off.w_s3[1], wf1, acc_a, wave, lane, s3_alt);
+            if (PRIO) __builtin_amdgcn_s_setprio(3);
+            __syncthreads();
+            if (tid < LQH::SLOTS * 4 * 32) {                             // pass 0 left conv0 row 16 in the bottom halo row: zero again (slots x 4 groups x 32 cells)
+                const int t = tid / 128, g = (tid >> 5) & 3, x = tid & 31;
+                *reinterpret_cast<f32x4*>(base + g * LQH::GS + LQH::at(17, x + 1) + t * LQH::TSTEP) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            conv0_half_split_q<NW, LQH, 2>(patch, w0, bias0, act, 1, wave, lane);
+            __syncthreads();
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            conv3x3_mfma_s3q<NW, CB, CB, LQH, 1, 4, 2>(act, a.packed + a.off.w_s3[1], wf1, acc_b, wave, lane, s3_alt);
+            if (PRIO) __builtin_amdgcn_s_setprio(3);
+            CNN_STAMP(3);
+            s3_prefetch_w0<NW, CB, 2 * CB, 8, 4, 1, TERMS>(a.packed + a.off.w_s3[2], wf2, wave, lane);
+            bias2[0] = *reinterpret_cast<const f32x4*>(&a.packed[a.off.b[2] + (wave >> 1) * 16 + 4 * (lane >> 4)]);      // MG = 8 tiles / 4 = 2: channel tile = wave / 2
+            __syncthreads();
+            // conv1's output goes back into the same half layout, pre-split, and conv2 (stride 2: output rows 0 .. 7 read input rows
+            // -1 .. 15, rows 8 .. 15 read 15 .. 31) runs in two passes as well
+            zero_halo_q<LQH2, NTHR>(act);                                // another group stride than LQH (bank conflicts of the stride-2 reader)
+            store_tiles_split_q<CB, LQH2, 4, 2>(act, bias1, acc_a, wave, lane);
+            __syncthreads();
+            CNN_STAMP(4);
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 4, 1>(act, a.packed + a.off.w_s3[2], wf2, acc2_a, wave, lane, s3_alt);
+            if (PRIO) __builtin_amdgcn_s_setprio(3);
+            __syncthreads();
+            store_tiles_split_q<CB, LQH2, 4, 2>(act, bias1, acc_b, wave, lane);
+            if (wave == 7) {                                             // conv1 row 15 (tiles 2, 3 of wave 7 in pass 0) = the top halo row of pass 1
+                const int n = lane & 15;
 #pragma unroll
-            for (int i = 2; i < 4; ++i) split_store_tile_q<LQH2, 2>(base, ((i - 2) * 16 + n + 1) * LQH2::CELL, 0, bias1, acc_a[i], lane >> 4);
+                for (int i = 2; i < 4; ++i) split_store_tile_q<LQH2, 2>(base, LQH2::at(0, (i - 2) * 16 + n + 1), 0, bias1, acc_a[i], lane >> 4);
+            }
+            __syncthreads();
+            if (PRIO) __builtin_amdgcn_s_setprio(0);
+            conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 4, 1>(act, a.packed + a.off.w_s3[2], wf2, acc2_b, wave, lane, s3_alt);
+            if (PRIO) __builtin_amdgcn_s_setprio(3);
         }
-        __syncthreads();
-        if (PRIO) __builtin_amdgcn_s_setprio(0);
-        conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 4, 1>(act, a.packed + a.off.w_s3[2], wf2, acc2_b, wave, lane, s3_alt);
-        if (PRIO) __builtin_amdgcn_s_setprio(3);
         CNN_STAMP(5);
         S3W<2> wf3;
         S3W<1> wf4, wf5;
@@ -620,8 +661,8 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
     if constexpr (S3 != 0 && CB == 16) {
         // AffNet / OriNet on split operands, same structure as the HardNet branch: conv0 .. conv2 in two half-patch passes on pre-split
         // layouts (conv1 / conv2 have 16 input channels: two taps per k = 32 step), conv3 .. conv5 whole.
-        typedef LayQ<16, 16, 18, 2 * CB, 0, TERMS> LQ2;                            // conv2 / conv3 outputs: 32 channels @16x16 (61 KB)
-        typedef LayQ<8, 8, 16, 4 * CB, 128, TERMS> LQ4;                         // conv4 output: 64 channels @8x8, row pitch 768 B (61 KB)
+        using LQ2 = std::conditional_t<TERMS == 2, LayR<16, 16, 20, 2 * CB, 16>, LayQ<16, 16, 18, 2 * CB, 0, 3>>;      // conv2 / conv3 outputs: 32 channels @16x16 (61 KB / 45 KB); see the HardNet branch
+        using LQ4 = std::conditional_t<TERMS == 2, LayR<8, 8, 12, 4 * CB, 0>, LayQ<8, 8, 16, 4 * CB, 128, 3>>;        // conv4 output: 64 channels @8x8 (61 KB / 30 KB)
         static_assert(LQH::BYTES <= TrunkLds<CB>::ACT * 4 && LQH2::BYTES <= TrunkLds<CB>::ACT * 4 && LQ2::BYTES <= TrunkLds<CB>::ACT * 4 && LQ4::BYTES <= TrunkLds<CB>::ACT * 4,
                       "pre-split layouts must fit the activation buffer");
         char* base = reinterpret_cast<char*>(act);
@@ -632,45 +673,70 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         // (128 VGPRs at two workgroups per CU: a loop's first weight fragments are requested right in front of it here - held across the
         // previous epilogue like in the HardNet branch they cost 17 / 23 spilled registers)
         S3W<1> wf1, wf2;
-        prefetch_bias_fresh<NW, 32, 8, 1>(a.packed + a.off.b[1], bias1, wave, lane);
-        conv0_half_split_q<NW, LQH, 1>(patch, w0, bias0, act, 0, wave, lane);
-        s3_prefetch_w0<NW, CB, CB, 32, 4, 1, TERMS>(a.packed + a.off.w_s3[1], wf1, wave, lane);
-        __syncthreads();
-        CNN_STAMP(2);
-        conv3x3_mfma_s3q<NW, CB, CB, LQH, 1, 4, 1>(act, a.packed + a.off.w_s3[1], wf1, acc_a, wave, lane, false);
-        __syncthreads();
-        if (tid < 6 * 32) {                                              // pass 0 left conv0 row 16 in the bottom halo row: zero again (3 terms x 2 groups x 32 cells)
-            const int t = tid >> 6, g = (tid >> 5) & 1, x = tid & 31;
-            *reinterpret_cast<f32x4*>(base + g * LQH::GS + (17 * LQH::WP + x + 1) * LQH::CELL + t * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
-        conv0_half_split_q<NW, LQH, 1>(patch, w0, bias0, act, 1, wave, lane);
-        s3_prefetch_w0<NW, CB, CB, 32, 4, 1, TERMS>(a.packed + a.off.w_s3[1], wf1, wave, lane);
-        __syncthreads();
-        conv3x3_mfma_s3q<NW, CB, CB, LQH, 1, 4, 1>(act, a.packed + a.off.w_s3[1], wf1, acc_b, wave, lane, false);
-        CNN_STAMP(3);
         f32x4 acc2_a[2][1], acc2_b[2][1], bias2[1];
-        {
-            int l2 = lane;
-            asm volatile("" : "+v"(l2));
-            bias2[0] = *reinterpret_cast<const f32x4*>(&a.packed[a.off.b[2] + (wave >> 2) * 16 + 4 * (l2 >> 4)]);
-        }
-        __syncthreads();
-        zero_halo_q<LQH2, NTHR>(act);                                    // another group stride than LQH (bank conflicts of the stride-2 reader)
-        store_tiles_split_q<CB, LQH2, 4, 1>(act, bias1, acc_a, wave, lane);
-        s3_prefetch_w0<NW, CB, 2 * CB, 8, 2, 1, TERMS>(a.packed + a.off.w_s3[2], wf2, wave, lane);
-        __syncthreads();
-        CNN_STAMP(4);
-        conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 2, 1>(act, a.packed + a.off.w_s3[2], wf2, acc2_a, wave, lane, false);
-        __syncthreads();
-        store_tiles_split_q<CB, LQH2, 4, 1>(act, bias1, acc_b, wave, lane);
-        if (wave == 7) {                                                 // conv1 row 15 (tiles 2, 3 of wave 7 in pass 0) = the top halo row of pass 1
-            const int n = lane & 15;
+        if constexpr (WHOLE) {
+            prefetch_bias_fresh<NW, 32, 8, 1>(a.packed + a.off.b[1], bias1, wave, lane);
+            conv0_whole_split_q<NW, LR0, 1>(patch, w0, bias0, act, wave, lane);
+            s3_prefetch_w0<NW, CB, CB, 32, 4, 1, TERMS>(a.packed + a.off.w_s3[1], wf1, wave, lane);
+            __syncthreads();
+            CNN_STAMP(2);
+            conv3x3_mfma_s3q<NW, CB, CB, LR0H, 1, 4, 1>(act, a.packed + a.off.w_s3[1], wf1, acc_a, wave, lane, false);
+            conv3x3_mfma_s3q<NW, CB, CB, LR0H, 1, 4, 1>(act + LR0::at(16, 0) / 4, a.packed + a.off.w_s3[1], wf1, acc_b, wave, lane, false);
+            CNN_STAMP(3);
+            {
+                int l2 = lane;
+                asm volatile("" : "+v"(l2));
+                bias2[0] = *reinterpret_cast<const f32x4*>(&a.packed[a.off.b[2] + (wave >> 2) * 16 + 4 * (l2 >> 4)]);
+            }
+            __syncthreads();
+            zero_halo_q<LR1, NTHR>(act);                                     // another group stride than LR0 (the stride-2 reader's): the halo cells move
+            store_tiles_split_q<CB, LR1, 4, 1, 16>(act, bias1, acc_a, wave, lane, 0);
+            store_tiles_split_q<CB, LR1, 4, 1, 16>(act, bias1, acc_b, wave, lane, 16);
+            s3_prefetch_w0<NW, CB, 2 * CB, 8, 2, 1, TERMS>(a.packed + a.off.w_s3[2], wf2, wave, lane);
+            __syncthreads();
+            CNN_STAMP(4);
+            conv3x3_mfma_s3q<NW, CB, 2 * CB, LR1H, 2, 2, 1>(act, a.packed + a.off.w_s3[2], wf2, acc2_a, wave, lane, false);
+            conv3x3_mfma_s3q<NW, CB, 2 * CB, LR1H, 2, 2, 1>(act + LR1::at(16, 0) / 4, a.packed + a.off.w_s3[2], wf2, acc2_b, wave, lane, false);
+        } else {
+            prefetch_bias_fresh<NW, 32, 8, 1>(a.packed + a.off.b[1], bias1, wave, lane);
+            conv0_half_split_q<NW, LQH, 1>(patch, w0, bias0, act, 0, wave, lane);
+            s3_prefetch_w0<NW, CB, CB, 32, 4, 1, TERMS>(a.packed + a.off.w_s3[1], wf1, wave, lane);
+            __syncthreads();
+            CNN_STAMP(2);
+            conv3x3_mfma_s3q<NW, CB, CB, LQH, 1, 4, 1>(act, a.packed + a.off.w_s3[1], wf1, acc_a, wave, lane, false);
+            __syncthreads();
+            if (tid < LQH::SLOTS * 2 * 32) {                                 // pass 0 left conv0 row 16 in the bottom halo row: zero again (slots x 2 groups x 32 cells)
+                const int t = tid >> 6, g = (tid >> 5) & 1, x = tid & 31;
+                *reinterpret_cast<f32x4*>(base + g * LQH::GS + LQH::at(17, x + 1) + t * LQH::TSTEP) = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            conv0_half_split_q<NW, LQH, 1>(patch, w0, bias0, act, 1, wave, lane);
+            s3_prefetch_w0<NW, CB, CB, 32, 4, 1, TERMS>(a.packed + a.off.w_s3[1], wf1, wave, lane);
+            __syncthreads();
+            conv3x3_mfma_s3q<NW, CB, CB, LQH, 1, 4, 1>(act, a.packed + a.off.w_s3[1], wf1, acc_b, wave, lane, false);
+            CNN_STAMP(3);
+            {
+                int l2 = lane;
+                asm volatile("" : "+v"(l2));
+                bias2[0] = *reinterpret_cast<const f32x4*>(&a.packed[a.off.b[2] + (wave >> 2) * 16 + 4 * (l2 >> 4)]);
+            }
+            __syncthreads();
+            zero_halo_q<LQH2, NTHR>(act);                                    // another group stride than LQH (bank conflicts of the stride-2 reader)
+            store_tiles_split_q<CB, LQH2, 4, 1>(act, bias1, acc_a, wave, lane);
+            s3_prefetch_w0<NW, CB, 2 * CB, 8, 2, 1, TERMS>(a.packed + a.off.w_s3[2], wf2, wave, lane);
+            __syncthreads();
+            CNN_STAMP(4);
+            conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 2, 1>(act, a.packed + a.off.w_s3[2], wf2, acc2_a, wave, lane, false);
+            __syncthreads();
+            store_tiles_split_q<CB, LQH2, 4, 1>(act, bias1, acc_b, wave, lane);
+            if (wave == 7) {                                                 // conv1 row 15 (tiles 2, 3 of wave 7 in pass 0) = the top halo row of pass 1
+                const int n = lane & 15;
 #pragma unroll
-            for (int i = 2; i < 4; ++i) split_store_tile_q<LQH2, 1>(base, ((i - 2) * 16 + n + 1) * LQH2::CELL, 0, bias1, acc_a[i], lane >> 4);
+                for (int i = 2; i < 4; ++i) split_store_tile_q<LQH2, 1>(base, LQH2::at(0, (i - 2) * 16 + n + 1), 0, bias1, acc_a[i], lane >> 4);
+            }
+            s3_prefetch_w0<NW, CB, 2 * CB, 8, 2, 1, TERMS>(a.packed + a.off.w_s3[2], wf2, wave, lane);
+            __syncthreads();
+            conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 2, 1>(act, a.packed + a.off.w_s3[2], wf2, acc2_b, wave, lane, false);
         }
-        s3_prefetch_w0<NW, CB, 2 * CB, 8, 2, 1, TERMS>(a.packed + a.off.w_s3[2], wf2, wave, lane);
-        __syncthreads();
-        conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 2, 1>(act, a.packed + a.off.w_s3[2], wf2, acc2_b, wave, lane, false);
         CNN_STAMP(5);
         // conv3 / conv4: four / two pixel tiles x ONE channel tile per wave (probe: conv3 64.8 % of the pipe floor vs 58.2 % for 2 x 2, conv4 60.6 % vs
         // 39.4 % for 1 x 2 - a weight fragment that feeds a single pixel tile leaves the loop waiting on L2)

@@ -381,8 +381,8 @@ __device__ __forceinline__ void split_remainder(f32x2& v, unsigned u) {
 // x ~ h + l, h = fp16(x), l = fp16(x - h) (both round-to-nearest-even; x - h is exact in fp32): 11 + 11 bits + the remainder's sign = 23 of
 // fp32's 24 significand bits, |x - h - l| <= 2^-23 |x| (rms ~2^-25).  w a = w_h a_h + w_l a_h + w_h a_l (+ w_l a_l <= 2^-24, dropped) on v_mfma_f32_16x16x32_f16: every fp16 x fp16 product is exact
 // in the fp32 accumulator and subnormal fp16 inputs are honoured (tools/probes/f16_split_probe.hip), so small activations keep an ABSOLUTE
-// error of 2^-25.  Half the matrix instructions of the three-term bf16 scheme; the layouts, loops and epilogues are the same code with
-// TERMS = 2 (LayQ keeps its 48-byte cells, the third slot stays unused, so every bank-conflict property carries over).
+// error of 2^-25.  Half the matrix instructions of the three-term bf16 scheme; the loops and epilogues are the same code with TERMS = 2, on
+// a layout of their own (LayR below: 16-byte pixels, two thirds of LayQ's bytes, conflict free for every reader).
 // Weights are packed times 2^e per layer (net_layout: w_h2) so that both terms sit in fp16's normal range; the loop multiplies its sums by
 // 2^-e (exact).  Activations are not scaled: |a| < 65504 required (include/affnet_hip.h).
 // The pair split is written in assembly: this compiler's own lowering of  <2 x float> -> <2 x half>  followed by element reads uses the LOW
@@ -397,7 +397,7 @@ __device__ __forceinline__ void split_h2_pair(f32x2 v, unsigned& hi, unsigned& l
 }
 
 // Split four fp32 values (a lane's four consecutive channels) into TERMS terms and store term t at dst + 16 t (8 bytes each: half a cell)
-template <int TERMS>
+template <int TERMS, int TSTEP = 16>
 __device__ __forceinline__ void split_store4(char* dst, f32x4 v) {
     f32x2 lo = {v.x, v.y}, hi = {v.z, v.w};
     if constexpr (TERMS == 2) {
@@ -405,13 +405,13 @@ __device__ __forceinline__ void split_store4(char* dst, f32x4 v) {
         split_h2_pair(lo, h0, l0);
         split_h2_pair(hi, h1, l1);
         *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
-        *reinterpret_cast<uint2*>(dst + 16) = make_uint2(l0, l1);
+        *reinterpret_cast<uint2*>(dst + TSTEP) = make_uint2(l0, l1);
     } else {
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const unsigned u0 = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, bf16x2));
             const unsigned u1 = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, bf16x2));
-            *reinterpret_cast<uint2*>(dst + t * 16) = make_uint2(u0, u1);
+            *reinterpret_cast<uint2*>(dst + t * TSTEP) = make_uint2(u0, u1);
             if (t < 2) { split_remainder(lo, u0); split_remainder(hi, u1); }
         }
     }
@@ -663,7 +663,31 @@ struct LayQ {
     static constexpr int GREM = GREM_;
     static constexpr int TERMS = TERMS_;                        // 3 bf16 terms or 2 fp16 terms per element (the cell keeps three 16-byte slots either way)
     static constexpr int CELL = 48;
-    static constexpr int GS = (((H_ + 2) * WP_ * CELL + 255) / 256) * 256 + GREM_;      // bytes per 8-channel group
+    // address pitches (bytes) every user goes through: right neighbour, the pixel below, next term of the same pixel; 16-byte slots per pixel
+    static constexpr int PIXB = CELL, ROWB = WP_ * CELL, TSTEP = 16, SLOTS = 3;
+    __device__ __host__ static constexpr int at(int y, int x) { return y * ROWB + x * PIXB; }      // (y, x) counted from the top-left halo cell
+    static constexpr int GS = (((H_ + 2) * ROWB + 255) / 256) * 256 + GREM_;      // bytes per 8-channel group
+    static constexpr int BYTES = (C_ / 8) * GS;
+};
+
+// Two-term layout with a 16-byte pixel pitch (AFFNET_ARITH_FP32_SPLIT2H): the hi cells and the lo cells of a ROW sit side by side - element (term t, channel c, y, x) at
+//   (c / 8) * GS + (y + 1) * ROWB + t * (WP * 16) + (x + 1) * 16 + (c % 8) * 2,   ROWB = 2 * WP * 16 bytes
+// - two thirds of LayQ's bytes (HardNet's conv0 output of a WHOLE patch fits: 148 KB), the second term still one immediate away, and with the pixel pitch a
+// divisor of the 256-byte bank window every reader of the trunks can be made conflict free (ds_read_b128 service groups {0-3, 12-15, 20-27} ..., 16-byte slots
+// mod 16; kq = lane quarter, its 8-channel group GS bytes further):
+//   stride 1, one-row tiles (32- / 16-wide layers): pixels 0-3, 12-15 of quarter kq and 4-11 of kq + 1 fill the 16 slots once with GS = 0 (mod 256);
+//   stride 1, two rows x 8 pixels (8-wide layers): the second row must start 8 slots later: ROWB / 16 = 2 WP = 8 (mod 16): WP = 12, GS = 0 (mod 256);
+//   stride 2, one-row tiles (32-wide input): pixel pitch 32 B = even slots only; quarter kq + 1 takes the odd ones with GS = 16 (mod 256);
+//   stride 2, two rows x 8 (16-wide input): rows 2 apart must start on the same slot: 4 WP = 0 (mod 16): WP = 20, and GS = 16 (mod 256) - the reader that
+//   kept 2-way conflicts in LayQ (conv4).
+// HALLOC_ = rows the group stride is sized for (default H + 2): a 16-row VIEW of a 32-row layout (the half-patch loops of conv1 / conv2) has HALLOC_ = 34
+template <int H_, int W_, int WP_, int C_, int GREM_ = 0, int HALLOC_ = H_ + 2>
+struct LayR {
+    static constexpr int H = H_, W = W_, WP = WP_, C = C_, GREM = GREM_;
+    static constexpr int TERMS = 2, SLOTS = 2;
+    static constexpr int PIXB = 16, ROWB = 2 * WP_ * 16, TSTEP = WP_ * 16;
+    __device__ __host__ static constexpr int at(int y, int x) { return y * ROWB + x * PIXB; }
+    static constexpr int GS = ((HALLOC_ * ROWB + 255) / 256) * 256 + GREM_;
     static constexpr int BYTES = (C_ / 8) * GS;
 };
 
@@ -671,14 +695,14 @@ template <typename L, int NTHR>
 __device__ __forceinline__ void zero_halo_q(float* act, int tid = threadIdx.x) {
     constexpr int H = L::H, W = L::W, CELLS = 2 * (W + 2) + 2 * H, GROUPS = L::C / 8;
     char* base = reinterpret_cast<char*>(act);
-    for (int i = tid; i < GROUPS * CELLS * 3; i += NTHR) {           // one 16-byte store = one term of one halo cell
-        const int t = i % 3, ce = i / 3;
+    for (int i = tid; i < GROUPS * CELLS * L::SLOTS; i += NTHR) {    // one 16-byte store = one term of one halo cell
+        const int t = i % L::SLOTS, ce = i / L::SLOTS;
         const int g = ce / CELLS, e = ce - g * CELLS;
         int y, x;
         if (e < W + 2) { y = 0; x = e; }
         else if (e < 2 * (W + 2)) { y = H + 1; x = e - (W + 2); }
         else { const int r = e - 2 * (W + 2); y = 1 + (r >> 1); x = (r & 1) ? W + 1 : 0; }
-        *reinterpret_cast<f32x4*>(base + (size_t)g * L::GS + (y * L::WP + x) * L::CELL + t * 16) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(base + (size_t)g * L::GS + L::at(y, x) + t * L::TSTEP) = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
 }
 
@@ -692,7 +716,7 @@ __device__ __forceinline__ void split_store_tile_q(char* base, int cell, int nt0
         v.x = fmaxf(v.x, 0.0f); v.y = fmaxf(v.y, 0.0f); v.z = fmaxf(v.z, 0.0f); v.w = fmaxf(v.w, 0.0f);
         const int c0 = (nt0 + j) * 16 + 4 * g;                           // first of this lane's 4 channels
         char* dst = base + (c0 >> 3) * LO::GS + cell + (c0 & 4) * 2;
-        split_store4<LO::TERMS>(dst, v);
+        split_store4<LO::TERMS, LO::TSTEP>(dst, v);
     }
 }
 
@@ -707,7 +731,7 @@ __device__ __forceinline__ void store_tiles_split_q(float* act, const f32x4 (&bi
     for (int i = 0; i < TM; ++i) {
         const int p = (mg * TM + i) * 16 + n;
         const int oy = p / W, ox = p - oy * W;
-        split_store_tile_q<LO, TN>(base, ((oy + row_off + 1) * LO::WP + ox + 1) * LO::CELL, ng * TN, bias, acc[i], g);
+        split_store_tile_q<LO, TN>(base, LO::at(oy + row_off + 1, ox + 1), ng * TN, bias, acc[i], g);
     }
 }
 
@@ -767,11 +791,11 @@ __device__ __forceinline__ void conv3x3_mfma_s3q(const float* act, const float* 
     {
         const int p = mg * TM * 16 + m;
         const int oy = p / WOUT, ox = p - oy * WOUT;
-        a_lane = (C16 ? (kq & 1) : kq) * LI::GS + ((oy * STRIDE) * LI::WP + ox * STRIDE) * LI::CELL;
+        a_lane = (C16 ? (kq & 1) : kq) * LI::GS + LI::at(oy * STRIDE, ox * STRIDE);
     }
     const unsigned a_addr0 = lds_byte_addr(act) + a_lane;
-    auto a_imm = [](int i) { return LI::CELL * (WOUT == 8 ? i * 2 * STRIDE * LI::WP : (((i * 16) / WOUT) * STRIDE * LI::WP + ((i * 16) % WOUT) * STRIDE)); };
-    static_assert(LI::CELL * ((TM - 1) * 2 * STRIDE * LI::WP + 2 * STRIDE * LI::WP) + 32 < 65536, "tile immediates must fit the DS offset field");
+    auto a_imm = [](int i) { return WOUT == 8 ? LI::at(i * 2 * STRIDE, 0) : LI::at(((i * 16) / WOUT) * STRIDE, ((i * 16) % WOUT) * STRIDE); };
+    static_assert(LI::at(TM * 2 * STRIDE, 0) + 2 * LI::TSTEP < 65536, "tile immediates must fit the DS offset field");
     constexpr int WS_FLOATS = (C16 ? 5 : 9 * NG32) * TERMS * 4 * COUT * 4;
     const __amdgpu_buffer_rsrc_t wrsrc = weight_rsrc(Ws, WS_FLOATS);
     const int w_lane = s3_w_lane<NW, COUT, MG, TN>(wave, lane);
@@ -782,12 +806,12 @@ __device__ __forceinline__ void conv3x3_mfma_s3q(const float* act, const float* 
     auto frag_addr = [&](int s) -> unsigned {
         if (C16) {
             const int ta = 2 * s, tb = (2 * s + 1 < 9) ? 2 * s + 1 : 8;
-            const int off_a = ((ta / 3) * LI::WP + ta % 3) * LI::CELL, off_b = ((tb / 3) * LI::WP + tb % 3) * LI::CELL;
+            const int off_a = LI::at(ta / 3, ta % 3), off_b = LI::at(tb / 3, tb % 3);
             return a_addr0 + ((kq >> 1) ? off_b : off_a);
         }
         const int tap = s / NG32, G = s - tap * NG32;
         const int ky = (tap * 11) >> 5, kx = tap - 3 * ky;
-        return a_addr0 + 4 * G * LI::GS + (ky * LI::WP + kx) * LI::CELL;
+        return a_addr0 + 4 * G * LI::GS + LI::at(ky, kx);
     };
     bf16x8 a[TM][TERMS];
     S3W<TN> wb[2];
@@ -797,7 +821,7 @@ __device__ __forceinline__ void conv3x3_mfma_s3q(const float* act, const float* 
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int t = 0; t < TERMS; ++t) a[i][t] = __builtin_bit_cast(bf16x8, lds_read4(ab + a_imm(i) + t * 16));
+            for (int t = 0; t < TERMS; ++t) a[i][t] = __builtin_bit_cast(bf16x8, lds_read4(ab + a_imm(i) + t * LI::TSTEP));
     }
     auto pair_mfma = [&](const S3W<TN>& wc, int tw, int ta) {
 #pragma unroll
@@ -813,7 +837,7 @@ __device__ __forceinline__ void conv3x3_mfma_s3q(const float* act, const float* 
     auto reload = [&](unsigned ab, int t) {
         if constexpr (PROBE & 2) return;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) a[i][t] = __builtin_bit_cast(bf16x8, lds_read4(ab + a_imm(i) + t * 16));
+        for (int i = 0; i < TM; ++i) a[i][t] = __builtin_bit_cast(bf16x8, lds_read4(ab + a_imm(i) + t * LI::TSTEP));
     };
     constexpr int NT_ = TM * TN;
     // the term pairs of one step in term-major order, every activation term reloaded (for the next step) right after its last use;
@@ -967,7 +991,37 @@ __device__ __forceinline__ void conv0_half_split_q(const float* patch, const flo
         for (int s3 = 0; s3 < 3; ++s3)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s3][j], av[s3], acc[j], 0, 0, 0);
-        split_store_tile_q<LQH, TN, false>(base, ((row_l + 1) * LQH::WP + x0 + m + 1) * LQH::CELL, 0, bv, acc, kq);
+        split_store_tile_q<LQH, TN, false>(base, LQH::at(row_l + 1, x0 + m + 1), 0, bv, acc, kq);
+    }
+}
+
+// conv0 of a WHOLE 32 x 32 patch straight into a pre-split layout L (32 rows x 32 columns; two-term arithmetic: LayR holds it in 145 KB for 32 channels)
+template <int NW, typename L, int TN>
+__device__ __forceinline__ void conv0_whole_split_q(const float* patch, const float (&b)[3][TN], const f32x4 (&bv)[TN], float* act, int wave, int lane) {
+    static_assert(NW == 8 && L::H == 32 && L::W == 32 && L::C == 16 * TN, "whole-patch conv0: 8 waves x 8 pixel tiles, all channel tiles in every wave");
+    const int m = lane & 15, kq = lane >> 4;
+    int toff[3];
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+        const int t = 4 * s3 + kq;
+        toff[s3] = t < 9 ? (t / 3) * WP32 + (t % 3) : 0;
+    }
+    char* base = reinterpret_cast<char*>(act);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int T = 8 * wave + k, row = T >> 1, x0 = (T & 1) * 16;
+        const int pb = row * WP32 + x0 + m;
+        float av[3];
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) av[s3] = patch[pb + toff[s3]];
+        f32x4 acc[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[j] = bv[j];
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(b[s3][j], av[s3], acc[j], 0, 0, 0);
+        split_store_tile_q<L, TN, false>(base, L::at(row + 1, x0 + m + 1), 0, bv, acc, kq);
     }
 }
 

@@ -269,8 +269,8 @@ __global__ __launch_bounds__(512, 4) void dense_conv_s3_kernel(DenseArgs a) {
         const int Y = Y0 + ty - 1, X = X0 + tx - 1;
         f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (Y >= 0 && Y < a.Hin && X >= 0 && X < a.Win) v = *reinterpret_cast<const f32x4*>(in + g * plane + ((size_t)Y * a.Win + X) * 4);
-        char* dst = actb + (g >> 1) * LQ::GS + (ty * LQ::WP + tx) * LQ::CELL + (g & 1) * 8;
-        split_store4<LQ::TERMS>(dst, v);
+        char* dst = actb + (g >> 1) * LQ::GS + LQ::at(ty, tx) + (g & 1) * 8;
+        split_store4<LQ::TERMS, LQ::TSTEP>(dst, v);
     }
     __syncthreads();
     f32x4 acc[TM][TN];
@@ -431,22 +431,22 @@ int aff_fullconv_launch(affnet_ctx* ctx, const float* packed, const float* img, 
         };
         // (register blockings as in the per-patch split trunks: one channel tile per wave for conv3 / conv4, tools/probes/s3_loop_probe)
         // Q1: conv1 input tile, 16 rows x 32 columns, 16 channels (59 KB); Q2: conv2 (stride 2); Q3: conv3 / conv4 input tiles (61 KB); Q5: conv5 (61 KB)
-#define DENSE_S3(CI, CO, STR, H_, W_, WP_, GREM, TM_, TN_, GX, GY)                                                                                 \
+#define DENSE_S3(CI, CO, STR, H_, W_, WP_, GREM, WPR, GREMR, TM_, TN_, GX, GY)   /* LayQ (three terms): WP_, GREM; LayR (two terms): WPR, GREMR - cnn_mfma.h */             \
         do {                                                                                                                                     \
-            if (h2) hipLaunchKernelGGL((dense_conv_s3_kernel<CI, CO, STR, LayQ<H_, W_, WP_, CI, GREM, 2>, TM_, TN_>), dim3(GX, GY, B), dim3(512), 0, st, a); \
+            if (h2) hipLaunchKernelGGL((dense_conv_s3_kernel<CI, CO, STR, LayR<H_, W_, WPR, CI, GREMR>, TM_, TN_>), dim3(GX, GY, B), dim3(512), 0, st, a);   \
             else hipLaunchKernelGGL((dense_conv_s3_kernel<CI, CO, STR, LayQ<H_, W_, WP_, CI, GREM, 3>, TM_, TN_>), dim3(GX, GY, B), dim3(512), 0, st, a);  \
             AFF_LAUNCH_CHECK(ctx);                                                                                                               \
         } while (0)
         layer3(1, bufA, bufB, g.Hp, g.Wp, g.Hp, g.Wp);
-        DENSE_S3(16, 16, 1, 16, 32, 34, 0, 4, 1, aff_cdiv(g.Wp, 32), aff_cdiv(g.Hp, 16));
+        DENSE_S3(16, 16, 1, 16, 32, 34, 0, 34, 0, 4, 1, aff_cdiv(g.Wp, 32), aff_cdiv(g.Hp, 16));
         layer3(2, bufB, bufA, g.Hp, g.Wp, g.H2, g.W2);
-        DENSE_S3(16, 32, 2, 16, 32, 34, 16, 2, 1, aff_cdiv(g.Wp, 32), aff_cdiv(g.Hp, 16));
+        DENSE_S3(16, 32, 2, 16, 32, 34, 16, 34, 16, 2, 1, aff_cdiv(g.Wp, 32), aff_cdiv(g.Hp, 16));
         layer3(3, bufA, bufB, g.H2, g.W2, g.H2, g.W2);
-        DENSE_S3(32, 32, 1, 16, 16, 18, 0, 4, 1, aff_cdiv(g.W2, 16), aff_cdiv(g.H2, 16));
+        DENSE_S3(32, 32, 1, 16, 16, 18, 0, 20, 0, 4, 1, aff_cdiv(g.W2, 16), aff_cdiv(g.H2, 16));
         layer3(4, bufB, bufA, g.H2, g.W2, g.H4, g.W4);
-        DENSE_S3(32, 64, 2, 16, 16, 18, 0, 2, 1, aff_cdiv(g.W2, 16), aff_cdiv(g.H2, 16));
+        DENSE_S3(32, 64, 2, 16, 16, 18, 0, 20, 16, 2, 1, aff_cdiv(g.W2, 16), aff_cdiv(g.H2, 16));
         layer3(5, bufA, bufB, g.H4, g.W4, g.H4, g.W4);
-        DENSE_S3(64, 64, 1, 8, 8, 16, 128, 2, 1, aff_cdiv(g.W4, 8), aff_cdiv(g.H4, 8));
+        DENSE_S3(64, 64, 1, 8, 8, 16, 128, 12, 0, 2, 1, aff_cdiv(g.W4, 8), aff_cdiv(g.H4, 8));
 #undef DENSE_S3
     } else {
     layer(1, bufA, bufB, g.Hp, g.Wp, g.Hp, g.Wp);

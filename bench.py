@@ -588,6 +588,8 @@ def run(args, world):
                                                                 AffNet=A, OriNet=O, arith=args.arith).to(dev)
             if args.all_candidates:
                 dets[k].lazy_shape_rows = 0
+            elif os.environ.get("AFFNET_BENCH_LAZY_ROWS"):              # tuning aid: size of the first AffNet pass (default N + N / 5; same output rows for any value)
+                dets[k].lazy_shape_rows = int(os.environ["AFFNET_BENCH_LAZY_ROWS"])
             dets[k]._context(c, allow_batch=True)  # create contexts / workspaces before anything is timed
     streams = [torch.cuda.Stream(device=dev) for _ in range(S)]
     det_stream = torch.cuda.Stream(device=dev) if PIPE else None

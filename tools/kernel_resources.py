@@ -121,7 +121,7 @@ DESIGN_KERNELS = [
     ("blur2d_pair_kernel<15, 9, 4>", "paired blur 15 x 15 / 9 x 9"),
     ("dense_conv_kernel<32, 32, 1", "dense AffNetFastFullConv conv3, exact"),
     ("dense_conv_s3_kernel<32, 32, 1, LayQ<16, 16, 18, 32, 0, 3>", "dense AffNetFastFullConv conv3, arith fp32_split3"),
-    ("dense_conv_s3_kernel<32, 32, 1, LayQ<16, 16, 18, 32, 0, 2>", "dense AffNetFastFullConv conv3, arith fp32_split2h"),
+    ("dense_conv_s3_kernel<32, 32, 1, LayR<16, 16, 20, 32", "dense AffNetFastFullConv conv3, arith fp32_split2h"),
 ]
 
 
