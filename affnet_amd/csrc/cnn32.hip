@@ -541,28 +541,30 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         S3W<2> wf1;
         S3W<1> wf2;
         f32x4 acc2_a[4][1], acc2_b[4][1], bias2[1];
+        f32x4 acc2w[4][2], bias2w[2];                                    // (two-term flow: conv2 as one 4 x 2 loop)
         if constexpr (WHOLE) {
-            s3_prefetch_w0<NW, CB, CB, 32, 4, 2, TERMS>(a.packed + a.off.w_s3[1], wf1, wave, lane);
+            // two terms: conv0 once, then conv1 as ONE loop over the whole patch (8 pixel tiles x 2 channel tiles per wave: the weights stream once, not once per half)
+            // and conv2 as one 4 x 2 loop
+            f32x4 acc1[8][2];
+            S3W<2> wf2w;
+            s3_prefetch_w0<NW, CB, CB, 64, 8, 2, TERMS>(a.packed + a.off.w_s3[1], wf1, wave, lane);
             prefetch_bias<NW, 32, 8, 2>(a.packed + a.off.b[1], bias1, wave, lane);
             conv0_whole_split_q<NW, LR0, 2>(patch, w0, bias0, act, wave, lane);
             __syncthreads();
             CNN_STAMP(2);
             if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3q<NW, CB, CB, LR0H, 1, 4, 2>(act, a.packed + a.off.w_s3[1], wf1, acc_a, wave, lane, s3_alt);
-            conv3x3_mfma_s3q<NW, CB, CB, LR0H, 1, 4, 2>(act + LR0::at(16, 0) / 4, a.packed + a.off.w_s3[1], wf1, acc_b, wave, lane, s3_alt);
+            conv3x3_mfma_s3q<NW, CB, CB, LR0, 1, 8, 2>(act, a.packed + a.off.w_s3[1], wf1, acc1, wave, lane, s3_alt);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
             CNN_STAMP(3);
-            s3_prefetch_w0<NW, CB, 2 * CB, 8, 4, 1, TERMS>(a.packed + a.off.w_s3[2], wf2, wave, lane);
-            bias2[0] = *reinterpret_cast<const f32x4*>(&a.packed[a.off.b[2] + (wave >> 1) * 16 + 4 * (lane >> 4)]);      // MG = 8 tiles / 4 = 2: channel tile = wave / 2
+            s3_prefetch_w0<NW, CB, 2 * CB, 16, 4, 2, TERMS>(a.packed + a.off.w_s3[2], wf2w, wave, lane);
+            prefetch_bias<NW, 16, 4, 2>(a.packed + a.off.b[2], bias2w, wave, lane);
             __syncthreads();
             zero_halo_q<LR1, NTHR>(act);                                 // another group stride than LR0 (the stride-2 reader's): the halo cells move
-            store_tiles_split_q<CB, LR1, 4, 2, 16>(act, bias1, acc_a, wave, lane, 0);
-            store_tiles_split_q<CB, LR1, 4, 2, 16>(act, bias1, acc_b, wave, lane, 16);
+            store_tiles_split_q<CB, LR1, 8, 2>(act, bias1, acc1, wave, lane);
             __syncthreads();
             CNN_STAMP(4);
             if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3q<NW, CB, 2 * CB, LR1H, 2, 4, 1>(act, a.packed + a.off.w_s3[2], wf2, acc2_a, wave, lane, s3_alt);
-            conv3x3_mfma_s3q<NW, CB, 2 * CB, LR1H, 2, 4, 1>(act + LR1::at(16, 0) / 4, a.packed + a.off.w_s3[2], wf2, acc2_b, wave, lane, s3_alt);
+            conv3x3_mfma_s3q<NW, CB, 2 * CB, LR1, 2, 4, 2>(act, a.packed + a.off.w_s3[2], wf2w, acc2w, wave, lane, s3_alt);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
         } else {
             s3_prefetch_w0<NW, CB, CB, 32, 4, 2, TERMS>(a.packed + a.off.w_s3[1], wf1, wave, lane);
@@ -616,8 +618,11 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
         prefetch_bias<NW, 16, 4, 2>(a.packed + a.off.b[3], bias3, wave, lane);
         __syncthreads();
         zero_halo_q<LQ2, NTHR>(act);
-        store_tiles_split_q<2 * CB, LQ2, 4, 1, 8>(act, bias2, acc2_a, wave, lane, 0);
-        store_tiles_split_q<2 * CB, LQ2, 4, 1, 8>(act, bias2, acc2_b, wave, lane, 8);
+        if constexpr (WHOLE) store_tiles_split_q<2 * CB, LQ2, 4, 2>(act, bias2w, acc2w, wave, lane);
+        else {
+            store_tiles_split_q<2 * CB, LQ2, 4, 1, 8>(act, bias2, acc2_a, wave, lane, 0);
+            store_tiles_split_q<2 * CB, LQ2, 4, 1, 8>(act, bias2, acc2_b, wave, lane, 8);
+        }
         __syncthreads();
         CNN_STAMP(6);
         {
