@@ -666,7 +666,9 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
     if constexpr (S3 != 0 && CB == 16) {
         // AffNet / OriNet on split operands, same structure as the HardNet branch: conv0 .. conv2 in two half-patch passes on pre-split
         // layouts (conv1 / conv2 have 16 input channels: two taps per k = 32 step), conv3 .. conv5 whole.
-        using LQ2 = std::conditional_t<TERMS == 2, LayR<16, 16, 20, 2 * CB, 16>, LayQ<16, 16, 18, 2 * CB, 0, 3>>;      // conv2 / conv3 outputs: 32 channels @16x16 (61 KB / 45 KB); see the HardNet branch
+        // conv2 / conv3 outputs: 32 channels @16x16 (61 KB / 45 KB).  LayR: GS = 0 (mod 256) here - with two workgroups per CU conv3's one-row reader is LDS-bound and the
+        // doubled slot of the HardNet branch's choice costs it 15 % (probe: 7.1 k vs 6.2 k cycles), while conv4 (2 x 1 tiles) is the same with or without its 2-way conflicts
+        using LQ2 = std::conditional_t<TERMS == 2, LayR<16, 16, 20, 2 * CB, 0>, LayQ<16, 16, 18, 2 * CB, 0, 3>>;
         using LQ4 = std::conditional_t<TERMS == 2, LayR<8, 8, 12, 4 * CB, 0>, LayQ<8, 8, 16, 4 * CB, 128, 3>>;        // conv4 output: 64 channels @8x8 (61 KB / 30 KB)
         static_assert(LQH::BYTES <= TrunkLds<CB>::ACT * 4 && LQH2::BYTES <= TrunkLds<CB>::ACT * 4 && LQ2::BYTES <= TrunkLds<CB>::ACT * 4 && LQ4::BYTES <= TrunkLds<CB>::ACT * 4,
                       "pre-split layouts must fit the activation buffer");
