@@ -111,7 +111,7 @@ __global__ __launch_bounds__(512, (Shape<SHAPE>::CB == 32) ? 2 : 4) void probe_k
             constexpr int PBITS = VAR == 9 ? 1 : (VAR == 10 ? 2 : (VAR == 11 ? 3 : (VAR == 12 ? (1 << 4) : (VAR == 13 ? (3 << 4) : (VAR == 14 ? (6 << 4) : 0)))));
             if constexpr (VAR == 15) {          // AFFNET_ARITH_FP32_SPLIT2H: the same cells and loop with two fp16 terms, three products
                 // the trunks' two-term layouts (LayR: 16-byte pixels; row pitch / group stride per reader as in cnn32.hip)
-                typedef LayR<S::LQ::H, S::LQ::W, (S::LQ::W == 16 ? 20 : (S::LQ::W == 8 ? 12 : 34)), S::LQ::C, ((S::STRIDE == 2 || S::LQ::W == 16) ? 16 : 0)> LQ2T;
+                typedef LayR<S::LQ::H, S::LQ::W, (S::LQ::W == 16 ? 20 : (S::LQ::W == 8 ? 12 : 34)), S::LQ::C, ((S::STRIDE == 2 || (S::LQ::W == 16 && S::CB == 32)) ? 16 : 0)> LQ2T;
                 s3_prefetch_w0<NW, S::CIN, S::COUT, MT, S::TM, S::TN, 2>(Ws, w0, wave, lane);
                 conv3x3_mfma_s3q<NW, S::CIN, S::COUT, LQ2T, S::STRIDE, S::TM, S::TN, 0>(lds, Ws, w0, acc, wave, lane, alt);
             } else
