@@ -524,9 +524,10 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
     // inside the loops.  Round 3's tile-major loops gained 2.5 % from it; with the term-major loops it costs 1 % (default off).
     const int s3_alt = KIND == AFFNET_NET_HARDNET ? a.s3_alt : 0;       // variant bits for the loops (conv3x3_mfma_s3q)
     if constexpr (S3 != 0 && KIND == AFFNET_NET_HARDNET) {
-        // conv2 / conv3 outputs, 64 channels @16x16 (122 KB / 90 KB): read at stride 1 (conv3) and, conv3's output written in place, at stride 2 (conv4).  LayR: the group
-        // stride is conv4's (GS = 16 mod 256, conflict free); conv3's one-row reader then has one doubled slot per 16 lanes (5 instead of 4 LDS cycles per fragment read,
-        // no measurable cost at 8 reads per 24 MFMAs) - a second layout with GS = 0 for conv3 cost 0.8 k cycles per patch for zeroing its halo again (measured)
+        // conv2 / conv3 outputs, 64 channels @16x16 (122 KB / 90 KB): read at stride 1 (conv3) and, conv3's output written in place, at stride 2 (conv4).  No group
+        // stride serves both readers (tools/lds_bank_model.py): GS = 0 (mod 256) leaves conv4's two-row reader with 2-way conflicts, GS = 16 conv3's one-row reader.
+        // LayR takes conv4's here: its 4 x 1 tiles are the more LDS-bound (probe: -1350 cycles for conv4, +300 for conv3's 4 x 2); a second layout for conv3's
+        // output with the other stride cost 0.8 k cycles per patch for zeroing its halo again (measured)
         using LQ2 = std::conditional_t<TERMS == 2, LayR<16, 16, 20, 2 * CB, 16>, LayQ<16, 16, 18, 2 * CB, 0, 3>>;
         using LQ4 = std::conditional_t<TERMS == 2, LayR<8, 8, 12, 4 * CB, 0>, LayQ<8, 8, 16, 4 * CB, 128, 3>>;        // conv4 output: 128 channels @8x8 (122 KB / 60 KB)
         static_assert(LQ2::BYTES <= TrunkLds<CB>::ACT * 4 && LQ4::BYTES <= TrunkLds<CB>::ACT * 4 && LQH::BYTES <= TrunkLds<CB>::ACT * 4 &&
@@ -666,8 +667,8 @@ __global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4)
     if constexpr (S3 != 0 && CB == 16) {
         // AffNet / OriNet on split operands, same structure as the HardNet branch: conv0 .. conv2 in two half-patch passes on pre-split
         // layouts (conv1 / conv2 have 16 input channels: two taps per k = 32 step), conv3 .. conv5 whole.
-        // conv2 / conv3 outputs: 32 channels @16x16 (61 KB / 45 KB).  LayR: GS = 0 (mod 256) here - with two workgroups per CU conv3's one-row reader is LDS-bound and the
-        // doubled slot of the HardNet branch's choice costs it 15 % (probe: 7.1 k vs 6.2 k cycles), while conv4 (2 x 1 tiles) is the same with or without its 2-way conflicts
+        // conv2 / conv3 outputs: 32 channels @16x16 (61 KB / 45 KB).  LayR: GS = 0 (mod 256) here - with two workgroups per CU conv3's one-row reader is LDS-bound and
+        // the 2-way conflicts of the HardNet branch's choice cost it 10 % (probe: 7.1 k vs 6.5 k cycles), while conv4 (2 x 1 tiles) is the same with or without its own
         using LQ2 = std::conditional_t<TERMS == 2, LayR<16, 16, 20, 2 * CB, 0>, LayQ<16, 16, 18, 2 * CB, 0, 3>>;
         using LQ4 = std::conditional_t<TERMS == 2, LayR<8, 8, 12, 4 * CB, 0>, LayQ<8, 8, 16, 4 * CB, 128, 3>>;        // conv4 output: 64 channels @8x8 (61 KB / 30 KB)
         static_assert(LQH::BYTES <= TrunkLds<CB>::ACT * 4 && LQH2::BYTES <= TrunkLds<CB>::ACT * 4 && LQ2::BYTES <= TrunkLds<CB>::ACT * 4 && LQ4::BYTES <= TrunkLds<CB>::ACT * 4,

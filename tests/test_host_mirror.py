@@ -395,3 +395,22 @@ def test_roofline_table_regenerates_from_the_tracked_evidence():
     fracs = [float(m) for m in re.findall(r"= ([0-9.]+) % of 157\.3", out.stdout)]
     assert len(fracs) >= 4 and max(fracs) < 100.0 and max(fracs) > 80.0, fracs
     assert "bench line:" in out.stdout
+
+def test_lds_bank_model_of_the_split_layouts():
+    """tools/lds_bank_model.py (service groups and bank rules of MI355X_MICROARCH.md, section LDS) on the layouts the split-operand trunks use: every
+    fragment read of the loops is conflict free (4 LDS cycles) except the ONE reader per net and mode the design knowingly leaves with 2-way conflicts
+     - conv4 in LayQ, conv3 (HardNet) / conv4 (16-channel nets) in LayR, whose output buffer two readers with opposite group strides
+    share.  A change of a row pitch or group stride in cnn32.hip that breaks this has to show up here (the model mirrors those parameters)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import lds_bank_model as bm
+    got = {name: bm.read_cycles(L, stride, c16) for name, L, stride, c16 in bm.readers()}
+    slow = {k for k, v in got.items() if v != 4}
+    assert slow == {"HardNet fp32_split3 conv4 (stride 2, 16-wide)", "AffNet / OriNet fp32_split3 conv4 (stride 2, 16-wide)",
+                    "HardNet fp32_split2h conv3 (stride 1, 16-wide)", "AffNet / OriNet fp32_split2h conv4 (stride 2, 16-wide)"}, got
+    assert all(got[k] == 8 for k in slow), got
+    # the parameters the model mirrors are the ones in the kernel source
+    src = open(os.path.join(ROOT, "affnet_amd", "csrc", "cnn32.hip")).read()
+    for frag in ("LayR<32, 32, 34, CB, 0>", "LayR<32, 32, 34, CB, 16>", "LayR<16, 16, 20, 2 * CB, 16>, LayQ<16, 16, 18, 2 * CB, 0, 3>", "LayR<16, 16, 20, 2 * CB, 0>, LayQ<16, 16, 18, 2 * CB, 0, 3>",
+                 "LayR<8, 8, 12, 4 * CB, 0>, LayQ<8, 8, 16, 4 * CB, 128, 3>", "LayQ<16, 32, 34, CB, 0, 3>", "LayQ<16, 32, 34, CB, 16, 3>"):
+        assert frag in src, frag
+    assert open(os.path.join(ROOT, "profiles", "r04_lds_bank_model.txt")).read().count(" 4\n") >= 16
