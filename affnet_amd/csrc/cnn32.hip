@@ -23,6 +23,7 @@
 #include <math.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <type_traits>
 
 #include "common.h"
@@ -96,7 +97,7 @@ extern "C" int affnet_cnn32_pack_weights(int kind, const float* const* conv_w, c
             const float sc = 1.0f / sqrtf(bn_var[i][n] + 1e-5f);
             for (int k = 0; k < ci * 9; ++k) wmax = fmaxf(wmax, fabsf(conv_w[i][(size_t)n * ci * 9 + k] * sc));
         }
-        const int e = (wmax > 0.0f && std::isfinite(wmax)) ? 13 - ilogbf(wmax) : 0;
+        const int e = (wmax > 0.0f && std::isfinite(wmax)) ? std::min(100, std::max(-100, 13 - ilogbf(wmax))) : 0;      // (clamped: 2^-e must stay a normal fp32)
         out[L.w_h2[i] + s3_floats(ci, co, 2)] = ldexpf(1.0f, -e);
         for (int n = 0; n < co; ++n) {
             const float sc = 1.0f / sqrtf(bn_var[i][n] + 1e-5f);
@@ -126,7 +127,7 @@ extern "C" int affnet_cnn32_pack_weights(int kind, const float* const* conv_w, c
                 const float sc = 1.0f / sqrtf(head_bn_var[n] + 1e-5f);
                 for (int k = 0; k < HEAD_K; ++k) wmax = fmaxf(wmax, fabsf(head_w[(size_t)n * HEAD_K + k] * sc));
             }
-            const int e = (wmax > 0.0f && std::isfinite(wmax)) ? 13 - ilogbf(wmax) : 0;
+            const int e = (wmax > 0.0f && std::isfinite(wmax)) ? std::min(100, std::max(-100, 13 - ilogbf(wmax))) : 0;      // (clamped: 2^-e must stay a normal fp32)
             out[L.head_h2 + (size_t)HEAD_K * 128] = ldexpf(1.0f, -e);
             for (int n = 0; n < 128; ++n) {
                 const float sc = 1.0f / sqrtf(head_bn_var[n] + 1e-5f);
