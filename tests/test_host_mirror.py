@@ -414,3 +414,14 @@ def test_lds_bank_model_of_the_split_layouts():
                  "LayR<8, 8, 12, 4 * CB, 0>, LayQ<8, 8, 16, 4 * CB, 128, 3>", "LayQ<16, 32, 34, CB, 0, 3>", "LayQ<16, 32, 34, CB, 16, 3>"):
         assert frag in src, frag
     assert open(os.path.join(ROOT, "profiles", "r04_lds_bank_model.txt")).read().count(" 4\n") >= 16
+
+def test_split_arithmetics_error_class_cpu_emulation():
+    """tools/split2h_numerics.py: conv-like dot products (K = 288, post-ReLU activations x N(0, 0.05) weights) against fp64 - the three-bf16-term and the
+    (weight-scaled) two-fp16-term summations are not less accurate than the fp32 fmaf chain of the exact mode; without the weight scale the two-term form is
+    (the reason the copies are packed times 2^e).  What include/affnet_hip.h states about AFFNET_ARITH_FP32_SPLIT3 / _SPLIT2H."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import split2h_numerics as sn
+    r = sn.errors(288, M=1024)
+    assert r["bf16x3"][0] <= r["fp32_chain"][0] and r["fp16x2"][0] <= r["fp32_chain"][0], r
+    assert r["fp16x2"][1] <= 1.2 * r["fp32_chain"][1] and r["fp16x2_unscaled"][0] > 1.5 * r["fp16x2"][0], r
+    assert r["fp32_chain"][0] < 1e-7 and r["fp16x2"][0] < 5e-8

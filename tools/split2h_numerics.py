@@ -9,8 +9,6 @@ inside a k = 32 step is not modelled).  Prints rms and max of |result - fp64| / 
 import numpy as np
 import torch
 
-rng = np.random.default_rng(0)
-
 
 def bf16(x):
     return torch.from_numpy(x.astype(np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
@@ -34,8 +32,9 @@ def chunked(xa, wa, pairs, K, M):
     return acc
 
 
-for K in (144, 288, 576, 1152, 8192):
-    M = 4096
+def errors(K, M=4096, rng=None):
+    """rms / max of |result - fp64| / sum|x||w| for the four summations on M conv-like dot products of length K."""
+    rng = rng or np.random.default_rng(0)
     X = np.maximum(rng.standard_normal((M, K)), 0).astype(np.float32) * rng.choice([1e-3, 1, 1, 3], size=(M, K)).astype(np.float32)
     W = (rng.standard_normal(K) * 0.05).astype(np.float32)
     ref = X.astype(np.float64) @ W.astype(np.float64)
@@ -48,5 +47,12 @@ for K in (144, 288, 576, 1152, 8192):
     s = 2.0 ** (13 - np.floor(np.log2(np.abs(W).max())))
     e2 = np.abs(chunked(split_h2(X), split_h2(W * np.float32(s)), ((0, 0), (1, 0), (0, 1)), K, M) / np.float32(s) - ref) / den
     e2n = np.abs(chunked(split_h2(X), split_h2(W), ((0, 0), (1, 0), (0, 1)), K, M) - ref) / den
-    print("K %5d | fp32 chain rms %.2e max %.2e | bf16 x 3 rms %.2e max %.2e | fp16 x 2 (weights x 2^e) rms %.2e max %.2e | fp16 x 2 unscaled rms %.2e max %.2e"
-          % (K, np.sqrt((e32 ** 2).mean()), e32.max(), np.sqrt((e3 ** 2).mean()), e3.max(), np.sqrt((e2 ** 2).mean()), e2.max(), np.sqrt((e2n ** 2).mean()), e2n.max()))
+    return {name: (float(np.sqrt((e ** 2).mean())), float(e.max())) for name, e in (("fp32_chain", e32), ("bf16x3", e3), ("fp16x2", e2), ("fp16x2_unscaled", e2n))}
+
+
+if __name__ == "__main__":
+    stream = np.random.default_rng(0)                 # one stream for the whole table
+    for K in (144, 288, 576, 1152, 8192):
+        r = errors(K, rng=stream)
+        print("K %5d | fp32 chain rms %.2e max %.2e | bf16 x 3 rms %.2e max %.2e | fp16 x 2 (weights x 2^e) rms %.2e max %.2e | fp16 x 2 unscaled rms %.2e max %.2e"
+              % ((K,) + r["fp32_chain"] + r["bf16x3"] + r["fp16x2"] + r["fp16x2_unscaled"]))
