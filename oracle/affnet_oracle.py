@@ -301,12 +301,18 @@ def eig2x2(A):
     return l1, l2
 
 
+def frame_corners(lafs):
+    """LAF.py:91-104 (LAFs_to_H_frames + the product checkTouchBoundary thresholds): the four corners (+-1, +-1) of every frame in the
+    LAFs' own (normalised) units, (n, 2, 4); dtype follows the input."""
+    pts = torch.tensor([[-1.0, -1, 1, 1], [-1, 1, -1, 1], [1, 1, 1, 1]], dtype=lafs.dtype).unsqueeze(0)
+    n = lafs.size(0)
+    Hm = torch.cat([lafs, torch.tensor([0.0, 0, 1], dtype=lafs.dtype).view(1, 1, 3).repeat(n, 1, 1)], dim=1)
+    return torch.bmm(Hm, pts.expand(n, 3, 4))[:, :2, :]
+
+
 def inside_image(lafs):
     """LAF.py:91-104 (LAFs_to_H_frames + checkTouchBoundary) on normalised LAFs."""
-    pts = torch.tensor([[-1.0, -1, 1, 1], [-1, 1, -1, 1], [1, 1, 1, 1]]).unsqueeze(0)
-    n = lafs.size(0)
-    Hm = torch.cat([lafs, torch.tensor([0.0, 0, 1]).view(1, 1, 3).repeat(n, 1, 1)], dim=1)
-    out = torch.bmm(Hm, pts.expand(n, 3, 4))[:, :2, :]
+    out = frame_corners(lafs)
     return ~(((out > 1.0).int() + (out < 0.0).int()).sum(dim=1).sum(dim=1) > 0)
 
 
@@ -491,6 +497,9 @@ class OracleExtractor(object):
         l1, l2 = eig2x2(base)
         ratio = torch.abs(l1 / (l2 + 1e-8))
         good = ((ratio < 6.0) & (ratio > (1.0 / 6.0))) & inside_image(new)
+        # what the hard decisions of :147-162 were taken on, per CANDIDATE (row order of self.detected) - read by the parity tests to trace every
+        # keypoint that only one side returns to the decision that differs (oracle/fp64_referee.py); no effect on the results
+        self.shape_stage = {"A": base.clone(), "frames": new.clone(), "ratio": ratio.clone(), "good": good.clone(), "n_out": n_out}
         if n_out > 0 and good.float().sum().item() > n_out:
             resp, sel = torch.topk(resp * good.float(), k=n_out)
         else:
@@ -527,7 +536,9 @@ class OracleExtractor(object):
             if do_ori:
                 lafs = self._orientation(lafs, octs, levs)
             self.keys = torch.stack([octs.long(), levs.long(), pixs.long()], dim=1)
-            return denormalize_lafs(lafs, x.size(3), x.size(2)), resp
+            out = denormalize_lafs(lafs, x.size(3), x.size(2))
+            self.last_lafs_px = out.numpy().copy()       # row order of self.keys (read by oracle/fp64_referee.py)
+            return out, resp
 
     __call__ = forward
 

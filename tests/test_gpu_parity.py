@@ -10,9 +10,12 @@ Bars (BASELINE.json: LAFs / descriptors within 1e-3 of the reference CPU path):
     (affine_grid's bmm, the 3-channel centroid conv), so against the oracle run live on this host a
     small tolerance applies where those operators are involved; blur and Hessian are exact on both;
   * CNN outputs: different summation order on MFMA -> 2e-5 abs on O(1) outputs;
-  * end to end: keypoints matched by integer key (octave, level, pixel); >= 99.5% must match, descriptors within 1e-3, and EVERY
-    matched LAF row inside the combined bar of _laf_bar(): 1e-3 px absolute, or - for large frames / short OriNet vectors, where 1e-3 px
-    is a few ulp - the error a 1e-5 relative + 4e-5 / |o| angular perturbation of the frame allows.
+  * end to end: keypoints matched by integer key (octave, level, pixel); >= 99.5% must match, descriptors within 1e-3, >= 99.5 % of the
+    matched LAF rows within 1e-3 px and none outside 5e-3 px.  The statement covers 100 % of the KEYS and ROWS (round 5, _referee()):
+    every key only one side returns is traced to a borderline decision of the reference's shape filter or to the top-N cut it shifted
+    (`unmatched_unexplained == 0`), and every row outside 1e-3 px is judged by a float64 evaluation of the post-detector stages:
+    |GPU - fp64| <= |CPU reference - fp64| + 1e-3 px (`rows_worse_than_cpu_vs_fp64 == 0`; oracle/fp64_referee.py).  The fitted bar of
+    round 4 (_laf_bar: max(1e-3 px, S (1e-5 + 4e-5 / |o|))) is still recorded, no longer the gate.
   * both arithmetic modes of the CNN contractions (include/affnet_hip.h AFFNET_ARITH_*: "fp32" = exact fp32 MFMA, "fp32_split3" = fp32 as
     three bf16 terms on the bf16 MFMA) run the full-path cases with the SAME bars.
 """
@@ -23,6 +26,7 @@ import pytest
 import torch
 
 import affnet_oracle as orc
+import fp64_referee as rf
 from _rowmatch import match_rows, tie_groups
 from conftest import load_gray, record_parity
 
@@ -59,6 +63,25 @@ def _oracle_describe(tag, x, n, weights):
     return _ORACLE_RUNS[key]
 
 
+_REFEREES = {}
+
+
+def _referee(ex, ids_g, L, hw, n_out, full=False):
+    """oracle/fp64_referee.parity_account for one image (the Referee and its float64 results are cached per oracle run: the arithmetic-mode
+    parametrisation asks about mostly the same rows)."""
+    if id(ex) not in _REFEREES:
+        _REFEREES[id(ex)] = (ex, rf.Referee(ex, hw[1], hw[0]))
+    return rf.parity_account(_REFEREES[id(ex)][1], ids_g, L, n_out, full=full)
+
+
+def _assert_accounted(rec):
+    """The two statements without a free parameter (module docstring)."""
+    acc = rec["accounting"]
+    assert acc["unmatched_unexplained"] == 0, "keys only one side returns and no borderline decision explains: %s" % [r for r in acc["unmatched_rows"] if r["why"] in ("UNEXPLAINED", "NOT A DETECTOR CANDIDATE")]
+    assert acc["rows_worse_than_cpu_vs_fp64"] == 0, "rows farther from the float64 referee than the CPU reference's own row + 1e-3 px: %s" % acc["rows_outside_1e-3_vs_fp64"]
+    assert rec["laf_max_px"] < 5e-3, "a matched LAF row differs by %.3g px" % rec["laf_max_px"]
+
+
 @pytest.fixture(scope="module")
 def amd():
     import affnet_amd
@@ -82,10 +105,12 @@ def _report(name, got, want):
     return d
 
 
-def _row_stats(name, ids_g, L, D, r, keys_w, Lw, Dw, rw, extra=None, ori_vec=None):
+def _row_stats(name, ids_g, L, D, r, keys_w, Lw, Dw, rw, extra=None, ori_vec=None, ex=None, hw=None, n_out=0, full_referee=False):
     """Key-matched comparison of one image's rows with the oracle's; records the numbers in the parity report.  ori_vec: the oracle's
     OriNet output vectors before atan2 (row order of Lw): for every LAF row outside 1e-3 px the report then carries the vector's
-    length - a short vector is what makes the angle (and with it the frame) sensitive to the CNN's summation order."""
+    length - a short vector is what makes the angle (and with it the frame) sensitive to the CNN's summation order.  ex (+ hw = image
+    (H, W), n_out = N): the OracleExtractor that produced the rows - the record then carries `accounting` = the float64 referee's verdict on
+    every row outside 1e-3 px and the trace of every key only one side returned (_referee); callers assert it with _assert_accounted."""
     gi, wi = _match(ids_g, keys_w)
     n = len(keys_w)
     dl = np.abs(L[gi] - Lw[wi]).reshape(len(gi), -1).max(axis=1)
@@ -115,8 +140,19 @@ def _row_stats(name, ids_g, L, D, r, keys_w, Lw, Dw, rw, extra=None, ori_vec=Non
         dd = np.abs(D[gi] - Dw[wi]).max(axis=1)
         rec.update({"desc_max": float(dd.max()), "desc_p99": float(np.percentile(dd, 99)), "desc_rows_within_1e-3": float((dd < 1e-3).mean())})
     rec.update(extra or {})
+    if os.environ.get("AFFNET_DUMP_ROWS"):          # the HIP path's rows, for analysis against the oracle on a host without a GPU
+        os.makedirs(os.environ["AFFNET_DUMP_ROWS"], exist_ok=True)
+        np.savez_compressed(os.path.join(os.environ["AFFNET_DUMP_ROWS"], "".join(c if c.isalnum() else "_" for c in name)[:120] + ".npz"),
+                            ids=np.asarray(ids_g), LAFs=L, resp=r, **({} if D is None else {"desc": D}))
+    if ex is not None:
+        rec["accounting"] = _referee(ex, np.asarray(ids_g), L, hw, n_out, full=full_referee)
     record_parity(name, **rec)
-    print(name, rec)
+    print(name, {k: v for k, v in rec.items() if k != "accounting"})
+    if ex is not None:
+        a = rec["accounting"]
+        print("  accounting: unmatched keys %d (borderline flips %d, unexplained %d); rows outside 1e-3 px %d, worse than the CPU row vs fp64 %d %s"
+              % (a["unmatched_keys"], a["unmatched_borderline_flips"], a["unmatched_unexplained"], a["rows_outside_1e-3"], a["rows_worse_than_cpu_vs_fp64"],
+                 a.get("referee_all_rows", "")))
     return gi, wi, dl, dd, rec
 
 
@@ -299,7 +335,7 @@ def _match(ids_got, keys_want):
     return np.array(gi, dtype=np.int64), np.array(wi, dtype=np.int64)
 
 
-def _check_full(amd, nets, x, n, weights, want=None, min_match=0.995, name=None, arith="fp32", tag=None):
+def _check_full(amd, nets, x, n, weights, want=None, min_match=0.995, name=None, arith="fp32", tag=None, full_referee=False):
     A, O, H = nets
     name = (name or "full path %dx%d n=%d" % (x.size(3), x.size(2), n)) + ("" if arith == "fp32" else " [arith %s]" % arith)
     ex, Lw, rw, Pw, Dw = _oracle_describe(tag or name, x, n, weights)
@@ -321,8 +357,9 @@ def _check_full(amd, nets, x, n, weights, want=None, min_match=0.995, name=None,
     inside = row_err < 1e-3 + 1e-6 * np.abs(Lw.numpy()).max()
     print("rows within 1e-3 px: %.4f ; worst row %.3g px" % (inside.mean(), row_err.max()))
     rec = _row_stats(name, res["ids"].cpu().numpy(), L, D, r, ex.keys.numpy(), Lw.numpy(), Dw.numpy(),
-                     rw.numpy(), ori_vec=None if ex.ori_vec is None else ex.ori_vec.numpy())[4]
-    assert rec["rows_outside_combined_bar"] == 0, "LAF rows outside the combined bar: %s" % rec["rows_outside_1e-3"]
+                     rw.numpy(), ori_vec=None if ex.ori_vec is None else ex.ori_vec.numpy(), ex=ex, hw=(x.size(2), x.size(3)), n_out=n,
+                     full_referee=full_referee)[4]
+    _assert_accounted(rec)
     assert inside.mean() >= 0.995 and row_err.max() < 5e-3, "LAF error above tolerance"
     assert dd[inside].max() < 1e-3 and np.percentile(dd, 99.5) < 1e-3, "descriptor error above 1e-3"
     assert np.array_equal(r[gi], rw.numpy()[wi]), "responses of matched keypoints must be bit-identical"
@@ -359,7 +396,7 @@ def test_full_path_graf_img1_golden_n500(amd, nets, weights, golden_dir, arith):
 def test_full_path_graf_img1_n2000_config2(amd, nets, weights, golden_dir, arith):
     """BASELINE.json configs[1]: test-graf/img1.png, 2000 kp, full path."""
     _check_full(amd, nets, load_gray(os.path.join(golden_dir, "graf_img1.png")), 2000, weights, name="configs[1]: graf img1 800x640, 2000 kp",
-                arith=arith, tag="graf1")
+                arith=arith, tag="graf1", full_referee=True)
 
 
 def test_threshold_mode_hesaffnet_as_shipped(amd, nets, weights, golden_dir):
@@ -819,11 +856,12 @@ def test_metric_configuration_batched_b32_vs_oracle(amd, nets, weights, golden_d
         ex, Lw, rw, Pw, Dw = _oracle_describe("synth768x1024 seed %d" % seeds[i], orc.synthetic_image(768, 1024, seeds[i]), 2000, weights)
         gi, wi, dl, dd, rec = _row_stats("configs[2] metric configuration: image %d of a 32-image batch, 1024x768, 2000 kp%s" % (i, sfx),
                                          got["ids"].cpu().numpy(), got["LAFs"].cpu().numpy(), got["descriptors"].cpu().numpy(),
-                                         got["responses"].cpu().numpy(), ex.keys.numpy(), Lw.numpy(), Dw.numpy(), rw.numpy(), ori_vec=ex.ori_vec.numpy())
+                                         got["responses"].cpu().numpy(), ex.keys.numpy(), Lw.numpy(), Dw.numpy(), rw.numpy(), ori_vec=ex.ori_vec.numpy(),
+                                         ex=ex, hw=(768, 1024), n_out=2000, full_referee=(i == 0))
         assert rec["match_rate"] >= 0.995, rec
         assert rec["responses_equal"], "responses of matched keypoints must be bit-identical"
-        assert rec["laf_rows_within_1e-3"] >= 0.995 and rec["laf_max_px"] < 1e-2, rec
-        assert rec["rows_outside_combined_bar"] == 0, "LAF rows outside the combined bar: %s" % rec["rows_outside_1e-3"]
+        assert rec["laf_rows_within_1e-3"] >= 0.995, rec
+        _assert_accounted(rec)
         assert rec["desc_rows_within_1e-3"] >= 0.995, rec
         assert dd[dl < 1e-3].max() < 1e-3, "descriptor of a geometrically matching row off by more than 1e-3"
     # image 31 against the UNMODIFIED reference's own output on the authoring host (tests/golden/make_golden_config3.py); rows
@@ -1082,9 +1120,9 @@ def test_config5_4k_deep_pyramid(amd, nets, weights, arith):
     ex, Lw, rw, Pw, Dw = _oracle_describe("synth 4K seed 0", x, 8000, weights)
     gi, wi, dl, dd, rec = _row_stats("configs[4]: 3840x2160 seed 0, 8000 kp" + ("" if arith == "fp32" else " [arith %s]" % arith), res["ids"].cpu().numpy(),
                                      res["LAFs"].cpu().numpy(), res["descriptors"].cpu().numpy(), res["responses"].cpu().numpy(), ex.keys.numpy(), Lw.numpy(),
-                                     Dw.numpy(), rw.numpy(), ori_vec=ex.ori_vec.numpy())
+                                     Dw.numpy(), rw.numpy(), ori_vec=ex.ori_vec.numpy(), ex=ex, hw=(2160, 3840), n_out=8000)
     assert rec["match_rate"] >= 0.995 and (dl < 1e-3 + 1e-6 * 3840).mean() >= 0.995, rec
-    assert rec["rows_outside_combined_bar"] == 0, "LAF rows outside the combined bar: %s" % rec["rows_outside_1e-3"]
+    _assert_accounted(rec)
     assert rec["responses_equal"]
     assert rec["desc_rows_within_1e-3"] >= 0.995 and dd[dl < 1e-3].max() < 1e-3, rec
     # batched: 8 images per launch (seed 0 first and last so that one oracle run covers both positions)
