@@ -61,6 +61,7 @@ class Nets(C.Structure):
 # name -> (restype, argtypes); every symbol declared in include/affnet_hip.h
 _P, _I, _SZ = C.c_void_p, C.c_int, C.c_size_t
 SYMBOLS = {
+    "affnet_config_fill": (_I, [C.POINTER(Config), _I, _I, _I, C.c_double, _I, C.c_double, C.c_double, _I, _I, _I, _I]),
     "affnet_ctx_create": (_I, [C.POINTER(_P), _I, C.POINTER(Config)]),
     "affnet_ctx_destroy": (None, [_P]),
     "affnet_last_error": (C.c_char_p, [_P]),

@@ -22,7 +22,8 @@
 //
 // Arithmetic is the reference's fp32 sequence exactly (compiled with -ffp-contract=off):
 // gxx = (l - 2c) + r, gxy from replicate-padded gx, |gxx*gyy - gxy*gxy| * float32(sigma^4),
-// keep iff (c - max27) + 1e-5f > 0, centroid sums as fmaf chains in (level, ky, kx) order.
+// keep iff (c - max27) + 1e-5f > 0, centroid sums as fmaf chains in the order of the reference's CPU conv2d for that map size
+// ((level, ky, kx) up to 6826 px, (ky, kx, level) above: see the centroid pass).
 #include <math.h>
 #include <stdlib.h>
 
@@ -297,26 +298,42 @@ __global__ __launch_bounds__(256, (NL <= 5 ? 3 : 1)) void hessian_nms_kernel(Hes
             const unsigned lower = code >> 16;
             const int py = y0 + qy, px = x0 + qx;
             const float c = Rr[l][(qy + 1) * HR_S + qx + 1];
-            // 27-tap centroid on the UNMASKED responses, zero padding (HandCraftedModules.py:279)
+            // 27-tap centroid on the UNMASKED responses, zero padding (HandCraftedModules.py:279): two conv2d calls of a (1, 3, h, w) tensor with
+            // 3 x 3 x 3 weights on the reference's CPU.  Their fp32 summation order depends on the map size - ATen's use_mkldnn() sends a
+            // batch-1 3 x 3 convolution to oneDNN only when the input has more than 20480 elements (Convolution.cpp: "for some case, native is
+            // faster"): the native path (im2col + sgemm, K = 27) accumulates in (level, ky, kx) order, oneDNN's direct convolution for 3 input
+            // channels in (ky, kx, level) order, both as fmaf chains (verified bit for bit on 300 x 500 / 40 x 50 maps, tools/probes/cpu_conv_order.py).
+            // A one-ulp difference of a sub-pixel centre moves the sampled patch enough to shift a sensitive frame by 1e-3 px (round 5: the
+            // float64 referee traced every LAF row outside 1e-3 px to this), so both orders are reproduced.
             float ns = 0.f, ny = 0.f, nx = 0.f, den = 0.f;
-#pragma unroll
-            for (int dl = 0; dl < 3; ++dl) {
-                const float sg = s_sigma[l - 1 + dl];
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky) {
-                    const float oy = (ky == 0) ? -0.5f : (ky == 1 ? 0.5f : 1.5f);
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const float ox = (kx == 0) ? -0.5f : (kx == 1 ? 0.5f : 1.5f);
-                        float r = Rr[l - 1 + dl][(qy + ky) * HR_S + qx + kx];
-                        if (r == -INFINITY) r = 0.0f;  // conv2d zero padding
-                        ns = fmaf(r, sg, ns);
-                        ny = fmaf(r, oy, ny);
-                        nx = fmaf(r, ox, nx);
-                        den = fmaf(r, 1.0f, den);
-                    }
-                }
+#define AFF_CENTROID_TAP(dl, ky, kx)                                                        \
+            {                                                                               \
+                const float sg = s_sigma[l - 1 + (dl)];                                     \
+                const float oy = ((ky) == 0) ? -0.5f : ((ky) == 1 ? 0.5f : 1.5f);           \
+                const float ox = ((kx) == 0) ? -0.5f : ((kx) == 1 ? 0.5f : 1.5f);           \
+                float r = Rr[l - 1 + (dl)][(qy + (ky)) * HR_S + qx + (kx)];                 \
+                if (r == -INFINITY) r = 0.0f; /* conv2d zero padding */                     \
+                ns = fmaf(r, sg, ns);                                                       \
+                ny = fmaf(r, oy, ny);                                                       \
+                nx = fmaf(r, ox, nx);                                                       \
+                den = fmaf(r, 1.0f, den);                                                   \
             }
+            if (3 * h * w > 20480) {                   // oneDNN: (ky, kx, level)
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                        for (int dl = 0; dl < 3; ++dl) AFF_CENTROID_TAP(dl, ky, kx)
+            } else {                                   // native im2col + sgemm: (level, ky, kx)
+#pragma unroll
+                for (int dl = 0; dl < 3; ++dl)
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                        for (int kx = 0; kx < 3; ++kx) AFF_CENTROID_TAP(dl, ky, kx)
+            }
+#undef AFF_CENTROID_TAP
             const float dd = den + 1e-8f;
             float cs = ns / dd, cy = ny / dd, cx = nx / dd;
             cy = cy + (float)py;

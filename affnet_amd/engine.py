@@ -26,7 +26,10 @@ def utility_ctx(device, arith=0):
         check(lib.affnet_ctx_create(C.byref(h), idx, None), None, "affnet_ctx_create(utility)")
         check(lib.affnet_set_arith(h, key[1]), h, "affnet_set_arith")
         _UTILITY[key] = h
-    return _UTILITY[key]
+    h = _UTILITY[key]
+    if lib.affnet_get_arith(h) != key[1]:       # a tool switched the shared handle in place (affnet_set_arith) and did not switch back
+        check(lib.affnet_set_arith(h, key[1]), h, "affnet_set_arith")
+    return h
 
 
 def stream_of(device):
@@ -133,6 +136,23 @@ def pack_state_dict(kind, sd):
     check(rc, None, "affnet_cnn32_pack_weights")
     del keep
     return out
+
+
+def save_flat_weights(kind, sd, path):
+    """state dict (reference key layout) -> the flat AFNW0001 file a non-Python caller of the C ABI feeds to affnet_cnn32_pack_weights
+    (examples/c_host/extract.c): magic, int32 kind, int32 float count, then float32 conv weights features.{0,3,6,9,12,15}, BN running means
+    features.{1,4,7,10,13,16}, BN running variances, head features.19.weight, features.19.bias (AffNet / OriNet) or features.20.running_mean /
+    running_var (HardNet)."""
+    conv_idx, bn_idx = (0, 3, 6, 9, 12, 15), (1, 4, 7, 10, 13, 16)
+    names = ["features.%d.weight" % i for i in conv_idx] + ["features.%d.running_mean" % i for i in bn_idx] + \
+            ["features.%d.running_var" % i for i in bn_idx] + ["features.19.weight"]
+    names += ["features.20.running_mean", "features.20.running_var"] if kind == _lib.NET_HARDNET else ["features.19.bias"]
+    flat = np.concatenate([sd[n].detach().to("cpu", torch.float32).contiguous().numpy().reshape(-1) for n in names])
+    with open(path, "wb") as f:
+        f.write(b"AFNW0001")
+        f.write(np.array([kind, flat.size], dtype=np.int32).tobytes())
+        f.write(flat.astype(np.float32).tobytes())
+    return flat.size
 
 
 def cnn_forward(kind, packed, patches, scratch=None, arith=0):

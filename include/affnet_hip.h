@@ -135,6 +135,22 @@ typedef struct affnet_config {
                                             * MFMA, the default); may be changed later with affnet_set_arith                        */
 } affnet_config;
 
+/* Fills *cfg for an height x width image with the reference's own formulas, so that a caller that is not Python can create a context
+ * without re-deriving them: the pyramid stop rule (minSize = 2 border + 3), octave sizes, level sigmas, the incremental blur sigmas and
+ * their k x k Gaussian tap tables (k = int(6 sigma + 1) | 1, taps at linspace(-k/2, k/2, k): Python-3 true division), sigma^4 and
+ * sigma x pixel distance.  Replaces ScalePyramid.__init__ / forward's bookkeeping (HandCraftedModules.py:14-56) and
+ * CircularGaussKernel / GaussianBlur.calculate_weights (Utils.py:92-114,155-161).  All intermediates are doubles evaluated like the
+ * numpy expressions of the reference (affnet_amd/host_plan.py is the Python mirror's restatement; a CPU test compares the two structs
+ * byte for byte).  Arguments = the ScaleSpaceAffinePatchExtractor ctor kwargs (SparseImgRepresenter.py:15-24): n_levels (nlevels, 3),
+ * init_sigma (1.6), border, mr_size (mrSize), threshold (th; 0 when None), num_features (N; <= 0 with a threshold),
+ * num_prefilter (C = int(1.5 N) when baum_iters > 0, else N), batch (images per call), baum_iters (num_Baum_iters).
+ * The remaining fields get their defaults (max_raw_per_octave_div 4, max_keep 16384, lazy_shape_rows -1, onepass 0,
+ * arith AFFNET_ARITH_FP32_MFMA) and may be changed before affnet_ctx_create.
+ * Returns AFFNET_ERR_INVALID for n_levels outside 1..AFFNET_MAX_LEVELS-2, more than AFFNET_MAX_OCTAVES octaves or a Gaussian of more than
+ * AFFNET_MAX_TAPS taps (there is no context yet to hold a message). */
+int affnet_config_fill(affnet_config* cfg, int height, int width, int n_levels, double init_sigma, int border, double mr_size,
+                       double threshold, int num_features, int num_prefilter, int batch, int baum_iters);
+
 /* ---- context ------------------------------------------------------------------------------- */
 
 /* Creates a context bound to HIP device `device` (one context per (device, stream) user).

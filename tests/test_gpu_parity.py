@@ -1099,6 +1099,18 @@ def test_cli_entry_points(amd, golden_dir, tmp_path):
     assert lines[0].strip() == "1.0" and int(lines[1]) == 500
     ell = np.loadtxt(out, skiprows=2)
     assert ell.shape == (500, 5) and (ell[:, 2] * ell[:, 4] - ell[:, 3] ** 2 > 0).all()   # positive definite ellipses
+    # VALUES: the file's rows against the unmodified reference's own output for this image and budget (tests/golden/graf_img1_n500.npz;
+    # those frames carry OriNet's rotation, the CLI's do not - the Oxford ellipse (A A^T)^-1 does not depend on it), rows matched by centre
+    gold = np.load(os.path.join(golden_dir, "graf_img1_n500.npz"))
+    want = orc.lafs_to_ellipses(gold["LAFs"])
+    pos = {(round(float(e[0]), 2), round(float(e[1]), 2)): i for i, e in enumerate(want)}
+    pairs = [(i, pos[(round(float(e[0]), 2), round(float(e[1]), 2))]) for i, e in enumerate(ell) if (round(float(e[0]), 2), round(float(e[1]), 2)) in pos]
+    a, b = np.array([q[0] for q in pairs]), np.array([q[1] for q in pairs])
+    rel = np.abs(ell[a] - want[b]) / np.maximum(np.abs(want[b]), 1e-6)
+    record_parity("hesaffnet.py CLI output vs the reference's golden rows (graf img1, 500 kp)", rows=500, matched_by_centre=len(pairs),
+                  centre_max_px=float(np.abs(ell[a, :2] - want[b, :2]).max()), ellipse_max_rel=float(rel[:, 2:].max()))
+    assert len(pairs) >= 0.995 * 500, "only %d of 500 golden rows found in the CLI output" % len(pairs)
+    assert np.abs(ell[a, :2] - want[b, :2]).max() < 1e-3 and rel[:, 2:].max() < 1e-3, "ellipse values of the CLI output differ from the reference's"
     g = np.load(os.path.join(golden_dir, "just_shape_column.npz"))
     col = tmp_path / "column.png"
     Image.fromarray(g["column"]).save(col)
@@ -1106,6 +1118,47 @@ def test_cli_entry_points(amd, golden_dir, tmp_path):
     subprocess.check_call([sys.executable, os.path.join(root, "examples/just_shape/detect_affine_shape.py"), str(col), str(out2)])
     got = np.loadtxt(out2)
     assert got.shape == (64, 4) and np.abs(got - g["affine"]).max() < 1e-4
+
+
+@pytest.mark.parametrize("arith", ARITH)
+def test_c_host_program_drives_the_boundary_without_python(amd, nets, weights, golden_dir, tmp_path, arith):
+    """examples/c_host/extract.c: a plain C99 program (gcc; hipMalloc, affnet_config_fill, flat weight files -> affnet_cnn32_pack_weights,
+    affnet_extract_features, affnet_lafs_to_ellipses, affnet_read_counts, Oxford text) - no Python, no torch in that process.  Its LAFs,
+    responses, ids and descriptors on graf img1 must be BYTE-equal to the Python mirror's, its text file equal to the mirror's device ellipses."""
+    import subprocess
+    from affnet_amd import _lib, engine
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "c_host", "extract")
+    assert os.path.isfile(exe), "examples/c_host/extract is missing: __graft_entry__.build() compiles it"
+    ldd = subprocess.run(["ldd", exe], capture_output=True, text=True).stdout
+    assert "libaffnet_hip.so" in ldd and "python" not in ldd.lower() and "torch" not in ldd.lower(), ldd
+    x = load_gray(os.path.join(golden_dir, "graf_img1.png"))
+    x[0, 0].numpy().tofile(str(tmp_path / "img.f32"))
+    for kind, name in ((_lib.NET_AFFNET, "AffNet"), (_lib.NET_ORINET, "OriNet"), (_lib.NET_HARDNET, "HardNet")):
+        engine.save_flat_weights(kind, weights[name], str(tmp_path / (name + ".afnw")))
+    prefix = str(tmp_path / "out")
+    code = _lib.arith_code(arith)
+    run = subprocess.run([exe, str(tmp_path / "img.f32"), str(x.size(2)), str(x.size(3)), "2000", str(tmp_path / "AffNet.afnw"),
+                          str(tmp_path / "OriNet.afnw"), str(tmp_path / "HardNet.afnw"), prefix, str(code)], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stderr
+    print(run.stdout.strip())
+    A, O, H = nets
+    det = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=2000, border=5, num_Baum_iters=1, AffNet=A, OriNet=O, arith=arith).to(DEV)
+    res = det.run(x.to(DEV), do_ori=True, desc=H)
+    n = res["LAFs"].shape[0]
+    got = {"LAFs": np.fromfile(prefix + ".lafs.f32", dtype=np.float32).reshape(-1, 2, 3), "responses": np.fromfile(prefix + ".resp.f32", dtype=np.float32),
+           "ids": np.fromfile(prefix + ".ids.i32", dtype=np.int32).reshape(-1, 3), "descriptors": np.fromfile(prefix + ".desc.f32", dtype=np.float32).reshape(-1, 128)}
+    for k, v in got.items():
+        assert v.shape[0] == n and np.array_equal(v, res[k].cpu().numpy()), "the C host program's %s differ from the Python mirror's" % k
+    lines = open(prefix + ".txt").read().split("\n")
+    assert lines[0] == "1.0" and int(lines[1]) == n
+    ell = np.loadtxt(prefix + ".txt", skiprows=2)
+    want = amd.LAF.LAFs2ellT(res["LAFs"]).cpu().numpy().astype(np.float64)
+    assert ell.shape == (n, 5) and np.abs(ell - want).max() <= 1e-9 * max(1.0, np.abs(want).max()) + 5.1e-11     # '%10.10f' rounding
+    record_parity("C host program (examples/c_host/extract.c) vs the Python mirror, graf img1 2000 kp" + ("" if arith == "fp32" else " [arith %s]" % arith),
+                  rows=int(n), byte_equal=True)
+    # wrong argv -> usage + exit code 1 (hesaffnet.py:21-23)
+    assert subprocess.run([exe], capture_output=True).returncode == 1
 
 
 @pytest.mark.parametrize("arith", ARITH)

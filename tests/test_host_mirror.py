@@ -58,6 +58,35 @@ def test_pyramid_plan_and_taps_match_oracle(hw):
     assert np.float32(cfg.level_sigma4[0][2]) == np.float32(plan.sigmas[0][2] ** 4)
 
 
+def test_c_side_config_fill_equals_the_python_plan_byte_for_byte():
+    """affnet_config_fill (csrc/config_fill.hip) = the C-side way to fill affnet_config (HandCraftedModules.py:14-56, Utils.py:92-114,155-161
+    restated with doubles, numpy's linspace and pairwise np.sum): the struct must be byte-identical to the one the Python mirror builds from
+    the reference's numpy formulas (affnet_amd/host_plan.py) - octave sizes, sigmas, sigma^4, every float32 tap of every Gaussian."""
+    from affnet_amd import _lib
+    from affnet_amd.host_plan import PyramidPlan
+    rng = np.random.RandomState(7)
+    cases = [(h, w, nl, s, b) for (h, w) in [(768, 1024), (640, 800), (2160, 3840), (240, 320), (481, 641), (598, 1000), (33, 47), (1000, 563)]
+             for nl in (1, 2, 3, 4, 5, 6) for s in (1.6, 0.4, 0.5, 1.0, 2.2) for b in (5, 15, 0)]
+    cases += [(768, 1024, 3, float(s), 5) for s in rng.uniform(0.3, 3.0, size=60)]
+    refused = 0
+    for h, w, nl, s, b in cases:
+        try:
+            want = PyramidPlan(h, w, nl, s, b).fill_config(5.192, 0.25, 2000, 3000, batch=2, baum_iters=1)
+        except ValueError:
+            want = None                                  # Gaussian wider than AFFNET_MAX_TAPS / pyramid too deep
+        got = _lib.Config()
+        rc = _lib.lib.affnet_config_fill(C.byref(got), h, w, nl, s, b, 5.192, 0.25, 2000, 3000, 2, 1)
+        if want is None:
+            assert rc == _lib.ERR_INVALID, (h, w, nl, s, b)
+            refused += 1
+            continue
+        assert rc == _lib.OK, (h, w, nl, s, b)
+        assert bytes(got) == bytes(want), "affnet_config_fill differs from host_plan for %s" % ((h, w, nl, s, b),)
+    assert refused > 0, "the sweep must include configurations both sides refuse"
+    assert _lib.lib.affnet_config_fill(C.byref(_lib.Config()), 100, 100, 7, 1.6, 5, 3.0, 0.0, 10, 10, 1, 0) == _lib.ERR_INVALID       # n_levels + 2 > AFFNET_MAX_LEVELS
+    assert _lib.lib.affnet_config_fill(None, 100, 100, 3, 1.6, 5, 3.0, 0.0, 10, 10, 1, 0) == _lib.ERR_INVALID
+
+
 def test_context_layout_no_gpu_needed():
     from affnet_amd import _lib
     from affnet_amd.host_plan import PyramidPlan
