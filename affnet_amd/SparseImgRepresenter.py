@@ -199,6 +199,8 @@ class ScaleSpaceAffinePatchExtractor(nn.Module):
     def run(self, x, do_ori=False, desc=None):
         """Fused path.  Returns dict(LAFs px (N,2,3), responses (N,), ids (N,3), descriptors (N,128)|None).
         `desc`: affnet_amd.HardNet.HardNet or None."""
+        if x.dim() == 4 and x.size(0) != 1:
+            raise ValueError("run() is for a single (1,1,H,W) image; use run_batch() for (B,1,H,W) batches")
         r = self.enqueue(x, do_ori=do_ori, desc=desc)
         ctx = self._ctx
         self._publish_pyramid(ctx)

@@ -1231,6 +1231,8 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
     if (!patches && !ctx->ws) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: sampling from the pyramid needs a bound workspace");
     if (dbg_layer < 0 && !scratch)
         return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: d_scratch is required (HardNet n*(8192+512) floats, AffNet / OriNet n*144 floats)");
+    if (dbg_layer >= 0 && ctx->arith != AFFNET_ARITH_FP32_MFMA)       // the split trunks have no per-layer dump: the exact kernel would answer
+        return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: layer dumps exist for AFFNET_ARITH_FP32_MFMA only (context is in arithmetic mode %d)", ctx->arith);
     if (n_max == 0) return AFFNET_OK;
     if (kind == AFFNET_NET_HARDNET && n_max > 65535) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: n_max=%d (HardNet head: max 65535 rows per image)", n_max);
     const NetLayout L = net_layout(kind);

@@ -379,7 +379,7 @@ __device__ __forceinline__ void split_remainder(f32x2& v, unsigned u) {
 
 // ---- AFFNET_ARITH_FP32_SPLIT2H: fp32 = two fp16 terms, three products ------------------------------------------------------------------
 // x ~ h + l, h = fp16(x), l = fp16(x - h) (both round-to-nearest-even; x - h is exact in fp32): 11 + 11 bits + the remainder's sign = 23 of
-// fp32's 24 significand bits, |x - h - l| <= 2^-23 |x| (rms ~2^-25).  w a = w_h a_h + w_l a_h + w_h a_l (+ w_l a_l <= 2^-24, dropped) on v_mfma_f32_16x16x32_f16: every fp16 x fp16 product is exact
+// fp32's 24 significand bits, |x - h - l| <= 2^-23 |x| for |x| >= 2^-2 and <= 2^-25 ABSOLUTE below (activations are not scaled: the low term is then a subnormal fp16).  w a = w_h a_h + w_l a_h + w_h a_l (+ w_l a_l <= 2^-24, dropped) on v_mfma_f32_16x16x32_f16: every fp16 x fp16 product is exact
 // in the fp32 accumulator and subnormal fp16 inputs are honoured (tools/probes/f16_split_probe.hip), so small activations keep an ABSOLUTE
 // error of 2^-25.  Half the matrix instructions of the three-term bf16 scheme; the loops and epilogues are the same code with TERMS = 2, on
 // a layout of their own (LayR below: 16-byte pixels, two thirds of LayQ's bytes, conflict free for every reader).

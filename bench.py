@@ -14,7 +14,7 @@ OriNet -> level select -> HardNet) over one batch of 64 synthetic 1024x768 image
 each (BASELINE.json configs[2], the configuration the metric is quoted on), per rank (weak scaling),
 images resident in HBM before the timed region, processed as 2 fused library calls of 32 images (every
 kernel launch covers 32 images), followed for N > 1 by the gather of the padded
-(count, LAFs, responses, descriptors) records (all_gather, or --gather rank0).  value = keypoints returned by
+(count, LAFs, responses, descriptors) records (gather to rank 0, or --gather all = all_gather).  value = keypoints returned by
 all ranks / max-over-ranks time.
 
 roofline           : dominant kernel = fused HardNet trunk (cnn32_trunk_kernel<2>, fp32 MFMA).  achieved = algorithmic FLOPs
@@ -261,7 +261,7 @@ def parity_check(kept, fetch):
     key = lambda a: a[:, 0].astype(np.int64) * (1 << 40) + a[:, 1].astype(np.int64) * (1 << 32) + a[:, 2].astype(np.int64)
     tot = {"images": 0, "seeds": [], "keypoints": 0, "matched": 0, "laf_max_px": 0.0, "laf_rows_within_1e-3": 0, "desc_max": 0.0,
            "desc_rows_within_1e-3": 0, "responses_equal": True, "same_row_order": True, "unmatched_keys": 0, "unmatched_borderline_flips": 0,
-           "unmatched_unexplained": 0, "unmatched_rows": [], "rows_worse_than_cpu_vs_fp64": 0, "rows_outside_1e-3": [],
+           "unmatched_unexplained": 0, "unmatched_rows": [], "rows_worse_than_cpu_vs_fp64": 0, "rows_outside_1e-3_unexplained": 0, "rows_outside_1e-3": [],
            "rows_outside_combined_bar_round4": 0}
     for seed, want in kept:
         got = fetch(seed)
@@ -279,6 +279,7 @@ def parity_check(kept, fetch):
         tot["unmatched_unexplained"] += acc["unmatched_unexplained"]
         tot["unmatched_rows"] += [dict(r, seed=seed) for r in acc["unmatched_rows"]]
         tot["rows_worse_than_cpu_vs_fp64"] += acc["rows_worse_than_cpu_vs_fp64"]
+        tot["rows_outside_1e-3_unexplained"] += acc["rows_outside_1e-3_unexplained"]
         # secondary record: round 4's fitted bar max(1e-3 px, S (1e-5 + 4e-5 / |o|)) - no longer part of `pass`
         Lw = want["LAFs"][wi].astype(np.float64)
         S = np.sqrt(np.abs(Lw[:, 0, 0] * Lw[:, 1, 1] - Lw[:, 0, 1] * Lw[:, 1, 0]))
@@ -303,11 +304,11 @@ def parity_check(kept, fetch):
         tot["same_row_order"] &= bool(len(gi) == len(kw) and np.array_equal(gi, wi))
     tot["match_rate"] = tot["matched"] / max(tot["keypoints"], 1)
     tot["pass"] = bool(tot["match_rate"] >= 0.995 and tot["laf_rows_within_1e-3"] >= 0.995 * tot["matched"] and tot["laf_max_px"] < 5e-3 and
-                       tot["unmatched_unexplained"] == 0 and tot["rows_worse_than_cpu_vs_fp64"] == 0 and
+                       tot["unmatched_unexplained"] == 0 and tot["rows_outside_1e-3_unexplained"] == 0 and
                        tot["desc_rows_within_1e-3"] >= 0.995 * tot["matched"] and tot["responses_equal"])
     tot["bar"] = ("keys: every key only one side returns traced to a borderline shape-filter decision or the shifted top-N cut (unmatched_unexplained = 0); "
                   "LAF rows: >= 99.5 % within 1e-3 px, none outside 5e-3 px, every row outside 1e-3 px no farther from the float64 referee than the CPU "
-                  "reference's row + 1e-3 px (rows_worse_than_cpu_vs_fp64 = 0); descriptors >= 99.5 % within 1e-3; responses bit-equal")
+                  "reference's row + 1e-3 px, or the CPU reference's own row >= 1e-3 px from fp64 (rows_outside_1e-3_unexplained = 0); descriptors >= 99.5 % within 1e-3; responses bit-equal")
     tot["reference"] = "oracle/affnet_oracle.py (bit-identical to the unmodified reference, oracle/check_restatement.py) on this host; referee oracle/fp64_referee.py"
     return tot
 
@@ -374,8 +375,9 @@ def main():
     ap.add_argument("--pipeline", type=int, default=int(os.environ.get("AFFNET_BENCH_PIPELINE", "0")),
                     help="1 (with --streams 1): pyramid + detector of chunk i+1 run on a second stream next to the CNN stages of "
                          "chunk i (two contexts alternate); the CNN kernels stay serialised on one stream")
-    ap.add_argument("--gather", choices=("all", "rank0"), default="all",
-                    help="N > 1 exchange of the padded records: all_gather (default) or gather to rank 0 (7/8 less xGMI traffic)")
+    ap.add_argument("--gather", choices=("all", "rank0"), default="rank0",
+                    help="N > 1 exchange of the padded records: gather to rank 0 (default; what north_star names: 69 MB out of every other rank, "
+                         "484 MB into rank 0 per 64-image step at N = 8) or all_gather (every rank receives the 484 MB: 8x the xGMI traffic)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the stand-alone sampler timing behind secondary_rooflines")
     ap.add_argument("--include-h2d", action="store_true",
@@ -785,6 +787,22 @@ def run(args, world):
                     "gather_ms": times[len(times) // 2], "gather_ms_min": times[0],
                     "how": "median of 5 stand-alone exchanges of one step's records after the timed region (HIP events around issue + wait, "
                            "barrier first); inside the timed region the exchange of step k runs under the kernels of step k+1"}
+        if SELF and world == 1:
+            # the record volume of ONE step at N = 8 (8 x 64 records = 553 MB at 2000 kp) through the same call in the 1-rank RCCL group: the
+            # software floor (pack, enqueue, local copy) the first real 8-GPU line's gather_ms can be read against - no xGMI link is crossed here
+            rec8 = rec_local.repeat(8, 1)
+            t8 = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                sharded.gather_features_async(rec8, args.batch * 8, force=True, dst=gather_dst)()
+                e1.record()
+                torch.cuda.synchronize()
+                t8.append(e0.elapsed_time(e1))
+            t8.sort()
+            exchange["n8_volume_1rank"] = {"records": int(rec8.size(0)), "bytes": int(rec8.numel()) * 4, "gather_ms": t8[len(t8) // 2], "gather_ms_min": t8[0],
+                                           "note": "one rank, no link crossed: software floor of the exchange at the N = 8 record volume"}
+            del rec8
     mode = args.verify_gather or ("sample" if world > 1 else ("sample" if SELF else "off"))
     gather_check = None
     if DIST and mode != "off":

@@ -71,7 +71,8 @@ extern "C" {
  *                 differ from FP32_MFMA by summation order only (descriptors ~1e-6); the parity bars are the same for both modes.
  *   FP32_SPLIT2H: every fp32 operand x is carried as x ~ h + l with h = fp16(x), l = fp16(x - h) (round to nearest even both; x - h is
  *                 exact): 11 + 11 significand bits + the sign of the remainder = 23 of fp32's 24 bits, |x - h - l| <= 2^-23 |x| (rms
- *                 ~2^-25).  A product w * a is the THREE fp16 products w_h a_h + w_l a_h + w_h a_l on v_mfma_f32_16x16x32_f16 (each exact
+ *                 ~2^-24.4) for |x| >= 2^-2; the operands are NOT scaled per element, so below 2^-2 the low term fp16(x - h) is a subnormal
+ *                 fp16 and the bound becomes ABSOLUTE: |x - h - l| <= 2^-25 whatever |x| (2^-22 |x| at 2^-3, 2^-17 |x| at 2^-8).  A product w * a is the THREE fp16 products w_h a_h + w_l a_h + w_h a_l on v_mfma_f32_16x16x32_f16 (each exact
  *                 in the fp32 accumulator; the dropped w_l a_l is <= 2^-24 relative), accumulated in fp32 - half the matrix instructions
  *                 of FP32_SPLIT3.  NOT bit-faithful fp32 operands like FP32_SPLIT3, but the same error class as an fp32 summation: a
  *                 K-term dot product against fp64 on the same data: 2.0e-8 rms of sum|w||a| vs 3.6e-8 for the fmaf chain of FP32_MFMA
@@ -79,8 +80,11 @@ extern "C" {
  *                 exponent, so the weights of a layer are packed times a power of two 2^e that puts the layer's largest |w| into
  *                 [2^13, 2^14) and the layer's sums are multiplied by 2^-e (both exact); activations are used as they are: |a| < 65504
  *                 is REQUIRED (the reference's nets are BatchNorm-ed, |a| stays below ~50; a larger value becomes inf and the output
- *                 non-finite - HardNet descriptors NaN, AffNet / OriNet outputs NaN or saturated - it does not pass as a plausible number) and an activation below 2^-14 keeps an ABSOLUTE error of 2^-25 instead of a relative
- *                 one (subnormal fp16 operands are honoured by the MFMA, tools/probes/f16_split_probe.hip).  Same interfaces (fp32
+ *                 non-finite - HardNet descriptors NaN, AffNet / OriNet outputs NaN or saturated - it does not pass as a plausible number) and an activation below 2^-2 keeps an
+ *                 ABSOLUTE error of 2^-25 instead of a relative one, as stated above (subnormal fp16 operands are honoured by the MFMA,
+ *                 tools/probes/f16_split_probe.hip).  Against the O(1) sums of the BatchNorm-ed layers of the shipped nets an absolute 2^-25
+ *                 per activation is fp32-level; a net whose activations are UNIFORMLY small (all |a| << 2^-2) loses relative precision in
+ *                 this mode - use AFFNET_ARITH_FP32_SPLIT3 (exact operands) or the default there.  Same interfaces (fp32
  *                 everywhere), same parity bars. */
 #define AFFNET_ARITH_FP32_MFMA 0
 #define AFFNET_ARITH_FP32_SPLIT3 1

@@ -18,7 +18,8 @@ extern "C" {
 
 /* Parity aid: runs the trunk of `net_kind` on ONE patch (d_patch (32,32) fp32) and copies the activation tensor after
  * trunk layer `layer` (0..5, post BN+ReLU, (C,H,W) fp32) to d_out.  Localises a kernel bug to one layer of
- * architectures.py:207-229 / HardNet.py:67-89. */
+ * architectures.py:207-229 / HardNet.py:67-89.  Exact-fp32 contexts only (AFFNET_ARITH_FP32_MFMA): the split-operand trunks have no
+ * per-layer dump, a context in another arithmetic mode gets AFFNET_ERR_INVALID instead of the exact path's activations. */
 int affnet_cnn32_debug_layer(affnet_ctx* ctx, int net_kind, const float* d_packed, const float* d_patch,
                              int layer, float* d_out, void* stream);
 

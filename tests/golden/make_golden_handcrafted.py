@@ -45,8 +45,14 @@ def main():
     with torch.no_grad(), rh.quiet():
         L, r = det(x, do_ori=False)
     out["baum4_LAFs"], out["baum4_resp"] = L.numpy(), r.numpy()
+    # hesaffBaum.py:40 as shipped: num_Baum_iters = 16 (same shim), and the file content it writes: LAFs2ellT (hesaffBaum.py:47)
+    det = SSAPE(mrSize=5.192, num_features=300, border=5, num_Baum_iters=16, AffNet=BaumShim(patch_size=19))
+    with torch.no_grad(), rh.quiet():
+        L, r = det(x, do_ori=False)
+    out["baum16_LAFs"], out["baum16_resp"] = L.numpy(), r.numpy()
+    out["baum16_ellT"] = ns.LAF.LAFs2ellT(L.clone()).numpy()
     np.savez_compressed(os.path.join(HERE, "handcrafted_slots.npz"), **out)
-    print("written; default path %d LAFs, Baumberg x4 %d LAFs" % (out["default_LAFs"].shape[0], out["baum4_LAFs"].shape[0]))
+    print("written; default path %d LAFs, Baumberg x4 %d LAFs, x16 %d LAFs" % (out["default_LAFs"].shape[0], out["baum4_LAFs"].shape[0], out["baum16_LAFs"].shape[0]))
 
 
 if __name__ == "__main__":

@@ -454,3 +454,33 @@ def test_split_arithmetics_error_class_cpu_emulation():
     assert r["bf16x3"][0] <= r["fp32_chain"][0] and r["fp16x2"][0] <= r["fp32_chain"][0], r
     assert r["fp16x2"][1] <= 1.2 * r["fp32_chain"][1] and r["fp16x2_unscaled"][0] > 1.5 * r["fp16x2"][0], r
     assert r["fp32_chain"][0] < 1e-7 and r["fp16x2"][0] < 5e-8
+
+
+def test_split2h_operand_error_bound_by_magnitude():
+    """include/affnet_hip.h on AFFNET_ARITH_FP32_SPLIT2H: x ~ fp16(x) + fp16(x - fp16(x)) holds to 2^-23 RELATIVE only for
+    |x| >= 2^-2; activations are not scaled, so below that the low term is a subnormal fp16 and the error is <= 2^-25 ABSOLUTE (2^-22 |x|
+    at 2^-3, 2^-17 |x| at 2^-8).  A layer of uniformly small activations therefore loses relative precision in this mode - a dot product
+    of such a layer against fp64 shows it, while the same layer at O(1) magnitudes does not."""
+    rng = np.random.RandomState(0)
+
+    def split_err(x):
+        h = x.astype(np.float16)
+        low = (x - h.astype(np.float32)).astype(np.float16)
+        return np.abs(x.astype(np.float64) - h.astype(np.float64) - low.astype(np.float64))
+
+    for lo, hi, rel_bound in ((-2, 15, 2.0 ** -23), (-3, -2, 2.0 ** -22), (-8, -5, 2.0 ** -17)):
+        x = (2.0 ** rng.uniform(lo, hi, 400000) * rng.choice([-1, 1], 400000)).astype(np.float32)
+        e = split_err(x)
+        assert (e / np.abs(x)).max() <= rel_bound * (1 + 1e-9), (lo, hi)
+        if hi <= -2:
+            assert e.max() <= 2.0 ** -25 * (1 + 1e-9) and (e / np.abs(x)).max() > 2.0 ** -23      # the absolute floor, beyond the relative bound
+    # a K = 288 dot product with two-term activations (weights exact here): O(1) activations vs the same values x 2^-10
+    w = rng.normal(0, 0.05, (64, 288)).astype(np.float32)
+    a = np.maximum(rng.normal(0, 1, (288,)), 0).astype(np.float32) + np.float32(0.3)
+    out = []
+    for scale in (1.0, 2.0 ** -10):
+        x = (a * np.float32(scale)).astype(np.float32)
+        two = x.astype(np.float16).astype(np.float64) + (x - x.astype(np.float16).astype(np.float32)).astype(np.float16).astype(np.float64)
+        exact = w.astype(np.float64) @ x.astype(np.float64)
+        out.append(np.abs(w.astype(np.float64) @ two - exact).max() / np.abs(w.astype(np.float64)).dot(np.abs(x.astype(np.float64))).max())
+    assert out[0] < 2.0 ** -23 and out[1] > 8 * out[0], out

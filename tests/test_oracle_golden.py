@@ -155,6 +155,10 @@ def test_handcrafted_slot_fillers_vs_reference_golden(golden_dir):
     ex = orc.OracleExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=4)
     L, r = ex(x, do_ori=False)
     assert np.array_equal(r.numpy(), g["baum4_resp"]) and np.abs(L.numpy() - g["baum4_LAFs"]).max() < 1e-3
+    ex = orc.OracleExtractor(mrSize=5.192, num_features=300, border=5, num_Baum_iters=16)             # hesaffBaum.py:40 as shipped
+    L, r = ex(x, do_ori=False)
+    assert np.array_equal(r.numpy(), g["baum16_resp"]) and np.abs(L.numpy() - g["baum16_LAFs"]).max() < 1e-3
+    assert np.abs(orc.lafs_to_ellipses_t(L).numpy() - g["baum16_ellT"]).max() <= 1e-4 * np.abs(g["baum16_ellT"]).max()
 
 
 def test_metric_configuration_1024x768_n2000(golden_dir, weights):
