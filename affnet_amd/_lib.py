@@ -8,7 +8,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaffnet_hip.so")
+# AFFNET_HIP_LIB: the tuning tools under tools/ point this at libaffnet_hip_probes.so (the same sources + the probe kernels of
+# include/affnet_hip_probes.h, `AFFNET_PROBES=1 bash affnet_amd/csrc/build.sh`); everything else loads the product library
+LIB_PATH = os.environ.get("AFFNET_HIP_LIB") or os.path.join(_HERE, "libaffnet_hip.so")
+PROBES_LIB_PATH = os.path.join(_HERE, "libaffnet_hip_probes.so")
 
 MAX_OCTAVES, MAX_LEVELS, MAX_TAPS = 16, 8, 37
 NET_AFFNET, NET_ORINET, NET_HARDNET, NET_AFFNET_FULLCONV = 0, 1, 2, 3
@@ -126,9 +129,13 @@ SYMBOLS = {
 DEBUG_SYMBOLS = {
     "affnet_cnn32_debug_timing": (_I, [_P, _P]),
     "affnet_cnn32_debug_layer": (_I, [_P, _I, _P, _P, _I, _P, _P]),
-    "affnet_cnn32_probe": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "affnet_selftest_mfma": (_I, [_P, _P, _P, _P]),
     "affnet_debug_split3_variant": (_I, [_P, _I]),
+}
+
+# include/affnet_hip_probes.h: probe kernels of the tuning tools - only in libaffnet_hip_probes.so (bound when present)
+PROBE_SYMBOLS = {
+    "affnet_cnn32_probe": (_I, [_P, _I, _I, _I, _I, _P, _P]),
     "affnet_split3_gemm": (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     "affnet_split3_rate": (_I, [_I, _I, _I, _P, _P]),
     "affnet_debug_stream": (_I, [_P, _P, _SZ, _I, _I, _I, _P]),
@@ -153,6 +160,10 @@ def _load():
     for table in (SYMBOLS, DEBUG_SYMBOLS):
         for name, (res, args) in table.items():
             fn = getattr(lib, name)  # raises AttributeError if the symbol is not exported
+            fn.restype, fn.argtypes = res, args
+    for name, (res, args) in PROBE_SYMBOLS.items():
+        if hasattr(lib, name):       # libaffnet_hip_probes.so
+            fn = getattr(lib, name)
             fn.restype, fn.argtypes = res, args
     return lib
 

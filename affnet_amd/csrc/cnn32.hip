@@ -1374,6 +1374,7 @@ extern "C" int affnet_cnn32_debug_layer(affnet_ctx* ctx, int net_kind, const flo
     return cnn_launch(ctx, net_kind, d_packed, d_patch, nullptr, nullptr, nullptr, 1, d_out, nullptr, layer, d_out, (hipStream_t)stream);
 }
 
+#ifdef AFFNET_PROBES   // libaffnet_hip_probes.so only (include/affnet_hip_probes.h)
 // ---- tuning aid: one HardNet layer's MFMA loop in isolation (no barriers, no epilogue), repeated ----------------------
 template <int LAYER, int PROBE>
 __global__ __launch_bounds__(512, 2) void cnn32_probe_kernel(const float* __restrict__ packed, NetOffsets off, int reps, float* __restrict__ out) {
@@ -1455,6 +1456,8 @@ extern "C" int affnet_cnn32_probe(const float* d_packed_hardnet, int layer, int 
 #undef PROBE_CASE
     return hipGetLastError() == hipSuccess ? AFFNET_OK : AFFNET_ERR_HIP;
 }
+
+#endif  // AFFNET_PROBES
 
 // ---- MFMA layout self-test ------------------------------------------------------------------------------
 __global__ void mfma_selftest_kernel(const float* __restrict__ A, const float* __restrict__ B, float* __restrict__ out) {

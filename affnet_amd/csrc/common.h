@@ -10,6 +10,9 @@
 
 #include "../../include/affnet_hip.h"
 #include "../../include/affnet_hip_debug.h"
+#ifdef AFFNET_PROBES
+#include "../../include/affnet_hip_probes.h"
+#endif
 
 #define AFF_WAVE 64
 

@@ -1,7 +1,9 @@
-// Counter-calibration kernels (include/affnet_hip_debug.h): known-byte-count streaming reads / writes / tile loads, so
+// Counter-calibration kernels (include/affnet_hip_probes.h): known-byte-count streaming reads / writes / tile loads, so
 // that rocprofv3's FETCH_SIZE / WRITE_SIZE can be turned into bytes for the access widths this library actually uses
 // (MI355X_MICROARCH.md, HBM section: only 16 B/lane streaming reads are calibrated there).  Not part of the product path.
 #include "common.h"
+
+#ifdef AFFNET_PROBES   // libaffnet_hip_probes.so only (include/affnet_hip_probes.h)
 
 template <typename T>
 __global__ __launch_bounds__(256) void stream_read_kernel(const T* __restrict__ src, float* __restrict__ dst, size_t n_items) {
@@ -68,3 +70,4 @@ extern "C" int affnet_debug_stream(const void* d_src, void* d_dst, size_t n_byte
     }
     return hipGetLastError() == hipSuccess ? AFFNET_OK : AFFNET_ERR_HIP;
 }
+#endif  // AFFNET_PROBES

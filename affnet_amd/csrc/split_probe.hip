@@ -1,4 +1,4 @@
-// Numerics / rate probes of the split-operand arithmetic (include/affnet_hip_debug.h; the product kernels of AFFNET_ARITH_FP32_SPLIT3 are in cnn32.hip / fullconv.hip).  fp32 = three bf16 terms: x = x0 + x1 + x2 with every term
+// Numerics / rate probes of the split-operand arithmetic (include/affnet_hip_probes.h, libaffnet_hip_probes.so only; the product kernels of AFFNET_ARITH_FP32_SPLIT3 are in cnn32.hip / fullconv.hip).  fp32 = three bf16 terms: x = x0 + x1 + x2 with every term
 // rounded to bf16 captures the 24-bit significand exactly, every bf16 x bf16 product is exact in the fp32 accumulator of
 // v_mfma_f32_16x16x32_bf16, and six of the nine term products (i + j <= 2) reproduce an fp32 product to 2^-25 relative.  At 16x the
 // fp32 matrix rate that is a 2.67x higher ceiling for the CNN stages.  Two probes:

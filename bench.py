@@ -249,7 +249,7 @@ def cpu_worker(spec):
         print(one(seed0 + 1 + k), flush=True)
 
 
-def parity_check(kept, fetch):
+def parity_check(kept, fetch, tag=None):
     """GPU rows of the benchmark's own batched launches vs the oracle outputs of the same seeds (north_star: LAFs and
     descriptors within 1e-3).  fetch(seed) -> dict(ids, LAFs, resp, desc) numpy arrays of that image from the LAST timed step.
     The statement covers every key and every row (oracle/fp64_referee.py, as in tests/test_gpu_parity.py): a key only one side returns must
@@ -265,6 +265,10 @@ def parity_check(kept, fetch):
            "rows_outside_combined_bar_round4": 0}
     for seed, want in kept:
         got = fetch(seed)
+        if os.environ.get("AFFNET_DUMP_ROWS"):          # the HIP path's rows of this seed, for tests/offline_parity_account.py on another host
+            os.makedirs(os.environ["AFFNET_DUMP_ROWS"], exist_ok=True)
+            np.savez_compressed(os.path.join(os.environ["AFFNET_DUMP_ROWS"], "configs_2__metric_configuration__image_%d__bench_%s.npz" % (seed, tag or "fp32")),
+                                ids=got["ids"], LAFs=got["LAFs"], resp=got["resp"], desc=got["desc"])
         kg, kw = key(got["ids"]), key(want["keys"])
         pos = {k: i for i, k in enumerate(kw)}
         gi = np.array([i for i, k in enumerate(kg) if k in pos], dtype=np.int64)
@@ -955,7 +959,7 @@ def run(args, world):
                 out["parity_check"] = parity_check(kept, fetcher(last))
                 for mode, res_m in last_split.items():
                     if "value" in out.get("arith_" + mode, {}):
-                        out["arith_" + mode]["parity_check"] = parity_check(kept, fetcher(res_m))
+                        out["arith_" + mode]["parity_check"] = parity_check(kept, fetcher(res_m), tag=mode)
         wall["total_since_process_start_s"] = round(time.time() - T_START, 1)
         out["wall_s"] = wall
         print(json.dumps(out), flush=True)

@@ -3,9 +3,10 @@
  *
  * NOT part of the drop-in boundary (include/affnet_hip.h): nothing here replaces a reference
  * function.  These symbols exist for the parity tests (layer-by-layer activation dumps, MFMA
- * fragment-layout self-test) and for the measurement tools under tools/ (in-kernel phase stamps,
- * isolated MFMA loops, known-byte-count streaming kernels that calibrate the rocprofv3
- * FETCH_SIZE / WRITE_SIZE counters).  A product build may drop them.
+ * fragment-layout self-test) and for the in-kernel phase stamps of tools/*_phase_timing.py.  The
+ * probe KERNELS of the tuning tools (isolated MFMA loops, counter-calibration streams, split-arithmetic
+ * GEMM / rate probes) are not in libaffnet_hip.so at all: include/affnet_hip_probes.h,
+ * libaffnet_hip_probes.so (AFFNET_PROBES=1 bash affnet_amd/csrc/build.sh).
  */
 #ifndef AFFNET_HIP_DEBUG_H
 #define AFFNET_HIP_DEBUG_H
@@ -29,40 +30,15 @@ int affnet_cnn32_debug_layer(affnet_ctx* ctx, int net_kind, const float* d_packe
  * 16..22 sub-phases of the input stage).  NULL switches it off.  Other contexts are not affected. */
 int affnet_cnn32_debug_timing(affnet_ctx* ctx, unsigned long long* d_stamps);
 
-/* Tuning aid: runs the MFMA loop of one layer in isolation `reps` times per workgroup on `n_blocks` workgroups (same LDS
- * footprint as the trunk kernel).  layer 1 / 5: HardNet conv1 / conv5 (d_packed = HardNet's packed weights); 13 / 14 / 15:
- * AffNet conv3 as 2 x 2 tiles / conv3 as 4 x 1 tiles / conv5 (d_packed = AffNet's).  probe bit 0: no weight loads inside
- * the loop, bit 1: no activation loads, bit 2: accumulators in AGPRs, bit 3: lane-consecutive LDS read pattern (HardNet
- * layers only) - separates matrix-pipe issue efficiency from L2 / LDS effects.  d_out: 2 floats (sink). */
-int affnet_cnn32_probe(const float* d_packed, int layer, int probe, int reps, int n_blocks, float* d_out, void* stream);
-
 /* 16x16x4 fp32 MFMA layout self-test: d_out (16,16) = A (16,4) * B (4,16). */
 int affnet_selftest_mfma(const float* d_A, const float* d_B, float* d_out, void* stream);
 
-/* Counter calibration (MI355X_MICROARCH.md, HBM section: "calibrate on a known byte count in your own access pattern"):
- * streams exactly n_bytes (a multiple of 64 KiB) with `width` bytes per lane per load (4, 8 or 16), fully coalesced.
- *   mode 0: read d_src, reduce, one 4-byte store per workgroup to d_dst     (known READ bytes  = n_bytes)
- *   mode 1: write d_dst with a lane pattern, no reads                        (known WRITE bytes = n_bytes)
- *   mode 2: 64 x 64 fp32 tiles with a (halo)-pixel apron through LDS like the blur / Hessian tile loaders: image
- *           (n_bytes / 4 / 4096 rows of 4096 px), 4-byte loads, known unique bytes = n_bytes (halo re-reads hit L2)
- * Run under `rocprofv3 --pmc FETCH_SIZE` / `WRITE_SIZE`; tools/fetch_calib.py turns the counters into the per-width
- * factors that tools/pmc_traffic.py applies. */
-int affnet_debug_stream(const void* d_src, void* d_dst, size_t n_bytes, int width, int mode, int halo, void* stream);
-
-/* Numerics / rate probes of the split-operand arithmetic (AFFNET_ARITH_FP32_SPLIT3): fp32 operands as three bf16 terms on v_mfma_f32_16x16x32_bf16 (csrc/split_probe.hip).
- *   affnet_split3_gemm: d_C (M x N) = d_A (M x K) * d_Bt^T (d_Bt: N x K), M, N multiples of 16, K of 32.  mode 0 = the exact-fp32
- *     v_mfma_f32_16x16x4_f32 chain (today's arithmetic), 1 = six split terms, 2 = nine, 3 = the leading bf16 term only.
- *   affnet_split3_rate: sustained rate of the inner-loop shape a trunk layer would have (fragments from LDS, 4 pixel tiles x 1 channel
- *     tile); terms = 6 / 9 on bf16 MFMA, 1 = the fp32 16x16x4 loop over the same tiles.  One launch = n_blocks x 8 waves x reps x 4 tiles
- *     x (16 x 16 x 32) multiply-adds.  d_out: 2 floats (sink). */
 /* Tuning aid for AFFNET_ARITH_FP32_SPLIT3 (include/affnet_hip.h: affnet_set_arith is the product switch): variant bits of the
  * split-operand trunk launches of this context.  bit 0 (value 1): alternating wave priorities in the HardNet loops (A/B aid of
  * tools/s3_net_timing.py; results identical; default off).  bit 1 (value 2): the HardNet loops of AFFNET_ARITH_FP32_SPLIT2H skip their
  * NaN -> +inf step (A/B of its cost only, tools/ab_nan_step.py: an out-of-range activation could then be hidden by a ReLU).  Does not
  * change the arithmetic mode. */
 int affnet_debug_split3_variant(affnet_ctx* ctx, int bits);
-int affnet_split3_gemm(const float* d_A, const float* d_Bt, int M, int N, int K, int mode, float* d_C, void* stream);
-int affnet_split3_rate(int reps, int terms, int n_blocks, float* d_out, void* stream);
 
 #ifdef __cplusplus
 }

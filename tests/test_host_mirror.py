@@ -28,6 +28,16 @@ def test_library_exports_every_declared_symbol():
         for name in declared:
             assert hasattr(raw, name), name
     assert not [n for n in _lib.SYMBOLS if "debug" in n or "probe" in n or "selftest" in n], "debug entry points leaked into the boundary"
+    # the probe kernels of the tuning tools (include/affnet_hip_probes.h) are NOT in the shipped library - only in libaffnet_hip_probes.so
+    hdr = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "affnet_hip_probes.h")).read(), flags=re.S)
+    probes = set(re.findall(r"\b(affnet_[a-z0-9_]+)\s*\(", hdr))
+    assert probes == set(_lib.PROBE_SYMBOLS)
+    product = C.CDLL(os.path.join(ROOT, "affnet_amd", "libaffnet_hip.so"))
+    assert not [n for n in probes if hasattr(product, n)], "probe entry points in the product library"
+    if os.path.isfile(_lib.PROBES_LIB_PATH):
+        pl = C.CDLL(_lib.PROBES_LIB_PATH)
+        for name in list(probes) + list(_lib.SYMBOLS) + list(_lib.DEBUG_SYMBOLS):
+            assert hasattr(pl, name), name
     assert b"gfx950" in _lib.lib.affnet_version()
     assert C.sizeof(_lib.Config) > 30000  # struct mirrors the 8 x 31x31 tap tables
 
@@ -158,8 +168,11 @@ def test_no_product_kernel_spills_registers():
     import kernel_resources as kr
     ks = kr.all_kernels()
     assert len(ks) > 100, "metadata of the built objects not found (run __graft_entry__.build())"
-    # (the STAMPS = true instantiations of the trunk kernel - third template argument - exist only for tools/*_phase_timing.py)
-    tooling = re.compile(r"cnn32_trunk_kernelILi\dELi8ELb1E|probe_kernel|split3_rate|split3_gemm|debug_stream")
+    # (the STAMPS = true instantiations of the trunk kernel - third template argument - exist only for tools/*_phase_timing.py and the
+    # layer dumps of the parity tests; the probe kernels of the tuning tools are not in these objects at all since round 5)
+    tooling = re.compile(r"cnn32_trunk_kernelILi\dELi8ELb1E")
+    assert not [k["name"] for k in ks.values() if re.search(r"probe_kernel|split3_rate|split3_gemm|stream_read_kernel|stream_write_kernel|tile_read_kernel", k["name"])], \
+        "probe kernels in the product objects (they belong to libaffnet_hip_probes.so, AFFNET_PROBES=1)"
     bad = {k["name"]: (k.get("vgpr_spill_count", 0), k.get("sgpr_spill_count", 0), k.get("private_segment_fixed_size", 0)) for k in ks.values()
            if (k.get("vgpr_spill_count", 0) or k.get("private_segment_fixed_size", 0)) and not tooling.search(k["name"])}
     assert not bad, bad

@@ -5,6 +5,8 @@ import os, subprocess, sys, time
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+import os as _os
+_os.environ.setdefault("AFFNET_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "affnet_amd", "libaffnet_hip_probes.so"))   # probe kernels live there (include/affnet_hip_probes.h)
 import affnet_amd
 from affnet_amd._lib import lib, ptr
 layer, probe = int(sys.argv[1]), int(sys.argv[2])

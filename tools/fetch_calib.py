@@ -29,6 +29,8 @@ KERNEL_OF = {("read", 4): "stream_read_kernel<float>", ("read", 8): "stream_read
 
 def run():
     import torch
+    import os as _os
+    _os.environ.setdefault("AFFNET_HIP_LIB", _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "affnet_amd", "libaffnet_hip_probes.so"))   # probe kernels live there (include/affnet_hip_probes.h)
     from affnet_amd._lib import lib, ptr
     dev = torch.device("cuda:0")
     src = torch.rand(N_BYTES // 4, device=dev)

@@ -13,11 +13,10 @@ A = affnet_amd.AffNetFast(); A.load_state_dict(torch.load(os.path.join(ROOT, "pr
 O = affnet_amd.OriNetFast(PS=32); O.load_state_dict(torch.load(os.path.join(ROOT, "pretrained/OriNet.pth"), map_location="cpu", weights_only=False)["state_dict"]); O.to(dev)
 H = affnet_amd.HardNet(); H.load_state_dict(affnet_amd.synthetic_hardnet_state(0)); H.to(dev)
 big = (torch.rand(48000, 1, 32, 32) * 255).to(dev)
-ctx = engine.utility_ctx(dev)        # the nets' stand-alone calls (arith "fp32") run on this context: switch IT for the A/B
 for arith in (0, 1, 2, 1, 2):          # AFFNET_ARITH_*: 0 exact, 1 three bf16 terms, 2 two fp16 terms
-    lib.affnet_set_arith(ctx, arith)
     row = []
     for nm, net in (("AffNet", A), ("OriNet", O), ("HardNet", H)):
+        net.arith = arith              # stand-alone calls run on the (device, arith) utility context: no shared handle is switched in place
         net(big); torch.cuda.synchronize()
         best = 1e9
         for _ in range(5):
@@ -26,4 +25,3 @@ for arith in (0, 1, 2, 1, 2):          # AFFNET_ARITH_*: 0 exact, 1 three bf16 t
             best = min(best, e0.elapsed_time(e1))
         row.append("%s %.3f ms" % (nm, best))
     print({0: "exact        ", 1: "fp32_split3  ", 2: "fp32_split2h "}[arith], " | ".join(row))
-lib.affnet_set_arith(ctx, 0)

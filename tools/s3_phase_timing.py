@@ -17,12 +17,12 @@ A = affnet_amd.AffNetFast(); A.load_state_dict(torch.load(os.path.join(ROOT, "pr
 O = affnet_amd.OriNetFast(PS=32); O.load_state_dict(torch.load(os.path.join(ROOT, "pretrained/OriNet.pth"), map_location="cpu", weights_only=False)["state_dict"]); O.to(dev)
 names = ["input+norm", "conv0", "conv1 mfma", "conv1 store", "conv2 mfma", "conv2 store", "conv3 mfma", "conv3 store",
          "conv4 mfma", "conv4 store", "conv5 mfma"]
-ctx = engine.utility_ctx(dev)
 SPLIT_MODES = tuple(int(v) for v in os.environ.get("PHASE_ARITH", "1,2").split(","))      # AFFNET_ARITH_* codes of the split modes to stamp
 nets = [("HardNet", H, (0,) + SPLIT_MODES)] + ([("AffNet", A, SPLIT_MODES), ("OriNet", O, SPLIT_MODES)] if os.environ.get("PHASE_ALL", "1") == "1" else [])
 for nm, net, modes in nets:
   for split in modes:
-    lib.affnet_set_arith(ctx, split)
+    net.arith = split                      # stand-alone calls run on the (device, arith) utility context: no shared handle is switched in place
+    ctx = engine.utility_ctx(dev, split)
     net(p); torch.cuda.synchronize()
     st = torch.zeros(n * nw * 32, dtype=torch.int64, device=dev)
     lib.affnet_cnn32_debug_timing(ctx, ptr(st))
@@ -49,4 +49,3 @@ for nm, net, modes in nets:
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); net(big); e1.record(); torch.cuda.synchronize()
     print("  48000 patches: %.3f ms" % e0.elapsed_time(e1))
-lib.affnet_set_arith(ctx, 0)
