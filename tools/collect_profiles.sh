@@ -39,6 +39,11 @@ grep -v "^ *value" gpurun_out/clock_watch.txt > profiles/${T}_clock_power_exact_
 # BASELINE configs[4] counters
 [ -f gpurun_out/config5_traffic.json ] && sed "s#gpurun_out/fetch_calibration.json#profiles/${T}_fetch_calibration.json#" gpurun_out/config5_traffic.json > profiles/${T}_config5_traffic.json
 [ -f gpurun_out/pmc_config5_summary.txt ] && cp gpurun_out/pmc_config5_summary.txt profiles/${T}_config5_pmc_summary.txt
+[ -f gpurun_out/cpu_conv_order_gpubox.txt ] && cp gpurun_out/cpu_conv_order_gpubox.txt profiles/${T}_cpu_conv_order_gpubox.txt
+[ -f gpurun_out/ab_variant.txt ] && cp gpurun_out/ab_variant.txt profiles/${T}_ab_variant.txt
+[ -f gpurun_out/bench_self_gather_all.log ] && grep '^{' gpurun_out/bench_self_gather_all.log > profiles/${T}_bench_self_gather_rccl_1rank_all_gather_verify_gather.json
+# the same GPU rows against the reference on THIS host (the authoring container = the host of tests/golden): needs the oracle, runs here
+[ -d gpurun_out/rows ] && python tests/offline_parity_account.py gpurun_out/rows profiles/${T}_offline_parity_account_authoring_host.json | tail -n 1
 python tools/kernel_resources.py > profiles/${T}_kernel_resources.md
 python tools/roofline_table.py profiles/${T} > profiles/${T}_roofline_table.md
 ls -la profiles/${T}_*

@@ -10,3 +10,6 @@ for N in 2 4; do
 done
 AFFNET_BENCH_SELF_GATHER=1 timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --verify-gather all > gpurun_out/bench_self_gather.log 2>&1
 echo "self-gather exit $?"; grep '^{' gpurun_out/bench_self_gather.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['gather_check'], d['exchange'])"; grep -i "error\|Traceback" gpurun_out/bench_self_gather.log | head -5
+# the other exchange mode through RCCL as well (round 5: gather to rank 0 is the default, --gather all = all_gather)
+AFFNET_BENCH_SELF_GATHER=1 timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-other-configs --no-split3 --gather all --verify-gather all > gpurun_out/bench_self_gather_all.log 2>&1
+echo "self-gather (all_gather) exit $?"; grep '^{' gpurun_out/bench_self_gather_all.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['gather_check'], d['exchange'])"; grep -i "error\|Traceback" gpurun_out/bench_self_gather_all.log | head -5

@@ -4,7 +4,10 @@
 # applies + the N-rank path on one device.  Part B (tools/gpu_full_prof.sh): rocprofv3 kernel stats, PMC passes, counter calibration.
 # Everything lands in gpurun_out/; copy what is to be judged into profiles/ with tools/collect_profiles.sh <tag>.
 mkdir -p gpurun_out; export HSA_ENABLE_IPC_MODE_LEGACY=0 TMPDIR=/tmp
-export AFFNET_PARITY_REPORT=$PWD/gpurun_out/parity_report.json
+export AFFNET_PARITY_REPORT=$PWD/gpurun_out/parity_report.json AFFNET_DUMP_ROWS=$PWD/gpurun_out/rows
+rm -rf gpurun_out/rows
+# which fp32 summation orders does THIS host's torch CPU use (the live oracle's host: reference-side host variation)
+lscpu | grep "Model name" > gpurun_out/cpu_conv_order_gpubox.txt; timeout 300 python tools/probes/cpu_conv_order.py 16 >> gpurun_out/cpu_conv_order_gpubox.txt 2>&1; tail -n 3 gpurun_out/cpu_conv_order_gpubox.txt | cut -c1-250
 timeout 1500 python -m pytest tests -q -m gpu -p no:cacheprovider -rA > gpurun_out/pytest_gpu.log 2>&1; echo "pytest exit: $?"; tail -n 3 gpurun_out/pytest_gpu.log | cut -c1-300
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; echo "smoke exit: $?"; tail -n 2 gpurun_out/smoke.log
 ( time timeout 900 python bench.py ) > gpurun_out/bench_default.log 2>&1; echo "bench exit: $?"; grep '^{' gpurun_out/bench_default.log | cut -c1-400; grep "^real" gpurun_out/bench_default.log
@@ -21,3 +24,4 @@ timeout 300 python bench.py --include-h2d --no-cpu-baseline --no-secondary --no-
 # gathered record re-computed by rank 0 (--verify-gather all); then the 1-rank RCCL flavour, verified too
 bash tools/gpu_dist_dryrun.sh
 timeout 120 python bench.py --gpus 2 --steps 1 --warmup 0 > gpurun_out/bench_gpus2_refused.log 2>&1; echo "gpus2 on a 1-GPU box exit (2 = refused loudly): $?"; tail -n 2 gpurun_out/bench_gpus2_refused.log
+timeout 200 python tools/ab_variant.py 2>&1 | grep -v amdgpu.ids > gpurun_out/ab_variant.txt; tail -n 4 gpurun_out/ab_variant.txt
