@@ -258,6 +258,7 @@ def parity_check(kept, fetch, tag=None):
     the CPU reference's own row + 1e-3 px (`rows_worse_than_cpu_vs_fp64`), and no row may be outside 5e-3 px."""
     import numpy as np
     import fp64_referee as rf
+    torch.set_num_threads(max(1, min(16, host_threads()[1])))      # the referee's small float64 GEMMs: more threads only get slower (cpu_baseline's sweep)
     key = lambda a: a[:, 0].astype(np.int64) * (1 << 40) + a[:, 1].astype(np.int64) * (1 << 32) + a[:, 2].astype(np.int64)
     tot = {"images": 0, "seeds": [], "keypoints": 0, "matched": 0, "laf_max_px": 0.0, "laf_rows_within_1e-3": 0, "desc_max": 0.0,
            "desc_rows_within_1e-3": 0, "responses_equal": True, "same_row_order": True, "unmatched_keys": 0, "unmatched_borderline_flips": 0,
