@@ -50,7 +50,7 @@ PEAK_HBM_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec; ~6
 GRAF = os.path.join(ROOT, "tests", "golden", "graf_img1.png")
 DTYPE_SPLIT3 = ("f32 (AFFNET_ARITH_FP32_SPLIT3: every fp32 operand of the CNN contractions as three bf16 terms, six v_mfma_f32_16x16x32_bf16 per "
                 "product, fp32 accumulate; conv0, the AffNet / OriNet heads and everything outside the CNNs plain fp32)")
-DTYPE_SPLIT2H = ("f32 (AFFNET_ARITH_FP32_SPLIT2H: every fp32 operand of the CNN contractions as two fp16 terms (|x - h - l| <= 2^-23 |x|), three "
+DTYPE_SPLIT2H = ("f32 (AFFNET_ARITH_FP32_SPLIT2H: every fp32 operand of the CNN contractions as two fp16 terms (|x - h - l| <= 2^-23 |x| for |x| >= 2^-2, <= 2^-25 absolute below), three "
                  "v_mfma_f32_16x16x32_f16 per product, fp32 accumulate; conv0, the AffNet / OriNet heads and everything outside the CNNs plain fp32)")
 # the split arithmetic modes of the boundary (include/affnet_hip.h): matrix instructions per fp32 product, labels
 SPLIT = {"fp32_split3": {"products": 6.0, "dtype": DTYPE_SPLIT3, "label": "CNN contractions on 3 x bf16 split operands", "insn": "6 x v_mfma_f32_16x16x32_bf16"},
@@ -920,7 +920,7 @@ def run(args, world):
                         "note": "another arithmetic mode of the boundary (affnet_config.arith / affnet_set_arith), never the headline: fp32 operands as "
                                 "%s, %s per product, fp32 accumulate; differs from the default path like one fp32 summation order from another (every "
                                 "full-path GPU test runs in all modes with the same bars)"
-                                % ("three bf16 terms (exact)" if mode == "fp32_split3" else "two fp16 terms (to 2^-23 relative)", SPLIT[mode]["insn"])}
+                                % ("three bf16 terms (exact)" if mode == "fp32_split3" else "two fp16 terms (to 2^-23 relative for |x| >= 2^-2, 2^-25 absolute below)", SPLIT[mode]["insn"])}
                 except Exception as e:                                   # noqa: BLE001  (never at the expense of the main line)
                     out[key] = {"error": repr(e)[:300]}
                     last_split.pop(mode, None)
