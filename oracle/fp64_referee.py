@@ -320,7 +320,10 @@ def parity_account(ref, ids_gpu, L_gpu, n_out, full=False):
                                    itself misses its float64 result by >= 1e-3 px - nor (c) an ordinary-accuracy evaluation of an
                                    ill-conditioned frame: the row's error as an equivalent CNN-output error, err |o| / S (S = frame scale in px,
                                    |o| = OriNet vector length, both from the fp64 evaluation), no larger than the MEDIAN of that quantity over
-                                   the reference's own rows of the image.  Must be 0.  (Measured, round 5: the rows concerned have S / |o| of
+                                   the reference's own rows of the image.  Must be 0.
+      rows_outside_5e-3_unexplained  rows that differ by >= 5e-3 px although the CPU reference's own row is within 5e-3 px of fp64 (must be 0: the
+                                   hard ceiling; a frame whose OriNet vector has length 0.0015 is 1e-2 px from fp64 on BOTH sides and may
+                                   exceed it - seen once in a sweep of 112 415 rows).  (Measured, round 5: the rows concerned have S / |o| of
                                    1400 - 5400 against a median of 29: 1 - 2 rows of 8000 at 4K, one of 4000 in the bench's images.)
     full=True evaluates the referee on EVERY matched row (seconds per 2000 rows) and adds the distributions of both sides' distance to fp64."""
     ex = ref.ex
@@ -336,7 +339,7 @@ def parity_account(ref, ids_gpu, L_gpu, n_out, full=False):
     rows = np.arange(len(gi)) if full else out
     rows, eg, ec, _ = referee_rows(ref, ids_gpu[gi], L_gpu[gi], L_cpu[wi], rows)
     at = {int(r): j for j, r in enumerate(rows)}
-    worse, unexplained_rows, listed = 0, 0, []
+    worse, unexplained_rows, beyond_ceiling, listed = 0, 0, 0, []
     median_u = None
     for r in out:
         j = at[int(r)]
@@ -349,6 +352,7 @@ def parity_account(ref, ids_gpu, L_gpu, n_out, full=False):
                "reference_row_itself_1e-3_from_fp64": ill, "frame_scale_px": float(S[0]), "orinet_norm": float(on[0]),
                "equivalent_output_error": float(u[0])}
         worse += bad
+        beyond_ceiling += bool(dl[r] >= 5e-3 and ec[j] < 5e-3)       # a row may differ by 5e-3 px only where the reference's own row is that far from fp64
         if bad and not ill:
             # third reading: is this an ordinary-accuracy evaluation of an ill-conditioned frame?  The row's error as an equivalent CNN-output
             # error (err |o| / S) against the MEDIAN of the same quantity over the CPU reference's own rows of this image (every row evaluated
@@ -369,7 +373,7 @@ def parity_account(ref, ids_gpu, L_gpu, n_out, full=False):
            "unmatched_keys": exp["gpu_only"] + exp["cpu_only"], "unmatched_borderline_flips": exp["borderline_flips"],
            "unmatched_unexplained": exp["unmatched_unexplained"], "unmatched_rows": exp["rows"],
            "rows_outside_1e-3": int(len(out)), "rows_worse_than_cpu_vs_fp64": int(worse), "rows_outside_1e-3_unexplained": int(unexplained_rows),
-           "rows_outside_1e-3_vs_fp64": listed,
+           "rows_outside_5e-3_unexplained": int(beyond_ceiling), "rows_outside_1e-3_vs_fp64": listed,
            "laf_max_px_gpu_vs_cpu": float(dl.max()) if len(dl) else 0.0}
     if full and len(rows):
         q = lambda a: [float(np.percentile(a, p)) for p in (50, 99, 100)]

@@ -34,6 +34,10 @@ CASES = [  # (file-name pattern, image factory, N)
     (r"^configs_4___3840x2160_seed_0", lambda m: orc.synthetic_image(2160, 3840, 0), 8000),
     (r"^odd_sized_input_(hesaffnet_cat|hesaffnet_fox1)", lambda m: load_gray(os.path.join(GOLD, m.group(1) + ".png")), 2000),
     (r"^odd_sized_input_synth_481x641_s5", lambda m: orc.synthetic_image(481, 641, 5), 2000),
+    # tests/dump_rows_gpu.py: the wide sweep
+    (r"^sweep_synth_(\d+)x(\d+)_s(\d+)_n(\d+)", lambda m: orc.synthetic_image(int(m.group(1)), int(m.group(2)), int(m.group(3))), None),
+    (r"^sweep_graf_img6_n(\d+)", lambda m: load_gray(os.path.join(GOLD, "graf_img6.png")), None),
+    (r"^sweep_hesaffnet_cat_n(\d+)", lambda m: load_gray(os.path.join(GOLD, "hesaffnet_cat.png")), None),
 ]
 
 
@@ -47,6 +51,8 @@ def main(argv):
             m = re.match(pat, name)
             if not m:
                 continue
+            if n is None:                                # N is the last group of the file name
+                n = int(m.groups()[-1])
             key = (pat, m.groups(), n)
             if key not in runs:
                 x = img(m)
@@ -63,7 +69,9 @@ def main(argv):
     if len(argv) > 1:
         json.dump({"what": "oracle/fp64_referee.parity_account of dumped GPU rows against the reference on this host (%s)" % os.uname().nodename,
                    "cases": out}, open(argv[1], "w"), indent=1, sort_keys=True)
-    bad = [k for k, a in out.items() if a["unmatched_unexplained"] or a["rows_outside_1e-3_unexplained"]]
+    bad = [k for k, a in out.items() if a["unmatched_unexplained"] or a["rows_outside_1e-3_unexplained"] or a["rows_outside_5e-3_unexplained"]]
+    tot = sum(a["matched"] for a in out.values())
+    print("matched rows %d, rows >= 1e-3 px %d, worst %.3g px" % (tot, sum(a["rows_outside_1e-3"] for a in out.values()), max(a["laf_max_px_gpu_vs_cpu"] for a in out.values())))
     print("cases: %d, with unexplained keys / rows: %d %s" % (len(out), len(bad), bad))
     return 1 if bad else 0
 

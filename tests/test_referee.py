@@ -96,6 +96,7 @@ def test_accounting_flags_a_dropped_keypoint_and_a_wrong_row(graf_run):
     L3[both[3], 0, 0] += 5e-3
     rec = rf.parity_account(ref, ids, L3, 500)
     assert rec["rows_outside_1e-3"] >= 1 and rec["rows_worse_than_cpu_vs_fp64"] >= 1 and rec["rows_outside_1e-3_unexplained"] >= 1
+    assert rec["rows_outside_5e-3_unexplained"] >= 1            # 5e-3 px off while the reference's own row is within 5e-3 px of float64: beyond the hard ceiling
     # (3) a row that is not a detector candidate at all
     ids4 = ids.copy()
     ids4[both[5]] = [0, 0, 12345678]
