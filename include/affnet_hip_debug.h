@@ -3,7 +3,7 @@
  *
  * NOT part of the drop-in boundary (include/affnet_hip.h): nothing here replaces a reference
  * function.  These symbols exist for the parity tests (layer-by-layer activation dumps, MFMA
- * fragment-layout self-test) and for the in-kernel phase stamps of tools/*_phase_timing.py.  The
+ * fragment-layout self-test) and for the in-kernel phase stamps of tools/cnn_phase_timing.py / s3_phase_timing.py.  The
  * probe KERNELS of the tuning tools (isolated MFMA loops, counter-calibration streams, split-arithmetic
  * GEMM / rate probes) are not in libaffnet_hip.so at all: include/affnet_hip_probes.h,
  * libaffnet_hip_probes.so (AFFNET_PROBES=1 bash affnet_amd/csrc/build.sh).
