@@ -311,13 +311,14 @@ def test_exact_arithmetic_spec_of_the_blur():
 
 
 def test_headers_are_plain_c():
-    """The drop-in boundary is a C ABI: both headers must compile as C99 (no C++ constructs, no torch / HIP types)."""
+    """The drop-in boundary is a C ABI: every header must compile as C99 without warnings (no C++ constructs, no torch / HIP types); and the plain-C
+    host program of examples/c_host builds against them with gcc -Wall -Wextra (examples/c_host/build.sh, run by __graft_entry__.build())."""
     import shutil
     import subprocess
     if shutil.which("gcc") is None:
         pytest.skip("gcc not available")
-    for h in ("affnet_hip.h", "affnet_hip_debug.h"):
-        subprocess.check_call(["gcc", "-std=c99", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", h)])
+    for h in ("affnet_hip.h", "affnet_hip_debug.h", "affnet_hip_probes.h"):
+        subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(ROOT, "include", h)])
         src = open(os.path.join(ROOT, "include", h)).read()
         assert "hip/" not in src and "torch" not in re.sub(r"/\*.*?\*/", "", src, flags=re.S), h
 
