@@ -258,6 +258,7 @@ def parity_check(kept, fetch, tag=None):
     the CPU reference's own row + 1e-3 px (`rows_worse_than_cpu_vs_fp64`), and no row may be outside 5e-3 px."""
     import numpy as np
     import fp64_referee as rf
+    threads_before = torch.get_num_threads()
     torch.set_num_threads(max(1, min(16, host_threads()[1])))      # the referee's small float64 GEMMs: more threads only get slower (cpu_baseline's sweep)
     key = lambda a: a[:, 0].astype(np.int64) * (1 << 40) + a[:, 1].astype(np.int64) * (1 << 32) + a[:, 2].astype(np.int64)
     tot = {"images": 0, "seeds": [], "keypoints": 0, "matched": 0, "laf_max_px": 0.0, "laf_rows_within_1e-3": 0, "desc_max": 0.0,
@@ -316,6 +317,7 @@ def parity_check(kept, fetch, tag=None):
                   "LAF rows: >= 99.5 % within 1e-3 px, none outside 5e-3 px unless the CPU reference's own row is that far from float64, every row outside 1e-3 px no farther from the float64 referee than the CPU "
                   "reference's row + 1e-3 px, or the CPU reference's own row >= 1e-3 px from fp64 (rows_outside_1e-3_unexplained = 0); descriptors >= 99.5 % within 1e-3; responses bit-equal")
     tot["reference"] = "oracle/affnet_oracle.py (bit-identical to the unmodified reference, oracle/check_restatement.py) on this host; referee oracle/fp64_referee.py"
+    torch.set_num_threads(threads_before)
     return tot
 
 
