@@ -498,3 +498,20 @@ def test_split2h_operand_error_bound_by_magnitude():
         exact = w.astype(np.float64) @ x.astype(np.float64)
         out.append(np.abs(w.astype(np.float64) @ two - exact).max() / np.abs(w.astype(np.float64)).dot(np.abs(x.astype(np.float64))).max())
     assert out[0] < 2.0 ** -23 and out[1] > 8 * out[0], out
+
+
+def test_reference_centroid_conv_order_the_detector_kernel_assumes():
+    """csrc/detect.hip sums the detector's 27-tap centroid in the order of the reference's CPU conv2d: (level, ky, kx) for maps of at most
+    20480 / 3 pixels (ATen's native im2col + sgemm path), (ky, kx, level) above (oneDNN) - round 5, DESIGN section 2.  This pins that
+    assumption against the torch build of THIS host (tools/probes/cpu_conv_order.py): a torch / oneDNN upgrade that changes the order shows
+    here, not as 1e-3 px LAF outliers on the GPU.  The large-map order holds on every host seen; the small-map order is a sequential chain on
+    the authoring host (Intel MKL) and NOT on an AMD host (MKL's sgemm there sums differently: reference-side host variation) - then only
+    the large-map half is asserted."""
+    sys.path.insert(0, os.path.join(ROOT, "tools", "probes"))
+    import cpu_conv_order as cco
+    assert cco.orders_matching(83, 83) == ["klc"] and cco.orders_matching(96, 128) == ["klc"], "oneDNN's direct 3-channel convolution no longer sums in (ky, kx, level) order"
+    small = cco.orders_matching(82, 83)
+    if small:
+        assert small == ["ckl"], small
+    else:
+        pytest.skip("this host's small-map sgemm is not a sequential fmaf chain (AMD host): the live oracle differs from tests/golden by an ulp in the small octaves")
