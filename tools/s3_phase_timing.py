@@ -23,6 +23,7 @@ for nm, net, modes in nets:
   for split in modes:
     net.arith = split                      # stand-alone calls run on the (device, arith) utility context: no shared handle is switched in place
     ctx = engine.utility_ctx(dev, split)
+    lib.affnet_debug_split3_variant(ctx, int(os.environ.get("PHASE_VARIANT", "0")) if split else 0)     # bit 0: alternating wave priorities in the HardNet loops
     net(p); torch.cuda.synchronize()
     st = torch.zeros(n * nw * 32, dtype=torch.int64, device=dev)
     lib.affnet_cnn32_debug_timing(ctx, ptr(st))
@@ -49,3 +50,5 @@ for nm, net, modes in nets:
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); net(big); e1.record(); torch.cuda.synchronize()
     print("  48000 patches: %.3f ms" % e0.elapsed_time(e1))
+for m in SPLIT_MODES:
+    lib.affnet_debug_split3_variant(engine.utility_ctx(dev, m), 0)
