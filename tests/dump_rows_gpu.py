@@ -28,6 +28,19 @@ def main(out):
     A = affnet_amd.AffNetFast(PS=32); A.load_state_dict(sd["AffNet"]); A = A.to(DEV)
     O = affnet_amd.OriNetFast(PS=32); O.load_state_dict(sd["OriNet"]); O = O.to(DEV)
     H = affnet_amd.HardNet(); H.load_state_dict(affnet_amd.synthetic_hardnet_state(0)); H = H.to(DEV)
+    if len(sys.argv) > 2 and sys.argv[2] == "metric_batch":
+        # every image of the metric's batch (BASELINE configs[2]: seeds 0 .. 63 of bench.py), as ONE 32-image batched call per half like the benchmark
+        for half in (0, 1):
+            seeds = list(range(32 * half, 32 * half + 32))
+            xb = torch.cat([affnet_amd.synthetic_image(768, 1024, s) for s in seeds], 0).to(DEV)
+            for arith in ("fp32", "fp32_split2h"):
+                det = affnet_amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=2000, border=5, num_Baum_iters=1, AffNet=A, OriNet=O, arith=arith).to(DEV)
+                for s, r in zip(seeds, det.run_batch(xb, do_ori=True, desc=H)):
+                    np.savez_compressed(os.path.join(out, "sweep_synth_768x1024_s%d_n2000%s.npz" % (s, "" if arith == "fp32" else "__arith_" + arith)),
+                                        ids=r["ids"].cpu().numpy(), LAFs=r["LAFs"].cpu().numpy(), resp=r["responses"].cpu().numpy())
+                del det
+            print("metric batch, seeds %d .. %d" % (seeds[0], seeds[-1]), flush=True)
+        return
     cases = [("sweep_synth_768x1024_s%d_n2000" % s, lambda s=s: affnet_amd.synthetic_image(768, 1024, s), 2000) for s in range(100, 124)]
     cases += [("sweep_synth_768x1024_s%d_n%d" % (s, n), lambda s=s: affnet_amd.synthetic_image(768, 1024, s), n) for s, n in ((7, 500), (8, 1000), (9, 4000))]
     cases += [("sweep_synth_480x640_s%d_n1000" % s, lambda s=s: affnet_amd.synthetic_image(480, 640, s), 1000) for s in (40, 41, 42, 43)]
