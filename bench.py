@@ -322,6 +322,113 @@ def parity_check(kept, fetch, tag=None):
 
 
 # ----------------------------------------------------------------------------------------------------------------------
+LINE_LIMIT = 4096                  # bytes of the ONE stdout line (the driver could not parse a 31 KB line)
+DETAIL_FILE = "bench_detail.json"
+
+
+def _num(v, digits=6):
+    """Numbers of the compact line at 6 significant digits (the detail file keeps every digit)."""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    if isinstance(v, float):
+        return float("%.*g" % (digits, v))
+    if isinstance(v, dict):
+        return {k: _num(x, digits) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_num(x, digits) for x in v]
+    return v
+
+
+def compact_line(d):
+    """The ONE line the driver parses, from the full record `d`: the contract's keys + `roofline` + `cpu_baseline` + a handful of scalars per
+    co-reported section.  Everything else (stage tables, unmatched-key dossiers, secondary rooflines, gpu_state, exchange details) is in
+    bench_detail.json / on stderr.  Never longer than LINE_LIMIT bytes."""
+    pick = lambda src, keys: {k: src[k] for k in keys if k in src} if isinstance(src, dict) else None
+    line = {k: d.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")}
+    cfg = d.get("config", {})
+    line["config"] = pick(cfg, ("workload", "global_batch", "keypoints_per_image", "images_per_launch", "parallelism", "keypoints"))
+    if isinstance(line["config"].get("workload"), str) and len(line["config"]["workload"]) > 330:
+        line["config"]["workload"] = line["config"]["workload"][:327] + "..."
+    if "roofline" in d:
+        line["roofline"] = pick(d["roofline"], ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic", "launch_ms", "flops_per_launch"))
+        if isinstance(line["roofline"].get("kernel"), str):
+            line["roofline"]["kernel"] = line["roofline"]["kernel"][:96]
+    cb = d.get("cpu_baseline")
+    if isinstance(cb, dict):
+        line["cpu_baseline"] = pick(cb, ("value", "unit", "cores", "kind"))
+        line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:150]
+        nt = cb.get("node_throughput") or {}
+        line["cpu_baseline"]["node_value"] = nt.get("value")
+        line["cpu_baseline"]["node_cores"] = nt.get("cores")
+    pc = d.get("parity_check")
+    if isinstance(pc, dict):
+        line["parity"] = pick(pc, ("pass", "images", "keypoints", "matched", "laf_rows_within_1e-3", "laf_max_px", "desc_max", "responses_equal", "unmatched_keys",
+                                   "unmatched_unexplained", "rows_outside_1e-3_beyond_referee", "rows_outside_1e-2", "golden"))
+    oc = d.get("other_configs")
+    other = {}
+    if isinstance(oc, dict):
+        other.update(pick(oc, ("config2_graph_ms", "config2_eager_ms", "config2_graph_identical_to_eager", "config2_launches", "config5_kp_s", "error")))
+        if isinstance(oc.get("config5_roofline"), dict):
+            other["config5_frac"] = oc["config5_roofline"].get("frac")
+        if isinstance(oc.get("config5_cpu_baseline"), dict):
+            other["config5_cpu_kp_s"] = oc["config5_cpu_baseline"].get("value")
+    for mode in SPLIT:
+        m = d.get("arith_" + mode)
+        if isinstance(m, dict):
+            short = mode.replace("fp32_", "")
+            other[short + "_value"] = m.get("value", m.get("error"))
+            if isinstance(m.get("roofline"), dict):
+                other[short + "_frac_of_16bit_peak"] = m["roofline"].get("frac")
+            if isinstance(m.get("parity_check"), dict):
+                other[short + "_parity_pass"] = m["parity_check"].get("pass")
+    if other:
+        line["other"] = other
+    for k in ("affnet_tflops", "orinet_tflops", "all_cnn_tflops"):
+        if k in d.get("roofline", {}):
+            line.setdefault("cnn", {})[k] = d["roofline"][k]
+    if "stage_ms_per_image" in d:
+        line["stage_ms_per_image"] = d["stage_ms_per_image"]
+    if "ms_per_image" in d:
+        line["ms_per_image"] = d["ms_per_image"]
+    if d.get("n_gpus", 1) > 1 or "exchange" in d:
+        ex = d.get("exchange") or {}
+        line["exchange"] = {"mode": ex.get("mode"), "bytes_per_step": ex.get("exchange_bytes_per_step"), "gather_ms": ex.get("gather_ms")}
+        pr = d.get("ms_per_step_per_rank") or {}
+        line["ms_per_step_per_rank"] = {"min": pr.get("min"), "max": pr.get("max")}
+        if isinstance(d.get("gather_check"), dict):
+            line["gather_check"] = pick(d["gather_check"], ("identical", "checked", "records", "mode", "error"))
+    for k in ("hip_graph", "cold_ms", "warm_ms_min", "dry_run", "records_in_global_order"):          # --config2 / --dry-run lines
+        if k in d:
+            line[k] = pick(d[k], ("warm_ms", "warm_ms_min", "identical_to_eager", "launches", "error")) if isinstance(d[k], dict) else d[k]
+    if isinstance(d.get("wall_s"), dict):
+        line["wall_s"] = d["wall_s"].get("total_since_process_start_s")
+    line["detail"] = DETAIL_FILE
+    line = _num(line)
+    text = json.dumps(line, separators=(",", ":"))
+    for drop in ("stage_ms_per_image", "cnn", "wall_s", "gather_check", "other", "parity"):          # cannot happen with today's fields; the limit holds regardless
+        if len(text) <= LINE_LIMIT:
+            break
+        line.pop(drop, None)
+        text = json.dumps(line, separators=(",", ":"))
+    assert len(text) <= LINE_LIMIT, "compact bench line is %d bytes" % len(text)
+    return text
+
+
+def emit(d):
+    """Full record -> bench_detail.json (next to bench.py, and gpurun_out/ when present) + stderr; compact line -> stdout, LAST."""
+    full = json.dumps(d)
+    for path in (os.path.join(ROOT, DETAIL_FILE), os.path.join(ROOT, "gpurun_out", DETAIL_FILE)):
+        try:
+            if os.path.isdir(os.path.dirname(path)):
+                with open(path, "w") as f:
+                    f.write(full + "\n")
+        except OSError as e:
+            sys.stderr.write("bench.py: could not write %s: %r\n" % (path, e))
+    sys.stderr.write("bench.py detail record (also in %s):\n%s\n" % (DETAIL_FILE, full))
+    sys.stderr.flush()
+    print(compact_line(d), flush=True)
+
+
 def free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -470,7 +577,7 @@ def config2_latency(args):
     out = config2_measure(det, Hn, host, dev, max(args.steps, 5) * 4, args.arith)
     out["cold_ms"] = cold * 1e3
     out["note"] = "cold = weight load + BN folding + packing + upload, context / workspace creation, HIP module load and the first call"
-    print(json.dumps(out), flush=True)
+    emit(out)
 
 
 def config2_measure(det, Hn, host, dev, n_lat, arith):
@@ -789,7 +896,7 @@ def run(args, world):
             times.append(e0.elapsed_time(e1))
         times.sort()
         rec_bytes = int(rec_local.size(1)) * 4
-        exchange = {"record_bytes": rec_bytes, "records_per_step": args.batch * world,
+        exchange = {"mode": "all_gather" if gather_dst is None else "gather_rank0", "record_bytes": rec_bytes, "records_per_step": args.batch * world,
                     "exchange_bytes_per_step": rec_bytes * args.batch * world * (world if gather_dst is None else 1),
                     "what": "all_gather: every rank receives every record" if gather_dst is None else "gather: rank 0 receives every record",
                     "gather_ms": times[len(times) // 2], "gather_ms_min": times[0],
@@ -966,7 +1073,7 @@ def run(args, world):
                         out["arith_" + mode]["parity_check"] = parity_check(kept, fetcher(res_m), tag=mode)
         wall["total_since_process_start_s"] = round(time.time() - T_START, 1)
         out["wall_s"] = wall
-        print(json.dumps(out), flush=True)
+        emit(out)
     if DIST:
         dist.destroy_process_group()
 
@@ -1260,11 +1367,15 @@ def dry_run(args, world, rank, dist, sharded, DIST, gather_dst, backend):
     if DIST:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if rank == 0:
-        print(json.dumps({"dry_run": True, "metric": "keypoints/sec (detect+AffNet+OriNet+HardNet) per image, %d kp @%dx%d" % (NKP, W, H),
-                          "value": None, "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": "weak",
-                          "config": {"global_batch": args.batch * world, "gather": "all_gather" if gather_dst is None else "gather to rank 0",
-                                     "backend": backend},
-                          "records_in_global_order": bool(flag.item() == 1.0)}), flush=True)
+        emit({"dry_run": True, "metric": "keypoints/sec (detect+AffNet+OriNet+HardNet) per image, %d kp @%dx%d" % (NKP, W, H),
+              "value": None, "unit": "keypoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
+              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (dry run: fake records, no kernels)",
+              "config": {"workload": "dry run of the N-rank bookkeeping", "global_batch": args.batch * world, "images_per_launch": args.chunk,
+                         "parallelism": "image-per-GPU x%d, %s over %s" % (world, "all_gather" if gather_dst is None else "gather to rank 0", backend)},
+              "exchange": {"mode": "all_gather" if gather_dst is None else "gather_rank0", "exchange_bytes_per_step": int(got.numel()) * 4 * (world if gather_dst is None else 1)
+                           if got is not None else None, "gather_ms": None},
+              "ms_per_step_per_rank": {"min": None, "max": None},
+              "records_in_global_order": bool(flag.item() == 1.0)})
     if DIST:
         dist.destroy_process_group()
     if flag.item() != 1.0:

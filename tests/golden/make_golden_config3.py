@@ -1,8 +1,10 @@
-"""Golden vector AT THE METRIC'S CONFIGURATION (BASELINE.json configs[2]): the UNMODIFIED reference on one of the benchmark's own
-synthetic 1024x768 images, 2000 keypoints, full path detect + AffNet + OriNet + HardNet (seed 31 = the last image of bench.py's
-first 32-image launch).  Run in the authoring container only:
+"""Golden vectors AT THE METRIC'S CONFIGURATION (BASELINE.json configs[2]): the UNMODIFIED reference on the benchmark's own
+synthetic 1024x768 images, 2000 keypoints, full path detect + AffNet + OriNet + HardNet.  Seed 31 = the last image of bench.py's
+first 32-image launch (round 3); seeds 0, 1, 2, 63 (round 6) = the images bench.py's parity leg reads back from its last timed step
+(first / second / third image of the first launch, last image of the second): host-independent expected values, so the driver-run
+line does not depend on how the GPU box's CPU rounds.  Run in the authoring container only:
 
-    python tests/golden/make_golden_config3.py
+    python tests/golden/make_golden_config3.py [seed ...]
 
 Rows are in the reference's output order (torch.topk order of the responses); tests match rows through the bit pattern of the
 response (responses are bit-identical between the reference and the HIP path and practically unique)."""
@@ -18,7 +20,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import affnet_oracle as orc  # noqa: E402  (synthetic input + synthetic HardNet weights only)
 import ref_harness as rh  # noqa: E402
 
-SEED = 31
+SEEDS = (31, 0, 1, 2, 63)
 
 
 def main():
@@ -26,13 +28,14 @@ def main():
     A = ns.architectures.AffNetFast(PS=32); A.load_state_dict(rh.load_state_dict("AffNet.pth")); A.eval()
     O = ns.architectures.OriNetFast(PS=32); O.load_state_dict(rh.load_state_dict("OriNet.pth")); O.eval()
     Hn = ns.HardNet.HardNet(); Hn.load_state_dict(orc.synthetic_hardnet_state(0)); Hn.eval()
-    x = orc.synthetic_image(768, 1024, SEED)
-    det = ns.SparseImgRepresenter.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=2000, border=5, num_Baum_iters=1, AffNet=A, OriNet=O)
-    with torch.no_grad(), rh.quiet():
-        L, r = det(x, do_ori=True)
-        D = Hn(det.extract_patches_from_pyr(L, PS=32))
-    np.savez_compressed(os.path.join(HERE, "synth_768x1024_s%d_n2000.npz" % SEED), seed=SEED, LAFs=L.numpy(), resp=r.numpy(), desc=D.numpy())
-    print("written:", L.shape, D.shape)
+    for seed in ([int(a) for a in sys.argv[1:]] or SEEDS):
+        x = orc.synthetic_image(768, 1024, seed)
+        det = ns.SparseImgRepresenter.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=2000, border=5, num_Baum_iters=1, AffNet=A, OriNet=O)
+        with torch.no_grad(), rh.quiet():
+            L, r = det(x, do_ori=True)
+            D = Hn(det.extract_patches_from_pyr(L, PS=32))
+        np.savez_compressed(os.path.join(HERE, "synth_768x1024_s%d_n2000.npz" % seed), seed=seed, LAFs=L.numpy(), resp=r.numpy(), desc=D.numpy())
+        print("written: seed", seed, L.shape, D.shape)
 
 
 if __name__ == "__main__":

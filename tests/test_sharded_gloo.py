@@ -80,7 +80,20 @@ def _bench(*argv, env=None):
     e.update(env or {})
     p = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + list(argv), env=e, capture_output=True, text=True, timeout=300)
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    _bench.last_stdout = p.stdout
     return p.returncode, [json.loads(l) for l in lines], p.stderr
+
+
+def _assert_compact(stdout):
+    """the LAST stdout line is the one JSON line, under 4 KB, with the contract's keys; details go to the side file."""
+    import json
+    last = stdout.rstrip("\n").splitlines()[-1]
+    assert len(last) < 4096, len(last)
+    d = json.loads(last)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "detail"):
+        assert k in d, k
+    assert "workload" in d["config"] and "model" not in d["config"]
+    return d
 
 
 @pytest.mark.parametrize("gather", ["all", "rank0"])
@@ -91,7 +104,10 @@ def test_bench_self_spawns_n_ranks(gather):
     assert rc == 0, err
     assert len(out) == 1, out
     assert out[0]["n_gpus"] == 2 and out[0]["config"]["global_batch"] == 6 and out[0]["records_in_global_order"] is True
-    assert out[0]["config"]["gather"] == ("all_gather" if gather == "all" else "gather to rank 0")
+    assert out[0]["exchange"]["mode"] == ("all_gather" if gather == "all" else "gather_rank0")
+    _assert_compact(_bench.last_stdout)
+    assert out[0]["exchange"]["bytes_per_step"] == 6 * (4 + 4 * 5 * (6 + 1 + 128)) * (2 if gather == "all" else 1)
+    assert set(out[0]["ms_per_step_per_rank"]) == {"min", "max"}
 
 
 def test_bench_eight_ranks_config5_dry_run():
@@ -102,6 +118,41 @@ def test_bench_eight_ranks_config5_dry_run():
     assert len(out) == 1, out
     assert out[0]["n_gpus"] == 8 and out[0]["config"]["global_batch"] == 64 and out[0]["records_in_global_order"] is True
     assert "8000 kp @3840x2160" in out[0]["metric"]
+    _assert_compact(_bench.last_stdout)
+
+
+def test_compact_line_from_the_recorded_round5_record():
+    """The record round 5's bench printed as ONE 31 KB line (profiles/archive/r05_s1_bench_default.json: the driver's `parsed` was null) through
+    today's formatter: under 4 KB, valid JSON, carrying `roofline`, `cpu_baseline`, the parity scalars and the co-reported configurations;
+    and a synthetic record with every optional section blown up still fits."""
+    import glob
+    import importlib.util
+    import json
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    rec = sorted(glob.glob(os.path.join(root, "profiles", "**", "r05_s1_bench_default.json"), recursive=True))
+    assert rec, "the recorded round-5 line is tracked under profiles/"
+    full = json.loads(open(rec[0]).read().strip().splitlines()[-1])
+    assert len(json.dumps(full)) > 20000
+    text = bench.compact_line(full)
+    assert len(text) < 4096 and "\n" not in text
+    d = json.loads(text)
+    assert d["value"] == pytest.approx(full["value"], rel=1e-5) and d["ms_per_step"] == pytest.approx(full["ms_per_step"], rel=1e-5)
+    assert d["roofline"]["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-5) and d["roofline"]["bound"] == "mfma" and "traffic" in d["roofline"]
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == full["cpu_baseline"]["cores"] and d["cpu_baseline"]["node_value"] is not None
+    assert d["parity"]["pass"] is True and d["parity"]["unmatched_unexplained"] == 0
+    assert d["other"]["config2_graph_ms"] == pytest.approx(full["other_configs"]["config2_graph_ms"], rel=1e-5)
+    assert d["other"]["split2h_value"] > d["other"]["split3_value"] > d["value"]
+    # worst case: long strings everywhere, N = 8 sections present
+    fat = dict(full, exchange={"mode": "gather_rank0", "exchange_bytes_per_step": 1 << 29, "gather_ms": 1.25, "how": "x" * 5000},
+               ms_per_step_per_rank={"min": 1.0, "max": 2.0, "all": [1.0] * 8}, gather_check={"identical": True, "checked": 16, "records": 512, "mode": "sample", "what": "y" * 5000})
+    fat["config"] = dict(full["config"], workload="w" * 5000, parallelism="p" * 100)
+    fat["cpu_baseline"] = dict(full["cpu_baseline"], sample="s" * 5000)
+    fat["roofline"] = dict(full["roofline"], kernel="k" * 5000)
+    t2 = bench.compact_line(fat)
+    assert len(t2) < 4096 and json.loads(t2)["exchange"]["bytes_per_step"] == 1 << 29
 
 
 def test_gather_to_rank_in_a_subgroup_uses_global_ranks():
