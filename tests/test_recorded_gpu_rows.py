@@ -53,7 +53,8 @@ def test_recorded_mi355x_rows_match_the_reference(path, weights, golden_dir):
     dl = np.abs(g["LAFs"][gi] - Lw.numpy()[wi]).reshape(len(gi), -1).max(axis=1)
     assert (dl < 1e-3).mean() >= 0.995
     assert acc["unmatched_unexplained"] == 0, [r for r in acc["unmatched_rows"] if r["why"] in ("UNEXPLAINED", "NOT A DETECTOR CANDIDATE")]
-    assert acc["rows_outside_1e-3_unexplained"] == 0 and acc["rows_outside_5e-3_unexplained"] == 0, acc["rows_outside_1e-3_vs_fp64"]
+    assert acc["rows_outside_1e-3_beyond_referee"] <= acc["beyond_budget"] and acc["rows_outside_1e-2"] == 0 and acc["rows_outside_5e-3_unexplained"] == 0, acc["rows_outside_1e-3_vs_fp64"]
+    print("rows outside 1e-3 px vs the float64 referee:", [(r["gpu_vs_cpu_px"], r["gpu_vs_fp64_px"], r["cpu_vs_fp64_px"], r["beyond_referee"]) for r in acc["rows_outside_1e-3_vs_fp64"]])
     if Dw is not None:
         dd = np.abs(g["desc"][gi] - Dw.numpy()[wi]).max(axis=1)
         assert (dd[dl < 1e-3] < 1e-3).all() and np.percentile(dd, 99.5) < 1e-3

@@ -66,7 +66,7 @@ def test_accounting_explains_a_second_fp32_class_evaluation(graf_run):
     ex, ref, dec, ids, L = graf_run
     rec = rf.parity_account(ref, ids, L, 500, full=True)
     assert rec["unmatched_unexplained"] == 0, rec["unmatched_rows"]
-    assert rec["rows_worse_than_cpu_vs_fp64"] == 0 and rec["rows_outside_1e-3_unexplained"] == 0
+    assert rec["rows_worse_than_cpu_vs_fp64"] == 0 and rec["rows_outside_1e-3_beyond_referee"] == 0 and rec["rows_outside_1e-2"] == 0
     # graf img1 holds near-isotropic AffNet outputs whose fp32 discriminant tr^2 - 4 det has the sign of its rounding error: the two sides
     # legitimately differ there, and every such key is traced to that decision or to the shifted cut
     assert rec["unmatched_keys"] > 0 and rec["unmatched_borderline_flips"] > 0
@@ -95,8 +95,16 @@ def test_accounting_flags_a_dropped_keypoint_and_a_wrong_row(graf_run):
     L3 = L.copy()
     L3[both[3], 0, 0] += 6e-3
     rec = rf.parity_account(ref, ids, L3, 500)
-    assert rec["rows_outside_1e-3"] >= 1 and rec["rows_worse_than_cpu_vs_fp64"] >= 1 and rec["rows_outside_1e-3_unexplained"] >= 1
+    assert rec["rows_outside_1e-3"] >= 1 and rec["rows_worse_than_cpu_vs_fp64"] >= 1 and rec["rows_outside_1e-3_beyond_referee"] >= 1 and rec["rows_outside_1e-2"] == 0
     assert rec["rows_outside_5e-3_unexplained"] >= 1            # 5e-3 px off while the reference's own row is within 5e-3 px of float64: beyond the hard ceiling
+    # (2b) the unconditional ceiling: 1.2e-2 px off counts whatever the conditioning; a row 3e-3 px off whose reference row is fine fails both clauses
+    L3 = L.copy()
+    L3[both[3], 0, 0] += 1.2e-2
+    L3[both[4], 1, 1] += 3e-3
+    rec = rf.parity_account(ref, ids, L3, 500)
+    assert rec["rows_outside_1e-2"] == 1 and rec["rows_outside_1e-3_beyond_referee"] == 2 and rec["beyond_budget"] == 1
+    assert rf.beyond_budget(2000) == 1 and rf.beyond_budget(4000) == 1 and rf.beyond_budget(4001) == 2 and rf.beyond_budget(8000) == 2
+    assert not hasattr(rf, "REF_QUANTILE")                  # round 5's fitted quantile clause is gone
     # (3) a row that is not a detector candidate at all
     ids4 = ids.copy()
     ids4[both[5]] = [0, 0, 12345678]
