@@ -440,6 +440,79 @@ def test_threshold_mode_hesaffnet_as_shipped(amd, nets, weights, golden_dir):
     np.testing.assert_allclose(ell[a], ge[b], rtol=5e-3, atol=1e-6)
 
 
+TH_CASES = [("graf_img1", "graf_img1.png"), ("cat", "hesaffnet_cat.png"), ("fox1", "hesaffnet_fox1.png")]
+_TH_ORACLE = {}
+
+
+@pytest.mark.parametrize("arith", ARITH)
+@pytest.mark.parametrize("case", TH_CASES, ids=[c[0] for c in TH_CASES])
+def test_threshold_mode_hesaffnet_as_shipped_full_size(amd, nets, weights, golden_dir, case, arith):
+    """hesaffnet.py EXACTLY as the reference ships it (examples/hesaffnet/hesaffnet.py:24-60): th = -1 => num = -1
+    (SparseImgRepresenter.py:33-37) - no feature budget, AffNetFast slot, no orientation - on the reference's own input images at their own
+    sizes (test-graf/img1.png 800x640: 7075 rows; img/cat.png, img/fox1.png).  Against the oracle on this host WITH the accounting (there is
+    no top-N cut in this mode, so every key only one side returns must be a borderline discriminant / eigen-ratio / corner decision of the
+    shape filter: `unmatched_unexplained == 0`), and against the unmodified reference's golden output (tests/golden/make_golden_thmode.py):
+    the same detector maxima, rows in (octave, level, pixel) order, matched rows within 1e-3 px, the rows of the Oxford file."""
+    tag, fname = case
+    g = np.load(os.path.join(golden_dir, "thmode_%s.npz" % tag))
+    x = load_gray(os.path.join(golden_dir, fname))
+    assert tuple(g["hw"]) == (x.size(2), x.size(3))
+    det = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=2000, border=5, num_Baum_iters=1, th=-1, AffNet=nets[0], arith=arith).to(DEV)
+    L, r = det(x.to(DEV))
+    ids = det.last_ids.cpu().numpy()
+    L, r = L.cpu().numpy(), r.cpu().numpy()
+    counts = det._ctx.read_counts()
+    if tag not in _TH_ORACLE:
+        ex = orc.OracleExtractor(mrSize=5.192, num_features=2000, border=5, num_Baum_iters=1, th=-1, affnet_sd=weights["AffNet"])
+        Lw, rw = ex(x)
+        _TH_ORACLE[tag] = (ex, Lw.numpy(), rw.numpy(), rf.Referee(ex, x.size(3), x.size(2)))
+    ex, Lw, rw, ref = _TH_ORACLE[tag]
+    assert np.array_equal(rw, g["resp"]) or abs(len(rw) - len(g["resp"])) <= 0.005 * len(rw)      # the live oracle may flip borderline rows against the golden host
+    assert counts[0] == ex.detected["resp"].numel(), "the detector must find exactly the oracle's 3-D maxima (%d vs %d)" % (counts[0], ex.detected["resp"].numel())
+    kg = _keys(ids)
+    assert np.all(np.diff(kg) > 0), "threshold mode returns rows in (octave, level, pixel) order (HandCraftedModules.py:283-291, no top-k)"
+    acc = rf.parity_account(ref, ids, L, -1)
+    gi, wi = _match(ids, ex.keys.numpy())
+    dl = np.abs(L[gi] - Lw[wi]).reshape(len(gi), -1).max(axis=1)
+    # vs the reference's golden output: rows matched through the response bit pattern (+ centre for tied responses)
+    g2, w2 = match_rows(r, L, g["resp"], g["LAFs"])
+    eg = np.abs(L[g2] - g["LAFs"][w2]).reshape(len(g2), -1).max(axis=1)
+    ell = amd.LAF.LAFs2ell(L)
+    rel = np.abs(ell[g2] - g["ells"][w2]) / np.maximum(np.abs(g["ells"][w2]), 1e-6)
+    sfx = "" if arith == "fp32" else " [arith %s]" % arith
+    record_parity("threshold mode (hesaffnet.py as shipped, th = -1) %s %dx%d%s" % (tag, x.size(3), x.size(2), sfx), detected=int(counts[0]), rows=int(L.shape[0]),
+                  oracle_rows=int(Lw.shape[0]), golden_rows=int(g["LAFs"].shape[0]), matched=int(len(gi)), laf_max_px=float(dl.max()),
+                  laf_rows_outside_1e_3=int((dl >= 1e-3).sum()), responses_equal=bool(np.array_equal(r[gi], rw[wi])),
+                  unmatched_keys=acc["unmatched_keys"], unmatched_borderline_flips=acc["unmatched_borderline_flips"], unmatched_unexplained=acc["unmatched_unexplained"],
+                  unmatched_rows=acc["unmatched_rows"], rows_outside_1e_3_beyond_referee=acc["rows_outside_1e-3_beyond_referee"],
+                  golden_matched=int(len(g2)), golden_laf_max_px=float(eg.max()), golden_rows_outside_1e_3=int((eg >= 1e-3).sum()),
+                  golden_ellipse_centre_max_px=float(np.abs(ell[g2, :2] - g["ells"][w2, :2]).max()), golden_ellipse_max_rel=float(rel[:, 2:].max()))
+    print("th mode %s%s: detected %d, rows %d (oracle %d, golden %d), unmatched keys %d (flips %d, unexplained %d), worst row %.3g px; vs golden matched %d, worst %.3g px, ellipse rel %.3g"
+          % (tag, sfx, counts[0], L.shape[0], Lw.shape[0], g["LAFs"].shape[0], acc["unmatched_keys"], acc["unmatched_borderline_flips"], acc["unmatched_unexplained"], dl.max(),
+             len(g2), eg.max(), rel[:, 2:].max()))
+    assert acc["unmatched_unexplained"] == 0, [q for q in acc["unmatched_rows"] if not str(q["why"]).startswith("borderline")]
+    assert all(str(q["why"]).startswith("borderline") for q in acc["unmatched_rows"]), "no top-N cut in this mode: every differing key must be a borderline decision"
+    assert len(gi) >= 0.995 * Lw.shape[0] and np.array_equal(r[gi], rw[wi])
+    assert (dl < 1e-3).all() or (acc["rows_outside_1e-3_beyond_referee"] <= acc["beyond_budget"] and acc["rows_outside_1e-2"] == 0), acc["rows_outside_1e-3_vs_fp64"]
+    assert len(g2) >= 0.995 * g["LAFs"].shape[0]
+    assert (eg < 1e-3).all(), "%d rows outside 1e-3 px vs the reference's golden output (worst %.3g)" % ((eg >= 1e-3).sum(), eg.max())
+    assert np.abs(ell[g2, :2] - g["ells"][w2, :2]).max() < 1e-3 and rel[:, 2:].max() < 1e-3, "Oxford ellipse rows differ from the reference's file"
+
+
+def test_threshold_mode_capacity_is_an_error_not_a_truncation(amd, nets, golden_dir):
+    """th = -1 keeps every maximum: the row capacity (`max_keep`, default 16384 - graf / cat / fox1 need 7885 / 8049 / 9888 detector rows) must
+    fail loudly when an image exceeds it, never return the first max_keep rows; raising it on the live object makes the same call succeed."""
+    x = load_gray(os.path.join(golden_dir, "graf_img1.png")).to(DEV)
+    det = amd.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=2000, border=5, num_Baum_iters=1, th=-1, AffNet=nets[0]).to(DEV)
+    det.max_keep = 4096
+    with pytest.raises(amd._lib.AffnetHipError) as e:
+        det(x)
+    assert "overflow" in str(e.value).lower() or "capacity" in str(e.value).lower(), str(e.value)
+    det.max_keep = 16384
+    L, r = det(x)
+    assert L.shape[0] > 7000
+
+
 def test_foreign_slots_staged_path_equals_fused(amd, nets, weights):
     """Any callable with the reference's slot signature works: the stage entry points give the same rows."""
     A, O, H = nets
@@ -1139,6 +1212,23 @@ def test_cli_entry_points(amd, golden_dir, tmp_path):
                   centre_max_px=float(np.abs(ell[a, :2] - want[b, :2]).max()), ellipse_max_rel=float(rel[:, 2:].max()))
     assert len(pairs) >= 0.995 * 500, "only %d of 500 golden rows found in the CLI output" % len(pairs)
     assert np.abs(ell[a, :2] - want[b, :2]).max() < 1e-3 and rel[:, 2:].max() < 1e-3, "ellipse values of the CLI output differ from the reference's"
+    # the SHIPPED mode (hesaffnet.py:26 th = -1; no HESAFFNET_TH in the environment): every maximum kept, nfeats ignored - the file against the
+    # rows the unmodified reference writes for this image (tests/golden/thmode_graf_img1.npz "ells"), matched by centre
+    out3 = tmp_path / "img1_th.txt"
+    env3 = {k: v for k, v in os.environ.items() if k != "HESAFFNET_TH"}
+    subprocess.check_call([sys.executable, os.path.join(root, "examples/hesaffnet/hesaffnet.py"), os.path.join(golden_dir, "graf_img1.png"), str(out3), "2000"], env=env3)
+    lines = open(out3).read().split("\n")
+    gt = np.load(os.path.join(golden_dir, "thmode_graf_img1.npz"))["ells"]
+    ell3 = np.loadtxt(out3, skiprows=2)
+    assert lines[0].strip() == "1.0" and int(lines[1]) == ell3.shape[0] and abs(ell3.shape[0] - gt.shape[0]) <= 0.005 * gt.shape[0], (lines[1], gt.shape)
+    pos = {(round(float(e[0]), 2), round(float(e[1]), 2), round(float(e[2]), 6)): i for i, e in enumerate(gt)}
+    pairs = [(i, pos[k]) for i, k in enumerate((round(float(e[0]), 2), round(float(e[1]), 2), round(float(e[2]), 6)) for e in ell3) if k in pos]
+    a, b = np.array([q[0] for q in pairs]), np.array([q[1] for q in pairs])
+    rel3 = np.abs(ell3[a] - gt[b]) / np.maximum(np.abs(gt[b]), 1e-6)
+    record_parity("hesaffnet.py CLI output AS SHIPPED (th = -1) vs the reference's golden file rows (graf img1)", rows=int(ell3.shape[0]), golden_rows=int(gt.shape[0]),
+                  matched=len(pairs), centre_max_px=float(np.abs(ell3[a, :2] - gt[b, :2]).max()), ellipse_max_rel=float(rel3[:, 2:].max()))
+    assert len(pairs) >= 0.99 * gt.shape[0], "only %d of %d golden rows found in the CLI output" % (len(pairs), gt.shape[0])
+    assert np.abs(ell3[a, :2] - gt[b, :2]).max() < 1e-3 and rel3[:, 2:].max() < 1e-3
     g = np.load(os.path.join(golden_dir, "just_shape_column.npz"))
     col = tmp_path / "column.png"
     Image.fromarray(g["column"]).save(col)
