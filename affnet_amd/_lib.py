@@ -153,6 +153,9 @@ class AffnetEmptyError(AffnetHipError):
 
 def _load():
     if not os.path.isfile(LIB_PATH):
+        if os.path.basename(LIB_PATH) == os.path.basename(PROBES_LIB_PATH):          # a tuning tool asked for the probe build
+            raise ImportError("affnet_amd: %s is missing - the tools under tools/ need the probe build of the library: "
+                              "AFFNET_PROBES=1 bash affnet_amd/csrc/build.sh" % LIB_PATH)
         raise ImportError(
             "affnet_amd: %s is missing - the HIP extension is the only implementation of this path "
             "(no CPU fallback). Build it: bash affnet_amd/csrc/build.sh" % LIB_PATH)

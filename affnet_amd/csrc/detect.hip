@@ -46,6 +46,7 @@ struct HessOct {           // one octave of the launch
     RawMax* raw;
     int32_t* raw_cnt;
     int h, w, raw_cap;
+    int centroid_order;        // summation order of the 27-tap centroid: 1 = (ky, kx, level) (oneDNN direct convolution), 0 = (level, ky, kx) (ATen im2col + sgemm); host decides
     int tiles_x, tile_begin;   // tiles per row; first flat tile index (blockIdx.x) of this octave
     float sigma[AFFNET_MAX_LEVELS];
     float sigma4[AFFNET_MAX_LEVELS];
@@ -84,7 +85,7 @@ __device__ __forceinline__ float hessian_at(const float* __restrict__ X, int ty,
 template <int NL>
 struct HessTile {
     const float* levels; RawMax* raw; int32_t* raw_cnt;
-    int h, w, raw_cap, x0, y0;
+    int h, w, raw_cap, x0, y0, centroid_order;
     float sigma[NL], sigma4[NL];
 };
 
@@ -92,7 +93,7 @@ template <int NL>
 __device__ __forceinline__ void hess_tile_setup(const HessParams& hp, int flat_tile, HessTile<NL>& t) {
     int oi = 0;
     while (oi + 1 < hp.n_oct && flat_tile >= hp.oct[oi + 1].tile_begin) ++oi;      // uniform: scalar loads from the kernel arguments
-    t.h = hp.oct[oi].h; t.w = hp.oct[oi].w; t.raw_cap = hp.oct[oi].raw_cap;
+    t.h = hp.oct[oi].h; t.w = hp.oct[oi].w; t.raw_cap = hp.oct[oi].raw_cap; t.centroid_order = hp.oct[oi].centroid_order;
 #pragma unroll
     for (int l = 0; l < NL; ++l) { t.sigma[l] = hp.oct[oi].sigma[l]; t.sigma4[l] = hp.oct[oi].sigma4[l]; }
     const int tile = flat_tile - hp.oct[oi].tile_begin, tiles_x = hp.oct[oi].tiles_x;
@@ -302,7 +303,10 @@ __global__ __launch_bounds__(256, (NL <= 5 ? 3 : 1)) void hessian_nms_kernel(Hes
             // 3 x 3 x 3 weights on the reference's CPU.  Their fp32 summation order depends on the map size - ATen's use_mkldnn() sends a
             // batch-1 3 x 3 convolution to oneDNN only when the input has more than 20480 elements (Convolution.cpp: "for some case, native is
             // faster"): the native path (im2col + sgemm, K = 27) accumulates in (level, ky, kx) order, oneDNN's direct convolution for 3 input
-            // channels in (ky, kx, level) order, both as fmaf chains (verified bit for bit on 300 x 500 / 40 x 50 maps, tools/probes/cpu_conv_order.py).
+            // channels in (ky, kx, level) order, both as fmaf chains (verified bit for bit on 300 x 500 / 40 x 50 maps ON THE AUTHORING HOST = the host of
+            // the golden vectors, tools/probes/cpu_conv_order.py; the small-map branch is host-specific: MKL's sgemm on the GPU box's EPYC sums
+            // differently, profiles/archive/r05_s1_cpu_conv_order_gpubox.txt).  The predicate is evaluated on the host in 64 bits (detect_candidates:
+            // HessOct::centroid_order; AFFNET_CENTROID_ORDER=onednn|native pins one order for a reference torch build that dispatches differently).
             // A one-ulp difference of a sub-pixel centre moves the sampled patch enough to shift a sensitive frame by 1e-3 px (round 5: the
             // float64 referee traced every LAF row outside 1e-3 px to this), so both orders are reproduced.
             float ns = 0.f, ny = 0.f, nx = 0.f, den = 0.f;
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(256, (NL <= 5 ? 3 : 1)) void hessian_nms_kernel(Hes
                 nx = fmaf(r, ox, nx);                                                       \
                 den = fmaf(r, 1.0f, den);                                                   \
             }
-            if (3 * h * w > 20480) {                   // oneDNN: (ky, kx, level)
+            if (p.centroid_order) {                    // oneDNN: (ky, kx, level)
 #pragma unroll
                 for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
@@ -1067,6 +1071,8 @@ static int detect_candidates(affnet_ctx* ctx, const float* d_responses, AffZeroS
     hp.levels_stride = ctx->pyr_stride; hp.raw_stride = ctx->raw_stride;
     hp.precomputed = d_responses ? 1 : 0;
     int n_tiles = 0;
+    int centroid_pin = -1;                       // -1 = follow ATen's dispatch rule per octave (the default: what the golden vectors were produced with)
+    if (const char* e = getenv("AFFNET_CENTROID_ORDER")) { if (!strcmp(e, "onednn")) centroid_pin = 1; else if (!strcmp(e, "native")) centroid_pin = 0; }
     for (int o = 0; o < c.n_octaves; ++o) {
         const OctaveGeom& g = ctx->oct[o];
         HessOct& ho = hp.oct[o];
@@ -1074,6 +1080,7 @@ static int detect_candidates(affnet_ctx* ctx, const float* d_responses, AffZeroS
         ho.h = g.h; ho.w = g.w;
         for (int l = 0; l < NLv; ++l) { ho.sigma[l] = c.level_sigma[o][l]; ho.sigma4[l] = c.level_sigma4[o][l]; }
         ho.raw = ctx->raw + g.raw_off; ho.raw_cap = g.raw_cap;
+        ho.centroid_order = centroid_pin >= 0 ? centroid_pin : (3LL * (long long)g.h * (long long)g.w > 20480LL ? 1 : 0);     // ATen use_mkldnn(): batch-1 3 x 3 conv goes to oneDNN above 20480 input elements
         ho.raw_cnt = ctx->cnt + CNT_RAW0 + o;
         ho.tiles_x = aff_cdiv(g.w, HT_X); ho.tile_begin = n_tiles;
         n_tiles += ho.tiles_x * aff_cdiv(g.h, HT_Y);
