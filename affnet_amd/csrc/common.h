@@ -59,8 +59,6 @@ struct OctaveGeom {
     int32_t raw_cap;
 };
 
-#define AFF_SYNC_WORDS 16                 // uint32 words of grid-barrier state per image (64 B: one cache line each)
-
 struct affnet_ctx {
     int device = 0;
     affnet_config cfg;
@@ -73,7 +71,7 @@ struct affnet_ctx {
     std::string err;
     OctaveGeom oct[AFFNET_MAX_OCTAVES];
     // workspace layout (byte offsets from the workspace base)
-    size_t off_pyr = 0, off_map = 0, off_raw = 0, off_cnt = 0, off_hist = 0, off_cand = 0, off_sel = 0, off_stage = 0, off_sync = 0;
+    size_t off_pyr = 0, off_map = 0, off_raw = 0, off_cnt = 0, off_hist = 0, off_cand = 0, off_sel = 0, off_stage = 0;
     // OnePassSIR extras (cfg.onepass != 0): dense affine-shape maps (4, h_o, w_o) per octave, the dense net's scratch, a second
     // candidate list and the per-(octave, level) top-k table
     size_t off_affmap = 0, off_dense = 0, off_cand2 = 0, off_lvltab = 0;
@@ -92,9 +90,6 @@ struct affnet_ctx {
     uint8_t* omap = nullptr;
     RawMax* raw = nullptr;
     int32_t* cnt = nullptr;
-    unsigned char* chain_tab = nullptr;  // step table of the small-octave pyramid chain (1 KB, written at bind time); chain_from = first octave of the chain (0: none)
-    int chain_from = 0, chain_grid = 0, chain_steps = 0;
-    uint32_t* sync = nullptr;            // B x AFF_SYNC_WORDS: grid-barrier words of the small-octave pyramid chain (pyramid.hip): [0] arrivals, [1] finished, [2] sticky time-out flag
     uint32_t* sel_hist = nullptr;        // B x SEL_HIST_BINS: histogram of the top 11 key bits of the candidate responses
     float* cand_resp = nullptr; float* cand_syx = nullptr; int32_t* cand_ids = nullptr;
     float* sel_resp = nullptr; float* sel_syx = nullptr; int32_t* sel_ids = nullptr;
@@ -185,7 +180,6 @@ struct AffZeroSegs {
     }
 };
 int aff_zero_multi_async(affnet_ctx* ctx, const AffZeroSegs& z, hipStream_t st);
-int aff_pyramid_chain_prepare(affnet_ctx* ctx);          // pyramid.hip: step table + barrier words of the small-octave chain (bind time)
 int aff_copy_async(affnet_ctx* ctx, void* dst, const void* src, size_t bytes, hipStream_t st);
 // rows x width_bytes, row r at dst + r * dpitch / src + r * spitch (all multiples of 4 bytes)
 int aff_copy2d_async(affnet_ctx* ctx, void* dst, size_t dpitch, const void* src, size_t spitch, size_t width_bytes, size_t rows, hipStream_t st);

@@ -173,7 +173,6 @@ extern "C" int affnet_ctx_create(affnet_ctx** out, int device, const affnet_conf
     ctx->off_raw = off; off += aff_align(B * raw * sizeof(RawMax));
     ctx->off_cnt = off; off += aff_align(B * CNT_TOTAL * sizeof(int32_t));
     ctx->off_hist = off; off += aff_align(B * SEL_HIST_BINS * sizeof(uint32_t));   // top-digit histogram of the global top-k (detect.hip)
-    ctx->off_sync = off; off += aff_align(B * AFF_SYNC_WORDS * sizeof(uint32_t)) + 4096;  // grid-barrier words + step / tap table (4 KB) of the small-octave pyramid chain (pyramid.hip)
     ctx->off_cand = off; off += aff_align(B * ctx->cand_cap * 7 * sizeof(float));   // resp + syx[3] + ids[3]
     ctx->off_sel = off; off += aff_align(B * (size_t)ctx->cap_pre * 7 * sizeof(float));
     ctx->off_stage = off;
@@ -280,13 +279,6 @@ extern "C" int affnet_bind_workspace(affnet_ctx* ctx, void* d_workspace, size_t 
     ctx->cnt = (int32_t*)(b + ctx->off_cnt);
     ctx->sel_hist = (uint32_t*)(b + ctx->off_hist);
     const size_t B = (size_t)ctx->B;
-    ctx->sync = (uint32_t*)(b + ctx->off_sync);
-    ctx->chain_tab = (unsigned char*)(b + ctx->off_sync + aff_align(B * AFF_SYNC_WORDS * sizeof(uint32_t)));
-    {   // the chain kernel's barrier words start at zero and are reset by the kernel's last workgroup; its step table is static (pyramid.hip).
-        // A host without a GPU (CPU-side layout tests) has nothing to write: the chain stays off
-        AffDeviceGuard g(ctx);
-        (void)aff_pyramid_chain_prepare(ctx);
-    }
     float* cand = (float*)(b + ctx->off_cand);
     const size_t CC = B * ctx->cand_cap;
     ctx->cand_resp = cand; ctx->cand_syx = cand + CC; ctx->cand_ids = (int32_t*)(cand + 4 * CC);

@@ -62,7 +62,6 @@ struct HessParams {
     float th;
     int border;            // int(mrSize)
     int32_t* overflow;
-    const uint32_t* chain_sync;   // grid-barrier words of the pyramid's small-octave chain (pyramid.hip); word 2 != 0: a barrier timed out, the levels are not trustworthy
     // batch (blockIdx.z = image): per-image strides of the pyramid (floats), the raw lists (entries), the counters
     size_t levels_stride, raw_stride;
     int precomputed;       // != 0: `levels` holds RESPONSE maps of a custom RespNet slot (same layout); only clamp(r - th, 0) applies
@@ -156,7 +155,6 @@ __global__ __launch_bounds__(256, (NL <= 5 ? 3 : 1)) void hessian_nms_kernel(Hes
     const int first = blockIdx.x * hp.tiles_per_wg;
     const int last = min(first + hp.tiles_per_wg, hp.n_tiles);
     int32_t* const overflow = hp.overflow + blockIdx.z * CNT_TOTAL;
-    if (blockIdx.x == 0 && threadIdx.x == 0 && hp.chain_sync && hp.chain_sync[blockIdx.z * AFF_SYNC_WORDS + 2]) atomicOr(overflow, 16);      // fails the call (affnet_read_counts)
     float tmp[NL][HESS_NLD];
     if (!hp.precomputed) {
         HessTile<NL> nxt;
@@ -1070,7 +1068,6 @@ static int detect_candidates(affnet_ctx* ctx, const float* d_responses, AffZeroS
     hp.th = c.threshold;
     hp.border = (int)c.mr_size;
     hp.overflow = ctx->cnt + CNT_OVERFLOW;
-    hp.chain_sync = d_responses ? nullptr : ctx->sync;
     hp.levels_stride = ctx->pyr_stride; hp.raw_stride = ctx->raw_stride;
     hp.precomputed = d_responses ? 1 : 0;
     int n_tiles = 0;

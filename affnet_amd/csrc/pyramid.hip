@@ -42,11 +42,9 @@ struct BlurTile {
 };
 
 // One output tile (tile coordinates bx, by) of one blur; `tile` = BlurTile<K, BT_R>::FLOATS floats of LDS.
-struct TapsPtr { const float* __restrict__ w; };      // taps in (read-only) device memory: uniform address -> scalar loads (the chain kernel)
-
-template <int K, int BT_R, typename TAPS = Taps<K>>
+template <int K, int BT_R>
 __device__ __forceinline__ void blur2d_tile(float* tile, const float* __restrict__ in, float* __restrict__ out, float* __restrict__ dec_out, int h, int w,
-                                            int w2, int bx, int by, const TAPS& taps) {
+                                            int w2, int bx, int by, const Taps<K>& taps) {
     constexpr int R = K / 2;
     constexpr int BT_Y = 16 * BT_R;
     constexpr int LW = BlurTile<K, BT_R>::LW, LS = BlurTile<K, BT_R>::LS, LH = BlurTile<K, BT_R>::LH;
@@ -200,140 +198,6 @@ static bool launch_blur_pair(const float* in_a, float* out_a, int ha, int wa, co
     return true;
 }
 
-
-// ---- small-octave chain -----------------------------------------------------------------------------------------------------
-// At one image per call every blur launch of the small octaves is a few workgroups and costs a launch latency (4.6 - 7 us in a graph,
-// profiles/archive/r05_s1_config2_gap_table.md: 12 launches = 68 us for octaves >= 2 of an 800 x 640 image).  ONE launch walks the
-// remaining steps of the pyramid - per octave [level 2], [level 3 + decimation], [level 4 | next octave's level 1] - with a grid
-// barrier between the steps: every workgroup is resident (grid <= CHAIN_MAX_G x batch <= the CU count), a step's tiles are spread
-// over the grid, arrivals are counted in one word per image.  The per-pixel fmaf chain is blur2d_tile's: bit-identical levels.
-// Only the reference's default schedule (taps 9 / 11 / 13 / 15) takes this path; everything else keeps the per-level launches.
-#define CHAIN_MAX_STEPS 18
-struct ChainJob { int32_t in_off, out_off, dec_off; int16_t h, w, tiles_x, tiles; int32_t k; };     // offsets in floats from the image's pyramid base; dec_off < 0: none
-struct ChainStep { ChainJob a, b; };                                                                   // b.tiles == 0: single job
-#define CHAIN_TAPS_FLOATS (81 + 121 + 169 + 225)
-#define CHAIN_TAB_BYTES 4096                        // workspace: CHAIN_MAX_STEPS steps (1 KB) + the four tap tables 9 / 11 / 13 / 15 (2384 B), written once at bind time
-static_assert(sizeof(ChainStep) * CHAIN_MAX_STEPS <= 1024 && 1024 + CHAIN_TAPS_FLOATS * 4 <= CHAIN_TAB_BYTES, "chain table");
-
-__device__ __forceinline__ void chain_grid_barrier(uint32_t* sync, uint32_t target) {
-    __threadfence();                                   // release (agent scope): this thread's level pixels are visible to every XCD
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t spins = 0;
-        while (__hip_atomic_load(&sync[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(2);
-            if (++spins > (1u << 21)) {                // ~1 s: a lost arrival must not hang the GPU; the sticky flag fails the call (hessian_nms_kernel folds it into the overflow flag)
-                __hip_atomic_store(&sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-    }
-    __syncthreads();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // acquire: drop this CU's / XCD's stale lines before reading the other workgroups' pixels
-}
-
-// steps / taps: the table in the workspace (read-only here; `pyr` never aliases it).  The tap tables are addressed through an offset that is
-// opaque per tile: as loop invariants the compiler hoisted all 596 tap loads out of the step loop and spilled 1100 SGPRs.
-__global__ __launch_bounds__(256) void blur_chain_kernel(const ChainStep* __restrict__ steps, const float* __restrict__ taps, int n_steps, float* __restrict__ pyr_base,
-                                                         size_t img_stride, uint32_t* __restrict__ sync_base) {
-    __shared__ __attribute__((aligned(16))) float tile[BlurTile<15, 1>::FLOATS];
-    float* pyr = pyr_base + blockIdx.y * img_stride;
-    uint32_t* sync = sync_base + blockIdx.y * AFF_SYNC_WORDS;
-    const int G = gridDim.x;
-    for (int s = 0; s < n_steps; ++s) {
-        const int na = steps[s].a.tiles, nb = steps[s].b.tiles;
-        for (int t = blockIdx.x; t < na + nb; t += G) {
-            const ChainJob j = t < na ? steps[s].a : steps[s].b;        // uniform: scalar loads
-            const int tt = t < na ? t : t - na;
-            const float* in = pyr + j.in_off;
-            float* out = pyr + j.out_off;
-            float* dec = j.dec_off >= 0 ? pyr + j.dec_off : nullptr;
-            const int bx = tt % j.tiles_x, by = tt / j.tiles_x, w2 = (j.w - 1) / 2 + 1;
-            int zero = 0;
-            asm volatile("" : "+s"(zero));
-            switch (j.k) {
-                case 9: blur2d_tile<9, 1>(tile, in, out, dec, j.h, j.w, w2, bx, by, TapsPtr{taps + zero}); break;
-                case 11: blur2d_tile<11, 1>(tile, in, out, dec, j.h, j.w, w2, bx, by, TapsPtr{taps + 81 + zero}); break;
-                case 13: blur2d_tile<13, 1>(tile, in, out, dec, j.h, j.w, w2, bx, by, TapsPtr{taps + 81 + 121 + zero}); break;
-                default: blur2d_tile<15, 1>(tile, in, out, dec, j.h, j.w, w2, bx, by, TapsPtr{taps + 81 + 121 + 169 + zero}); break;
-            }
-            __syncthreads();                           // the tile buffer is reused
-        }
-        if (s + 1 < n_steps) chain_grid_barrier(sync, (uint32_t)(s + 1) * (uint32_t)G);
-    }
-    // the last workgroup to finish resets the barrier words for the next launch (every workgroup has passed every barrier by then)
-    if (threadIdx.x == 0) {
-        const uint32_t d = __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        if (d == (uint32_t)G - 1u) {
-            __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
-
-// First octave the chain may start at (>= 1; its level 1 comes from the previous octave's paired launch), or 0 = no chain.
-static int chain_first_octave(const affnet_ctx* ctx, int* grid_out) {
-    const affnet_config& c = ctx->cfg;
-    int max_g = 64;                                    // workgroups per image: one 64 x 16 tile each in the widest step
-    if (const char* e = getenv("AFFNET_PYR_CHAIN_G")) max_g = atoi(e);       // tuning aid; 0 switches the chain off
-    if (max_g <= 0 || c.levels_per_octave != 5 || c.n_octaves < 2) return 0;
-    if (c.level_blur_taps[1] != 9 || c.level_blur_taps[2] != 11 || c.level_blur_taps[3] != 13 || c.level_blur_taps[4] != 15) return 0;
-    if (max_g * ctx->B > 240) max_g = 240 / ctx->B;    // every workgroup of the launch must be resident (256 CUs)
-    auto tiles = [&](int o) { return aff_cdiv(ctx->oct[o].w, BT_X) * aff_cdiv(ctx->oct[o].h, 16); };
-    for (int o = 1; o < c.n_octaves; ++o) {
-        if (ctx->oct[o].h > 32767 || ctx->oct[o].w > 32767) continue;
-        const int g = tiles(o) + (o + 1 < c.n_octaves ? tiles(o + 1) : 0);
-        if (g <= max_g && 3 * (c.n_octaves - o) <= CHAIN_MAX_STEPS) { *grid_out = g; return o; }
-    }
-    return 0;
-}
-
-// The chain's step table for this context's plan -> workspace (affnet_bind_workspace; synchronous, once).  Also clears the barrier words.
-int aff_pyramid_chain_prepare(affnet_ctx* ctx) {
-    const affnet_config& c = ctx->cfg;
-    int grid = 0;
-    const int first = chain_first_octave(ctx, &grid);
-    ctx->chain_from = first; ctx->chain_grid = grid; ctx->chain_steps = 0;
-    if (hipMemset(ctx->sync, 0, (size_t)ctx->B * AFF_SYNC_WORDS * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); ctx->chain_from = 0; return AFFNET_OK; }   // no GPU (CPU-side layout tests)
-    if (first <= 0) return AFFNET_OK;
-    ChainStep steps[CHAIN_MAX_STEPS];
-    memset(steps, 0, sizeof(steps));
-    auto job = [&](int o, int l_in, int l_out, int k, bool dec) {
-        const OctaveGeom& g = ctx->oct[o];
-        const size_t lvl = (size_t)g.h * g.w;
-        ChainJob j;
-        j.in_off = (int32_t)(g.pyr_off + l_in * lvl); j.out_off = (int32_t)(g.pyr_off + l_out * lvl);
-        j.dec_off = (dec && o + 1 < c.n_octaves) ? (int32_t)ctx->oct[o + 1].pyr_off : -1;
-        j.h = (int16_t)g.h; j.w = (int16_t)g.w; j.tiles_x = (int16_t)aff_cdiv(g.w, BT_X); j.tiles = (int16_t)(aff_cdiv(g.w, BT_X) * aff_cdiv(g.h, 16));
-        j.k = k;
-        return j;
-    };
-    int n = 0;
-    for (int o = first; o < c.n_octaves; ++o) {
-        steps[n++].a = job(o, 1, 2, 11, false);
-        steps[n++].a = job(o, 2, 3, 13, true);
-        steps[n].a = job(o, 3, 4, 15, false);
-        if (o + 1 < c.n_octaves) steps[n].b = job(o + 1, 0, 1, 9, false);
-        ++n;
-    }
-    std::vector<unsigned char> tab(CHAIN_TAB_BYTES, 0);
-    memcpy(tab.data(), steps, sizeof(steps));
-    float* tp = reinterpret_cast<float*>(tab.data() + 1024);
-    memcpy(tp, c.level_blur[1], 81 * sizeof(float)); memcpy(tp + 81, c.level_blur[2], 121 * sizeof(float));
-    memcpy(tp + 81 + 121, c.level_blur[3], 169 * sizeof(float)); memcpy(tp + 81 + 121 + 169, c.level_blur[4], 225 * sizeof(float));
-    if (hipMemcpy(ctx->chain_tab, tab.data(), tab.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipGetLastError(); ctx->chain_from = 0; return AFFNET_OK; }
-    ctx->chain_steps = n;
-    return AFFNET_OK;
-}
-
-static int launch_blur_chain(affnet_ctx* ctx, hipStream_t st) {
-    hipLaunchKernelGGL(blur_chain_kernel, dim3(ctx->chain_grid, ctx->B), dim3(256), 0, st, reinterpret_cast<const ChainStep*>(ctx->chain_tab),
-                       reinterpret_cast<const float*>(ctx->chain_tab + 1024), ctx->chain_steps, ctx->pyr, ctx->pyr_stride, ctx->sync);
-    AFF_LAUNCH_CHECK(ctx);
-    return AFFNET_OK;
-}
-
 template <int K>
 static void launch_blur(const float* in, float* out, float* dec, int h, int w, int batch, size_t in_stride, size_t out_stride,
                         const float* taps, hipStream_t st) {
@@ -396,9 +260,7 @@ extern "C" int affnet_pyramid_build(affnet_ctx* ctx, const float* d_img, void* s
     const int L = c.levels_per_octave;
     const int dec_level = L - 2;  // i == nLevels (HandCraftedModules.py:46)
     int first_level = 1;             // 2 when the previous octave's paired launch already produced this octave's level 1
-    const int chain_from = ctx->chain_steps > 0 ? ctx->chain_from : 0;      // > 0: octaves >= chain_from in ONE launch (latency path: few workgroups per level)
     for (int o = 0; o < c.n_octaves; ++o) {
-        if (chain_from > 0 && o == chain_from && first_level == 2) return launch_blur_chain(ctx, st);
         const OctaveGeom& g = ctx->oct[o];
         float* base = ctx->pyr + g.pyr_off;
         const size_t lvl = (size_t)g.h * g.w;
