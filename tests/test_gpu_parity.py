@@ -1239,6 +1239,36 @@ def test_cli_entry_points(amd, golden_dir, tmp_path):
     assert got.shape == (64, 4) and np.abs(got - g["affine"]).max() < 1e-4
 
 
+def test_cli_threshold_script_variants(amd, weights, golden_dir, tmp_path):
+    """The `...Th.py` variants of the reference's scripts: extract_geom_and_desc_upisupTh.py (OnePassSIR, num_features = -1,
+    th = argv[3]; its line 63) and extract_geomOriTh.py (th = 28.41, OriNet slot, LAFs saved with np.save as lafs1.npy; its lines 31, 62, 88).  Their
+    files against the same calls through the Python API: identical rows."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    img = os.path.join(golden_dir, "graf_img1.png")
+    FC = amd.AffNetFastFullConv(PS=32); FC.load_state_dict(weights["AffNet"]); FC = FC.to(DEV)
+    O = amd.OriNetFast(PS=32); O.load_state_dict(weights["OriNet"]); O = O.to(DEV)
+    x = load_gray(img).to(DEV)
+    out = tmp_path / "graf_th"
+    subprocess.check_call([sys.executable, os.path.join(root, "examples/hesaffnet/extract_geomOriTh.py"), img, str(out)])
+    L = np.load(str(out) + ".lafs1.npy")
+    D = np.load(str(out) + ".desc.npy")
+    det = amd.OnePassSIR(mrSize=5.192, num_features=-1, th=28.41, border=15, num_Baum_iters=1, AffNet=FC, OriNet=O).to(DEV)
+    Lw, rw = det(x, do_ori=True)
+    assert L.ndim == 3 and L.shape[1:] == (2, 3) and L.shape[0] > 100 and D.shape == (L.shape[0], 128)
+    assert np.array_equal(L, Lw.cpu().numpy()), "lafs1.npy differs from OnePassSIR(th = 28.41)(img, do_ori = True)"
+    out2 = tmp_path / "graf_th.txt"
+    subprocess.check_call([sys.executable, os.path.join(root, "examples/hesaffnet/extract_geom_and_desc_upisupTh.py"), img, str(out2), "28.41"])
+    lines = open(out2).read().split("\n")
+    ell = np.loadtxt(out2, skiprows=2)
+    det2 = amd.OnePassSIR(mrSize=5.192, num_features=-1, th=28.41, border=15, num_Baum_iters=1, AffNet=FC).to(DEV)
+    L2, _ = det2(x)
+    want = amd.LAF.LAFs2ellT(L2).cpu().numpy()
+    assert lines[0].strip() == "1.0" and int(lines[1]) == ell.shape[0] == want.shape[0] and np.load(str(out2) + ".desc.npy").shape == (ell.shape[0], 128)
+    np.testing.assert_allclose(ell, want, rtol=1e-6, atol=1e-9)
+    record_parity("threshold-mode script variants (extract_geomOriTh.py, extract_geom_and_desc_upisupTh.py) on graf img1", rows_ori_th=int(L.shape[0]), rows_upisup_th=int(ell.shape[0]))
+
+
 @pytest.mark.parametrize("arith", ARITH)
 def test_c_host_program_drives_the_boundary_without_python(amd, nets, weights, golden_dir, tmp_path, arith):
     """examples/c_host/extract.c: a plain C99 program (gcc; hipMalloc, affnet_config_fill, flat weight files -> affnet_cnn32_pack_weights,
