@@ -196,9 +196,6 @@ extern "C" int affnet_cnn32_pack_weights(int kind, const float* const* conv_w, c
 // partials per patch are combined in fixed order by cnn16_finish_kernel (bit-reproducible, no atomics).
 //   AffNet: 3 outputs  = conv 64 -> 3, 8x8 valid                   (architectures.py:227-229)      part[8][4]
 //   OriNet: 2 x 9      = conv 64 -> 2, 8x8, padding 1 -> 3x3 map   (architectures.py:56-58)        part[8][18]
-#ifndef AFFNET_PERSIST_LAUNDER
-#define AFFNET_PERSIST_LAUNDER 1
-#endif
 #define HEAD_PART_AFF 32
 #define HEAD_PART_ORI 144
 template <int KIND, int TM>
@@ -340,9 +337,6 @@ struct CnnArgs {
     int n_max;
     float* out;            // AffNet/OriNet: (n,2,2); HardNet: trunk output (n,8192)
     int dbg_layer;         // >= 0: dump activations after this trunk layer of patch 0 and exit
-    int pair_mid_at;              // EXPERIMENT (paired persistent workgroups): where a patch publishes "past the midpoint": 0 = after the conv2 epilogue, 1 = after conv3's, 2 = after conv1's
-    int pair_epoch;               //   launch tag (20 bits) of the progress words
-    int persist, persist_delay;   // EXPERIMENT: persistent trunk workgroups (cnn32_trunk_persist_kernel): which workgroups start late, by how many 8128-cycle sleeps
     int s3_alt;            // tuning variant bits of the split-operand trunks (affnet_debug_split3_variant): bit 0 = the two waves of a SIMD alternate at the higher priority inside the HardNet loops
     float* dbg_out;
     unsigned long long* dbg_time;   // != NULL: s_memtime stamps [patch][wave][32] at the phase boundaries (tuning aid)
@@ -394,9 +388,8 @@ __device__ __forceinline__ void dump_planes(const float* act, float* dst) {
 // CU (2 waves / SIMD, 256 VGPRs).
 // STAMPS = debug instantiation: the s_memtime phase stamps of tools/cnn_phase_timing.py and the per-layer activation dumps
 // of affnet_cnn32_debug_layer exist only there (26 stamp sites = 26 predicated stores + branches in every wave otherwise).
-template <int KIND, int NW, bool STAMPS, int S3>
-__device__ __forceinline__ void trunk_patch(const CnnArgs& a, const PyrSrc& ps, float* lds, const int bx, const int by, const int tid_in, const float* __restrict__ pk,
-                                            unsigned* pair_my = nullptr, unsigned pair_mid_val = 0) {
+template <int KIND, int NW, bool STAMPS, int S3 = 0>
+__global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4) void cnn32_trunk_kernel(CnnArgs a, PyrSrc ps) {
     constexpr int CB = (KIND == AFFNET_NET_HARDNET) ? 32 : 16;
     constexpr int NTHR = NW * 64;
     constexpr int PPT = 1024 / NTHR;                    // input pixels per thread (2 or 1)
@@ -415,20 +408,21 @@ __device__ __forceinline__ void trunk_patch(const CnnArgs& a, const PyrSrc& ps, 
     constexpr int G3 = pick_groups(2 * CB, T2M, T2N, 32, AREG), G4 = pick_groups(2 * CB, T4M, T4N, 32, AREG);
     constexpr int G5 = pick_groups(4 * CB, T4M, T4N, 32, AREG);
     static_assert((CB / 4) * LayC1::PSG <= TrunkLds<CB>::ACT && (CB / 2) * LayC3::PSG <= TrunkLds<CB>::ACT, "LDS layout");
+    __shared__ __attribute__((aligned(16))) float lds[TrunkLds<CB>::TOTAL];
     float* act = lds;
     float* patch = lds + TrunkLds<CB>::ACT;
     float* red = patch + TrunkLds<CB>::PATCH;
-    // grid = (n_max, batch): row bx of image by; global row = image * n_max + row
-    const int n = a.count ? min(a.count[by], a.n_max) : a.n_max;
-    const int prow = bx + a.row_begin;
-    if (KIND == AFFNET_NET_AFFNET && a.shape_cnt && bx == 0 && tid_in == 0) {
-        int32_t* c = a.shape_cnt + (size_t)by * CNT_TOTAL;
+    // grid = (n_max, batch): row blockIdx.x of image blockIdx.y; global row = image * n_max + row
+    const int n = a.count ? min(a.count[blockIdx.y], a.n_max) : a.n_max;
+    const int prow = blockIdx.x + a.row_begin;
+    if (KIND == AFFNET_NET_AFFNET && a.shape_cnt && blockIdx.x == 0 && threadIdx.x == 0) {
+        int32_t* c = a.shape_cnt + (size_t)blockIdx.y * CNT_TOTAL;
         if (a.shape_op == 1) { c[CNT_SURVIVED] = 0; c[CNT_SURVIVED1] = 0; c[CNT_AFF_EVAL] = 0; }
         else if (a.shape_op == 2) c[CNT_SURVIVED1] = c[CNT_SURVIVED];
     }
-    if (prow >= n || lazy_skip(a.skip_cnt, a.skip_n, by, CNT_SURVIVED)) return;
-    const size_t pidx = (size_t)by * a.n_max + prow;
-    const int tid = tid_in, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;     // (scalar: in the persistent kernel the thread index is opaque, and the wave index must stay an SGPR)
+    if (prow >= n || lazy_skip(a.skip_cnt, a.skip_n, blockIdx.y, CNT_SURVIVED)) return;
+    const size_t pidx = (size_t)blockIdx.y * a.n_max + prow;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     // Issue priority (HardNet only, one workgroup per CU): the short latency-bound phases (input, conv0, epilogues) run at
     // priority 3, the MFMA loops at 0: +2% (130 -> 133 TFLOP/s).  For AffNet / OriNet (two workgroups per CU) it is
     // zero-sum: the non-MFMA phases of one workgroup get 2x faster (with equal priorities the arbiter prefers the OLDER
@@ -444,9 +438,9 @@ __device__ __forceinline__ void trunk_patch(const CnnArgs& a, const PyrSrc& ps, 
     // conv0 taps + bias and the first weight chunk of conv1: requested now, consumed after the input phase
     float w0[3][T1N];
     f32x4 bias0[T1N];
-    conv0_load_w<NW, CB, T1M, T1N>(pk + a.off.w[0], pk + a.off.b[0], w0, bias0, wave, lane);
+    conv0_load_w<NW, CB, T1M, T1N>(a.packed + a.off.w[0], a.packed + a.off.b[0], w0, bias0, wave, lane);
     f32x4 b1[ROLL1 ? 1 : G1][T1N];
-    prefetch_b0<NW, CB, 32, T1M, T1N, (ROLL1 ? 1 : G1)>(pk + a.off.w[1], b1, wave, lane);
+    prefetch_b0<NW, CB, 32, T1M, T1N, (ROLL1 ? 1 : G1)>(a.packed + a.off.w[1], b1, wave, lane);
 
     // ---- input: load or sample 1024 pixels (PPT per thread), standardise, store padded ----------------
     float v[PPT];
@@ -458,7 +452,7 @@ __device__ __forceinline__ void trunk_patch(const CnnArgs& a, const PyrSrc& ps, 
         int o = a.ids[3 * pidx], l = a.ids[3 * pidx + 1];
         o = o < 0 ? 0 : (o >= ps.n_octaves ? ps.n_octaves - 1 : o);
         l = l < 0 ? 0 : (l >= ps.n_levels ? ps.n_levels - 1 : l);
-        const float* img = ps.lvl[o][l] + by * ps.img_stride;
+        const float* img = ps.lvl[o][l] + blockIdx.y * ps.img_stride;
         const int h = ps.h[o], w = ps.w[o];
         const float* L = a.lafs + 6 * pidx;
         const float m = (float)(h < w ? h : w);
@@ -515,7 +509,7 @@ __device__ __forceinline__ void trunk_patch(const CnnArgs& a, const PyrSrc& ps, 
         f32x4 acc[T1M][T1N];
         conv0_mfma<NW, CB, T1M, T1N>(patch, w0, bias0, acc, wave, lane);
         CNN_STAMP(19);
-        prefetch_bias<NW, 32, T1M, T1N>(pk + a.off.b[1], bias1, wave, lane);
+        prefetch_bias<NW, 32, T1M, T1N>(a.packed + a.off.b[1], bias1, wave, lane);
         store_tiles_lds<CB, LayC0, T1M, T1N, false>(act, bias0, acc, wave, lane);
         CNN_STAMP(20);
         __syncthreads();
@@ -555,33 +549,33 @@ __device__ __forceinline__ void trunk_patch(const CnnArgs& a, const PyrSrc& ps, 
             // and conv2 as one 4 x 2 loop
             f32x4 acc1[8][2];
             S3W<2> wf2w;
-            s3_prefetch_w0<NW, CB, CB, 64, 8, 2, TERMS>(pk + a.off.w_s3[1], wf1, wave, lane);
-            prefetch_bias<NW, 32, 8, 2>(pk + a.off.b[1], bias1, wave, lane);
+            s3_prefetch_w0<NW, CB, CB, 64, 8, 2, TERMS>(a.packed + a.off.w_s3[1], wf1, wave, lane);
+            prefetch_bias<NW, 32, 8, 2>(a.packed + a.off.b[1], bias1, wave, lane);
             conv0_whole_split_q<NW, LR0, 2>(patch, w0, bias0, act, wave, lane);
             __syncthreads();
             CNN_STAMP(2);
             if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3q<NW, CB, CB, LR0, 1, 8, 2>(act, pk + a.off.w_s3[1], wf1, acc1, wave, lane, s3_alt);
+            conv3x3_mfma_s3q<NW, CB, CB, LR0, 1, 8, 2>(act, a.packed + a.off.w_s3[1], wf1, acc1, wave, lane, s3_alt);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
             CNN_STAMP(3);
-            s3_prefetch_w0<NW, CB, 2 * CB, 16, 4, 2, TERMS>(pk + a.off.w_s3[2], wf2w, wave, lane);
-            prefetch_bias<NW, 16, 4, 2>(pk + a.off.b[2], bias2w, wave, lane);
+            s3_prefetch_w0<NW, CB, 2 * CB, 16, 4, 2, TERMS>(a.packed + a.off.w_s3[2], wf2w, wave, lane);
+            prefetch_bias<NW, 16, 4, 2>(a.packed + a.off.b[2], bias2w, wave, lane);
             __syncthreads();
             zero_halo_q<LR1, NTHR>(act);                                 // another group stride than LR0 (the stride-2 reader's): the halo cells move
             store_tiles_split_q<CB, LR1, 8, 2>(act, bias1, acc1, wave, lane);
             __syncthreads();
             CNN_STAMP(4);
             if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3q<NW, CB, 2 * CB, LR1, 2, 4, 2>(act, pk + a.off.w_s3[2], wf2w, acc2w, wave, lane, s3_alt);
+            conv3x3_mfma_s3q<NW, CB, 2 * CB, LR1, 2, 4, 2>(act, a.packed + a.off.w_s3[2], wf2w, acc2w, wave, lane, s3_alt);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
         } else {
-            s3_prefetch_w0<NW, CB, CB, 32, 4, 2, TERMS>(pk + a.off.w_s3[1], wf1, wave, lane);
-            prefetch_bias<NW, 32, 8, 2>(pk + a.off.b[1], bias1, wave, lane);
+            s3_prefetch_w0<NW, CB, CB, 32, 4, 2, TERMS>(a.packed + a.off.w_s3[1], wf1, wave, lane);
+            prefetch_bias<NW, 32, 8, 2>(a.packed + a.off.b[1], bias1, wave, lane);
             conv0_half_split_q<NW, LQH, 2>(patch, w0, bias0, act, 0, wave, lane);
             __syncthreads();
             CNN_STAMP(2);
             if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3q<NW, CB, CB, LQH, 1, 4, 2>(act, pk + a.off.w_s3[1], wf1, acc_a, wave, lane, s3_alt);
+            conv3x3_mfma_s3q<NW, CB, CB, LQH, 1, 4, 2>(act, a.packed + a.off.w_s3[1], wf1, acc_a, wave, lane, s3_alt);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
             __syncthreads();
             if (tid < LQH::SLOTS * 4 * 32) {                             // pass 0 left conv0 row 16 in the bottom halo row: zero again (slots x 4 groups x 32 cells)
@@ -591,11 +585,11 @@ __device__ __forceinline__ void trunk_patch(const CnnArgs& a, const PyrSrc& ps, 
             conv0_half_split_q<NW, LQH, 2>(patch, w0, bias0, act, 1, wave, lane);
             __syncthreads();
             if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3q<NW, CB, CB, LQH, 1, 4, 2>(act, pk + a.off.w_s3[1], wf1, acc_b, wave, lane, s3_alt);
+            conv3x3_mfma_s3q<NW, CB, CB, LQH, 1, 4, 2>(act, a.packed + a.off.w_s3[1], wf1, acc_b, wave, lane, s3_alt);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
             CNN_STAMP(3);
-            s3_prefetch_w0<NW, CB, 2 * CB, 8, 4, 1, TERMS>(pk + a.off.w_s3[2], wf2, wave, lane);
-            bias2[0] = *reinterpret_cast<const f32x4*>(&pk[a.off.b[2] + (wave >> 1) * 16 + 4 * (lane >> 4)]);      // MG = 8 tiles / 4 = 2: channel tile = wave / 2
+            s3_prefetch_w0<NW, CB, 2 * CB, 8, 4, 1, TERMS>(a.packed + a.off.w_s3[2], wf2, wave, lane);
+            bias2[0] = *reinterpret_cast<const f32x4*>(&a.packed[a.off.b[2] + (wave >> 1) * 16 + 4 * (lane >> 4)]);      // MG = 8 tiles / 4 = 2: channel tile = wave / 2
             __syncthreads();
             // conv1's output goes back into the same half layout, pre-split, and conv2 (stride 2: output rows 0 .. 7 read input rows
             // -1 .. 15, rows 8 .. 15 read 15 .. 31) runs in two passes as well
@@ -604,7 +598,7 @@ __device__ __forceinline__ void trunk_patch(const CnnArgs& a, const PyrSrc& ps, 
             __syncthreads();
             CNN_STAMP(4);
             if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 4, 1>(act, pk + a.off.w_s3[2], wf2, acc2_a, wave, lane, s3_alt);
+            conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 4, 1>(act, a.packed + a.off.w_s3[2], wf2, acc2_a, wave, lane, s3_alt);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
             __syncthreads();
             store_tiles_split_q<CB, LQH2, 4, 2>(act, bias1, acc_b, wave, lane);
@@ -615,15 +609,15 @@ __device__ __forceinline__ void trunk_patch(const CnnArgs& a, const PyrSrc& ps, 
             }
             __syncthreads();
             if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 4, 1>(act, pk + a.off.w_s3[2], wf2, acc2_b, wave, lane, s3_alt);
+            conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 4, 1>(act, a.packed + a.off.w_s3[2], wf2, acc2_b, wave, lane, s3_alt);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
         }
         CNN_STAMP(5);
         S3W<2> wf3;
         S3W<1> wf4, wf5;
         f32x4 bias3[2], bias4[1], bias5s[1];
-        s3_prefetch_w0<NW, 2 * CB, 2 * CB, 16, 4, 2, TERMS>(pk + a.off.w_s3[3], wf3, wave, lane);
-        prefetch_bias<NW, 16, 4, 2>(pk + a.off.b[3], bias3, wave, lane);
+        s3_prefetch_w0<NW, 2 * CB, 2 * CB, 16, 4, 2, TERMS>(a.packed + a.off.w_s3[3], wf3, wave, lane);
+        prefetch_bias<NW, 16, 4, 2>(a.packed + a.off.b[3], bias3, wave, lane);
         __syncthreads();
         zero_halo_q<LQ2, NTHR>(act);
         if constexpr (WHOLE) store_tiles_split_q<2 * CB, LQ2, 4, 2>(act, bias2w, acc2w, wave, lane);
@@ -636,11 +630,11 @@ __device__ __forceinline__ void trunk_patch(const CnnArgs& a, const PyrSrc& ps, 
         {
             f32x4 acc_[4][2];                                            // conv3: 64 -> 64 @16x16
             if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3q<NW, 2 * CB, 2 * CB, LQ2, 1, 4, 2>(act, pk + a.off.w_s3[3], wf3, acc_, wave, lane, s3_alt);
+            conv3x3_mfma_s3q<NW, 2 * CB, 2 * CB, LQ2, 1, 4, 2>(act, a.packed + a.off.w_s3[3], wf3, acc_, wave, lane, s3_alt);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
             CNN_STAMP(7);
-            s3_prefetch_w0<NW, 2 * CB, 4 * CB, 4, 4, 1, TERMS>(pk + a.off.w_s3[4], wf4, wave, lane);
-            prefetch_bias<NW, 8, 4, 1>(pk + a.off.b[4], bias4, wave, lane);
+            s3_prefetch_w0<NW, 2 * CB, 4 * CB, 4, 4, 1, TERMS>(a.packed + a.off.w_s3[4], wf4, wave, lane);
+            prefetch_bias<NW, 8, 4, 1>(a.packed + a.off.b[4], bias4, wave, lane);
             __syncthreads();
             store_tiles_split_q<2 * CB, LQ2, 4, 2>(act, bias3, acc_, wave, lane);      // same layout in place: the halo is still zero
             __syncthreads();
@@ -649,11 +643,11 @@ __device__ __forceinline__ void trunk_patch(const CnnArgs& a, const PyrSrc& ps, 
         {
             f32x4 acc_[4][1];                                            // conv4: 64 -> 128, stride 2 -> 8x8
             if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3q<NW, 2 * CB, 4 * CB, LQ2, 2, 4, 1>(act, pk + a.off.w_s3[4], wf4, acc_, wave, lane, s3_alt);
+            conv3x3_mfma_s3q<NW, 2 * CB, 4 * CB, LQ2, 2, 4, 1>(act, a.packed + a.off.w_s3[4], wf4, acc_, wave, lane, s3_alt);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
             CNN_STAMP(9);
-            s3_prefetch_w0<NW, 4 * CB, 4 * CB, 4, 4, 1, TERMS>(pk + a.off.w_s3[5], wf5, wave, lane);
-            prefetch_bias<NW, 8, 4, 1>(pk + a.off.b[5], bias5s, wave, lane);
+            s3_prefetch_w0<NW, 4 * CB, 4 * CB, 4, 4, 1, TERMS>(a.packed + a.off.w_s3[5], wf5, wave, lane);
+            prefetch_bias<NW, 8, 4, 1>(a.packed + a.off.b[5], bias5s, wave, lane);
             __syncthreads();
             zero_halo_q<LQ4, NTHR>(act);
             store_tiles_split_q<4 * CB, LQ4, 4, 1>(act, bias4, acc_, wave, lane);
@@ -663,7 +657,7 @@ __device__ __forceinline__ void trunk_patch(const CnnArgs& a, const PyrSrc& ps, 
         {
             f32x4 acc5[4][1];                                            // conv5: 128 -> 128 @8x8, conv5 tensor -> HBM for the head GEMM
             if (PRIO) __builtin_amdgcn_s_setprio(0);
-            conv3x3_mfma_s3q<NW, 4 * CB, 4 * CB, LQ4, 1, 4, 1>(act, pk + a.off.w_s3[5], wf5, acc5, wave, lane, s3_alt);
+            conv3x3_mfma_s3q<NW, 4 * CB, 4 * CB, LQ4, 1, 4, 1>(act, a.packed + a.off.w_s3[5], wf5, acc5, wave, lane, s3_alt);
             if (PRIO) __builtin_amdgcn_s_setprio(3);
             CNN_STAMP(11);
             store_tiles_global<4 * CB, 4, 1>(a.out + pidx * (64 * 4 * CB), bias5s, acc5, wave, lane);
@@ -690,57 +684,57 @@ __device__ __forceinline__ void trunk_patch(const CnnArgs& a, const PyrSrc& ps, 
         S3W<1> wf1, wf2;
         f32x4 acc2_a[2][1], acc2_b[2][1], bias2[1];
         if constexpr (WHOLE) {
-            prefetch_bias_fresh<NW, 32, 8, 1>(pk + a.off.b[1], bias1, wave, lane);
+            prefetch_bias_fresh<NW, 32, 8, 1>(a.packed + a.off.b[1], bias1, wave, lane);
             conv0_whole_split_q<NW, LR0, 1>(patch, w0, bias0, act, wave, lane);
-            s3_prefetch_w0<NW, CB, CB, 32, 4, 1, TERMS>(pk + a.off.w_s3[1], wf1, wave, lane);
+            s3_prefetch_w0<NW, CB, CB, 32, 4, 1, TERMS>(a.packed + a.off.w_s3[1], wf1, wave, lane);
             __syncthreads();
             CNN_STAMP(2);
-            conv3x3_mfma_s3q<NW, CB, CB, LR0H, 1, 4, 1>(act, pk + a.off.w_s3[1], wf1, acc_a, wave, lane, false);
-            conv3x3_mfma_s3q<NW, CB, CB, LR0H, 1, 4, 1>(act + LR0::at(16, 0) / 4, pk + a.off.w_s3[1], wf1, acc_b, wave, lane, false);
+            conv3x3_mfma_s3q<NW, CB, CB, LR0H, 1, 4, 1>(act, a.packed + a.off.w_s3[1], wf1, acc_a, wave, lane, false);
+            conv3x3_mfma_s3q<NW, CB, CB, LR0H, 1, 4, 1>(act + LR0::at(16, 0) / 4, a.packed + a.off.w_s3[1], wf1, acc_b, wave, lane, false);
             CNN_STAMP(3);
             {
                 int l2 = lane;
                 asm volatile("" : "+v"(l2));
-                bias2[0] = *reinterpret_cast<const f32x4*>(&pk[a.off.b[2] + (wave >> 2) * 16 + 4 * (l2 >> 4)]);
+                bias2[0] = *reinterpret_cast<const f32x4*>(&a.packed[a.off.b[2] + (wave >> 2) * 16 + 4 * (l2 >> 4)]);
             }
             __syncthreads();
             zero_halo_q<LR1, NTHR>(act);                                     // another group stride than LR0 (the stride-2 reader's): the halo cells move
             store_tiles_split_q<CB, LR1, 4, 1, 16>(act, bias1, acc_a, wave, lane, 0);
             store_tiles_split_q<CB, LR1, 4, 1, 16>(act, bias1, acc_b, wave, lane, 16);
-            s3_prefetch_w0<NW, CB, 2 * CB, 8, 2, 1, TERMS>(pk + a.off.w_s3[2], wf2, wave, lane);
+            s3_prefetch_w0<NW, CB, 2 * CB, 8, 2, 1, TERMS>(a.packed + a.off.w_s3[2], wf2, wave, lane);
             __syncthreads();
             CNN_STAMP(4);
-            conv3x3_mfma_s3q<NW, CB, 2 * CB, LR1H, 2, 2, 1>(act, pk + a.off.w_s3[2], wf2, acc2_a, wave, lane, false);
-            conv3x3_mfma_s3q<NW, CB, 2 * CB, LR1H, 2, 2, 1>(act + LR1::at(16, 0) / 4, pk + a.off.w_s3[2], wf2, acc2_b, wave, lane, false);
+            conv3x3_mfma_s3q<NW, CB, 2 * CB, LR1H, 2, 2, 1>(act, a.packed + a.off.w_s3[2], wf2, acc2_a, wave, lane, false);
+            conv3x3_mfma_s3q<NW, CB, 2 * CB, LR1H, 2, 2, 1>(act + LR1::at(16, 0) / 4, a.packed + a.off.w_s3[2], wf2, acc2_b, wave, lane, false);
         } else {
-            prefetch_bias_fresh<NW, 32, 8, 1>(pk + a.off.b[1], bias1, wave, lane);
+            prefetch_bias_fresh<NW, 32, 8, 1>(a.packed + a.off.b[1], bias1, wave, lane);
             conv0_half_split_q<NW, LQH, 1>(patch, w0, bias0, act, 0, wave, lane);
-            s3_prefetch_w0<NW, CB, CB, 32, 4, 1, TERMS>(pk + a.off.w_s3[1], wf1, wave, lane);
+            s3_prefetch_w0<NW, CB, CB, 32, 4, 1, TERMS>(a.packed + a.off.w_s3[1], wf1, wave, lane);
             __syncthreads();
             CNN_STAMP(2);
-            conv3x3_mfma_s3q<NW, CB, CB, LQH, 1, 4, 1>(act, pk + a.off.w_s3[1], wf1, acc_a, wave, lane, false);
+            conv3x3_mfma_s3q<NW, CB, CB, LQH, 1, 4, 1>(act, a.packed + a.off.w_s3[1], wf1, acc_a, wave, lane, false);
             __syncthreads();
             if (tid < LQH::SLOTS * 2 * 32) {                                 // pass 0 left conv0 row 16 in the bottom halo row: zero again (slots x 2 groups x 32 cells)
                 const int t = tid >> 6, g = (tid >> 5) & 1, x = tid & 31;
                 *reinterpret_cast<f32x4*>(base + g * LQH::GS + LQH::at(17, x + 1) + t * LQH::TSTEP) = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
             conv0_half_split_q<NW, LQH, 1>(patch, w0, bias0, act, 1, wave, lane);
-            s3_prefetch_w0<NW, CB, CB, 32, 4, 1, TERMS>(pk + a.off.w_s3[1], wf1, wave, lane);
+            s3_prefetch_w0<NW, CB, CB, 32, 4, 1, TERMS>(a.packed + a.off.w_s3[1], wf1, wave, lane);
             __syncthreads();
-            conv3x3_mfma_s3q<NW, CB, CB, LQH, 1, 4, 1>(act, pk + a.off.w_s3[1], wf1, acc_b, wave, lane, false);
+            conv3x3_mfma_s3q<NW, CB, CB, LQH, 1, 4, 1>(act, a.packed + a.off.w_s3[1], wf1, acc_b, wave, lane, false);
             CNN_STAMP(3);
             {
                 int l2 = lane;
                 asm volatile("" : "+v"(l2));
-                bias2[0] = *reinterpret_cast<const f32x4*>(&pk[a.off.b[2] + (wave >> 2) * 16 + 4 * (l2 >> 4)]);
+                bias2[0] = *reinterpret_cast<const f32x4*>(&a.packed[a.off.b[2] + (wave >> 2) * 16 + 4 * (l2 >> 4)]);
             }
             __syncthreads();
             zero_halo_q<LQH2, NTHR>(act);                                    // another group stride than LQH (bank conflicts of the stride-2 reader)
             store_tiles_split_q<CB, LQH2, 4, 1>(act, bias1, acc_a, wave, lane);
-            s3_prefetch_w0<NW, CB, 2 * CB, 8, 2, 1, TERMS>(pk + a.off.w_s3[2], wf2, wave, lane);
+            s3_prefetch_w0<NW, CB, 2 * CB, 8, 2, 1, TERMS>(a.packed + a.off.w_s3[2], wf2, wave, lane);
             __syncthreads();
             CNN_STAMP(4);
-            conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 2, 1>(act, pk + a.off.w_s3[2], wf2, acc2_a, wave, lane, false);
+            conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 2, 1>(act, a.packed + a.off.w_s3[2], wf2, acc2_a, wave, lane, false);
             __syncthreads();
             store_tiles_split_q<CB, LQH2, 4, 1>(act, bias1, acc_b, wave, lane);
             if (wave == 7) {                                                 // conv1 row 15 (tiles 2, 3 of wave 7 in pass 0) = the top halo row of pass 1
@@ -748,9 +742,9 @@ __device__ __forceinline__ void trunk_patch(const CnnArgs& a, const PyrSrc& ps, 
 #pragma unroll
                 for (int i = 2; i < 4; ++i) split_store_tile_q<LQH2, 1>(base, LQH2::at(0, (i - 2) * 16 + n + 1), 0, bias1, acc_a[i], lane >> 4);
             }
-            s3_prefetch_w0<NW, CB, 2 * CB, 8, 2, 1, TERMS>(pk + a.off.w_s3[2], wf2, wave, lane);
+            s3_prefetch_w0<NW, CB, 2 * CB, 8, 2, 1, TERMS>(a.packed + a.off.w_s3[2], wf2, wave, lane);
             __syncthreads();
-            conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 2, 1>(act, pk + a.off.w_s3[2], wf2, acc2_b, wave, lane, false);
+            conv3x3_mfma_s3q<NW, CB, 2 * CB, LQH2, 2, 2, 1>(act, a.packed + a.off.w_s3[2], wf2, acc2_b, wave, lane, false);
         }
         CNN_STAMP(5);
         // conv3 / conv4: four / two pixel tiles x ONE channel tile per wave (probe: conv3 64.8 % of the pipe floor vs 58.2 % for 2 x 2, conv4 60.6 % vs
@@ -761,18 +755,18 @@ __device__ __forceinline__ void trunk_patch(const CnnArgs& a, const PyrSrc& ps, 
         zero_halo_q<LQ2, NTHR>(act);
         store_tiles_split_q<2 * CB, LQ2, 2, 1, 8>(act, bias2, acc2_a, wave, lane, 0);
         store_tiles_split_q<2 * CB, LQ2, 2, 1, 8>(act, bias2, acc2_b, wave, lane, 8);
-        s3_prefetch_w0<NW, 2 * CB, 2 * CB, 16, 4, 1, TERMS>(pk + a.off.w_s3[3], wf3, wave, lane);
-        prefetch_bias_fresh<NW, 16, 4, 1>(pk + a.off.b[3], bias3, wave, lane);
+        s3_prefetch_w0<NW, 2 * CB, 2 * CB, 16, 4, 1, TERMS>(a.packed + a.off.w_s3[3], wf3, wave, lane);
+        prefetch_bias_fresh<NW, 16, 4, 1>(a.packed + a.off.b[3], bias3, wave, lane);
         __syncthreads();
         CNN_STAMP(6);
         {
             f32x4 acc_[4][1];                                            // conv3: 32 -> 32 @16x16
-            conv3x3_mfma_s3q<NW, 2 * CB, 2 * CB, LQ2, 1, 4, 1>(act, pk + a.off.w_s3[3], wf3, acc_, wave, lane, false);
+            conv3x3_mfma_s3q<NW, 2 * CB, 2 * CB, LQ2, 1, 4, 1>(act, a.packed + a.off.w_s3[3], wf3, acc_, wave, lane, false);
             CNN_STAMP(7);
             __syncthreads();
             store_tiles_split_q<2 * CB, LQ2, 4, 1>(act, bias3, acc_, wave, lane);      // in place: the halo is still zero
-            s3_prefetch_w0<NW, 2 * CB, 4 * CB, 4, 2, 1, TERMS>(pk + a.off.w_s3[4], wf4, wave, lane);
-            prefetch_bias_fresh<NW, 8, 2, 1>(pk + a.off.b[4], bias4, wave, lane);
+            s3_prefetch_w0<NW, 2 * CB, 4 * CB, 4, 2, 1, TERMS>(a.packed + a.off.w_s3[4], wf4, wave, lane);
+            prefetch_bias_fresh<NW, 8, 2, 1>(a.packed + a.off.b[4], bias4, wave, lane);
             __syncthreads();
             CNN_STAMP(8);
         }
@@ -780,27 +774,27 @@ __device__ __forceinline__ void trunk_patch(const CnnArgs& a, const PyrSrc& ps, 
         f32x4 bias5s[T4N];
         {
             f32x4 acc_[2][1];                                            // conv4: 32 -> 64, stride 2 -> 8x8
-            conv3x3_mfma_s3q<NW, 2 * CB, 4 * CB, LQ2, 2, 2, 1>(act, pk + a.off.w_s3[4], wf4, acc_, wave, lane, false);
+            conv3x3_mfma_s3q<NW, 2 * CB, 4 * CB, LQ2, 2, 2, 1>(act, a.packed + a.off.w_s3[4], wf4, acc_, wave, lane, false);
             CNN_STAMP(9);
             __syncthreads();
             zero_halo_q<LQ4, NTHR>(act);
             store_tiles_split_q<4 * CB, LQ4, 2, 1>(act, bias4, acc_, wave, lane);
-            s3_prefetch_w0<NW, 4 * CB, 4 * CB, 4, T4M, T4N, TERMS>(pk + a.off.w_s3[5], wf5, wave, lane);
-            prefetch_bias_fresh<NW, 8, T4M, T4N>(pk + a.off.b[5], bias5s, wave, lane);
+            s3_prefetch_w0<NW, 4 * CB, 4 * CB, 4, T4M, T4N, TERMS>(a.packed + a.off.w_s3[5], wf5, wave, lane);
+            prefetch_bias_fresh<NW, 8, T4M, T4N>(a.packed + a.off.b[5], bias5s, wave, lane);
             __syncthreads();
             CNN_STAMP(10);
         }
         {
             f32x4 acc5[T4M][T4N];                                        // conv5: 64 -> 64 @8x8 in the exact path's tiling (the heads read it)
-            conv3x3_mfma_s3q<NW, 4 * CB, 4 * CB, LQ4, 1, T4M, T4N>(act, pk + a.off.w_s3[5], wf5, acc5, wave, lane, false);
+            conv3x3_mfma_s3q<NW, 4 * CB, 4 * CB, LQ4, 1, T4M, T4N>(act, a.packed + a.off.w_s3[5], wf5, acc5, wave, lane, false);
             CNN_STAMP(11);
             if constexpr (KIND != AFFNET_NET_HARDNET) {
                 int lane_h = lane;                                       // opaque: 4 * (lane >> 4) is recomputed here, not carried (and spilled) from the kernel's top
                 asm volatile("" : "+v"(lane_h));
                 if constexpr (KIND == AFFNET_NET_ORINET)
-                    head_partials_ori_lds<T4M, NTHR>(pk + a.off.head_w, bias5s, acc5, a.out + pidx * HEAD_PART_ORI, act, wave, lane_h, tid);
+                    head_partials_ori_lds<T4M, NTHR>(a.packed + a.off.head_w, bias5s, acc5, a.out + pidx * HEAD_PART_ORI, act, wave, lane_h, tid);
                 else
-                    head_partials<KIND, T4M>(pk + a.off.head_w, bias5s, acc5, a.out + pidx * HEAD_PART_AFF, wave, lane_h);
+                    head_partials<KIND, T4M>(a.packed + a.off.head_w, bias5s, acc5, a.out + pidx * HEAD_PART_AFF, wave, lane_h);
             }
             CNN_STAMP(13);
         }
@@ -815,12 +809,12 @@ __device__ __forceinline__ void trunk_patch(const CnnArgs& a, const PyrSrc& ps, 
     {
         f32x4 acc[T1M][T1N];
         if (PRIO) __builtin_amdgcn_s_setprio(0);
-        if (ROLL1) conv3x3_mfma_roll<NW, CB, CB, LayC0, 1, T1M, T1N>(act, pk + a.off.w[1], reinterpret_cast<const f32x4 (&)[1][T1N]>(b1), acc, wave, lane);
-        else conv3x3_mfma<NW, CB, CB, LayC0, 1, T1M, T1N, G1>(act, pk + a.off.w[1], reinterpret_cast<const f32x4 (&)[G1][T1N]>(b1), acc, wave, lane);
+        if (ROLL1) conv3x3_mfma_roll<NW, CB, CB, LayC0, 1, T1M, T1N>(act, a.packed + a.off.w[1], reinterpret_cast<const f32x4 (&)[1][T1N]>(b1), acc, wave, lane);
+        else conv3x3_mfma<NW, CB, CB, LayC0, 1, T1M, T1N, G1>(act, a.packed + a.off.w[1], reinterpret_cast<const f32x4 (&)[G1][T1N]>(b1), acc, wave, lane);
         if (PRIO) __builtin_amdgcn_s_setprio(3);
         CNN_STAMP(3);
-        prefetch_b0<NW, 2 * CB, 16, T2M, T2N, G2>(pk + a.off.w[2], b2, wave, lane);
-        prefetch_bias<NW, 16, T2M, T2N>(pk + a.off.b[2], bias2, wave, lane);
+        prefetch_b0<NW, 2 * CB, 16, T2M, T2N, G2>(a.packed + a.off.w[2], b2, wave, lane);
+        prefetch_bias<NW, 16, T2M, T2N>(a.packed + a.off.b[2], bias2, wave, lane);
         __syncthreads();
         CNN_STAMP(21);
         zero_halo<LayC1, NTHR>(act, CB);
@@ -828,7 +822,6 @@ __device__ __forceinline__ void trunk_patch(const CnnArgs& a, const PyrSrc& ps, 
         CNN_STAMP(22);
         __syncthreads();
         CNN_STAMP(4);
-        if (pair_my && a.pair_mid_at == 2 && tid == 0) __hip_atomic_store(pair_my, pair_mid_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (STAMPS && a.dbg_layer == 1) { dump_planes<CB, LayC1, NTHR>(act, a.dbg_out); return; }
 
@@ -838,17 +831,16 @@ __device__ __forceinline__ void trunk_patch(const CnnArgs& a, const PyrSrc& ps, 
     {
         f32x4 acc[T2M][T2N];
         if (PRIO) __builtin_amdgcn_s_setprio(0);
-        conv3x3_mfma<NW, CB, 2 * CB, LayC1, 2, T2M, T2N, G2>(act, pk + a.off.w[2], b2, acc, wave, lane);
+        conv3x3_mfma<NW, CB, 2 * CB, LayC1, 2, T2M, T2N, G2>(act, a.packed + a.off.w[2], b2, acc, wave, lane);
         if (PRIO) __builtin_amdgcn_s_setprio(3);
         CNN_STAMP(5);
-        prefetch_b0<NW, 2 * CB, 16, T2M, T2N, G3>(pk + a.off.w[3], b3, wave, lane);
-        prefetch_bias<NW, 16, T2M, T2N>(pk + a.off.b[3], bias3, wave, lane);
+        prefetch_b0<NW, 2 * CB, 16, T2M, T2N, G3>(a.packed + a.off.w[3], b3, wave, lane);
+        prefetch_bias<NW, 16, T2M, T2N>(a.packed + a.off.b[3], bias3, wave, lane);
         __syncthreads();
         zero_halo<LayC2, NTHR>(act, 2 * CB);
         store_tiles_lds<2 * CB, LayC2, T2M, T2N>(act, bias2, acc, wave, lane);
         __syncthreads();
         CNN_STAMP(6);
-        if (pair_my && a.pair_mid_at == 0 && tid == 0) __hip_atomic_store(pair_my, pair_mid_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (STAMPS && a.dbg_layer == 2) { dump_planes<2 * CB, LayC2, NTHR>(act, a.dbg_out); return; }
 
@@ -858,17 +850,16 @@ __device__ __forceinline__ void trunk_patch(const CnnArgs& a, const PyrSrc& ps, 
     {
         f32x4 acc[T2M][T2N];
         if (PRIO) __builtin_amdgcn_s_setprio(0);
-        conv3x3_mfma<NW, 2 * CB, 2 * CB, LayC2, 1, T2M, T2N, G3>(act, pk + a.off.w[3], b3, acc, wave, lane);
+        conv3x3_mfma<NW, 2 * CB, 2 * CB, LayC2, 1, T2M, T2N, G3>(act, a.packed + a.off.w[3], b3, acc, wave, lane);
         if (PRIO) __builtin_amdgcn_s_setprio(3);
         CNN_STAMP(7);
-        prefetch_b0<NW, 4 * CB, 8, T4M, T4N, G4>(pk + a.off.w[4], b4, wave, lane);
-        prefetch_bias<NW, 8, T4M, T4N>(pk + a.off.b[4], bias4, wave, lane);
+        prefetch_b0<NW, 4 * CB, 8, T4M, T4N, G4>(a.packed + a.off.w[4], b4, wave, lane);
+        prefetch_bias<NW, 8, T4M, T4N>(a.packed + a.off.b[4], bias4, wave, lane);
         __syncthreads();
         zero_halo<LayC3, NTHR>(act, 2 * CB);
         store_tiles_lds<2 * CB, LayC3, T2M, T2N>(act, bias3, acc, wave, lane);
         __syncthreads();
         CNN_STAMP(8);
-        if (pair_my && a.pair_mid_at == 1 && tid == 0) __hip_atomic_store(pair_my, pair_mid_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (STAMPS && a.dbg_layer == 3) { dump_planes<2 * CB, LayC3, NTHR>(act, a.dbg_out); return; }
 
@@ -878,11 +869,11 @@ __device__ __forceinline__ void trunk_patch(const CnnArgs& a, const PyrSrc& ps, 
     {
         f32x4 acc[T4M][T4N];
         if (PRIO) __builtin_amdgcn_s_setprio(0);
-        conv3x3_mfma<NW, 2 * CB, 4 * CB, LayC3, 2, T4M, T4N, G4>(act, pk + a.off.w[4], b4, acc, wave, lane);
+        conv3x3_mfma<NW, 2 * CB, 4 * CB, LayC3, 2, T4M, T4N, G4>(act, a.packed + a.off.w[4], b4, acc, wave, lane);
         if (PRIO) __builtin_amdgcn_s_setprio(3);
         CNN_STAMP(9);
-        prefetch_b0<NW, 4 * CB, 8, T4M, T4N, G5>(pk + a.off.w[5], b5, wave, lane);
-        prefetch_bias<NW, 8, T4M, T4N>(pk + a.off.b[5], bias5, wave, lane);
+        prefetch_b0<NW, 4 * CB, 8, T4M, T4N, G5>(a.packed + a.off.w[5], b5, wave, lane);
+        prefetch_bias<NW, 8, T4M, T4N>(a.packed + a.off.b[5], bias5, wave, lane);
         __syncthreads();
         zero_halo<LayC4, NTHR>(act, 4 * CB);
         store_tiles_lds<4 * CB, LayC4, T4M, T4N>(act, bias4, acc, wave, lane);
@@ -895,16 +886,16 @@ __device__ __forceinline__ void trunk_patch(const CnnArgs& a, const PyrSrc& ps, 
     {
         f32x4 acc[T4M][T4N];
         if (PRIO) __builtin_amdgcn_s_setprio(0);
-        conv3x3_mfma<NW, 4 * CB, 4 * CB, LayC4, 1, T4M, T4N, G5>(act, pk + a.off.w[5], b5, acc, wave, lane);
+        conv3x3_mfma<NW, 4 * CB, 4 * CB, LayC4, 1, T4M, T4N, G5>(act, a.packed + a.off.w[5], b5, acc, wave, lane);
         if (PRIO) __builtin_amdgcn_s_setprio(3);
         CNN_STAMP(11);
         if (!STAMPS || a.dbg_layer < 0) {
             if constexpr (KIND == AFFNET_NET_HARDNET)   // conv5 tensor -> HBM as [pixel][channel]; the head GEMM runs over all patches
                 store_tiles_global<4 * CB, T4M, T4N>(a.out + pidx * (64 * 4 * CB), bias5, acc, wave, lane);
             else if constexpr (KIND == AFFNET_NET_ORINET)   // per-wave partial sums of the head's dot products: weights once, shifted activations from LDS
-                head_partials_ori_lds<T4M, NTHR>(pk + a.off.head_w, bias5, acc, a.out + pidx * HEAD_PART_ORI, act, wave, lane, tid);
+                head_partials_ori_lds<T4M, NTHR>(a.packed + a.off.head_w, bias5, acc, a.out + pidx * HEAD_PART_ORI, act, wave, lane, tid);
             else
-                head_partials<KIND, T4M>(pk + a.off.head_w, bias5, acc,
+                head_partials<KIND, T4M>(a.packed + a.off.head_w, bias5, acc,
                                          a.out + pidx * (KIND == AFFNET_NET_AFFNET ? HEAD_PART_AFF : HEAD_PART_ORI), wave, lane);
             CNN_STAMP(13);
             return;
@@ -915,82 +906,6 @@ __device__ __forceinline__ void trunk_patch(const CnnArgs& a, const PyrSrc& ps, 
         CNN_STAMP(12);
     }
     if (STAMPS && a.dbg_layer == 5) { dump_planes<4 * CB, LayC5, NTHR>(act, a.dbg_out); return; }
-}
-
-// One workgroup = one patch: grid = (rows of the window, images).
-template <int KIND, int NW, bool STAMPS, int S3 = 0>
-__global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4) void cnn32_trunk_kernel(CnnArgs a, PyrSrc ps) {
-    constexpr int CB = (KIND == AFFNET_NET_HARDNET) ? 32 : 16;
-    __shared__ __attribute__((aligned(16))) float lds[TrunkLds<CB>::TOTAL];
-    trunk_patch<KIND, NW, STAMPS, S3>(a, ps, lds, blockIdx.x, blockIdx.y, threadIdx.x, a.packed);
-}
-
-// EXPERIMENT (round 6): persistent workgroups - one per CU slot, item i = (image i / rows, row i % rows), striding over the
-// items - with the two workgroups of a CU started HALF A PATCH APART (a.persist_delay x 8128 cycles for the workgroups a.persist selects), so that
-// one is in its MFMA loops while the other is in input / conv0 / an epilogue.  Round 1 measured plain persistent workgroups 5 - 10 % slower:
-// the two workgroups of a CU start together and stay in phase.
-__device__ unsigned g_cu_arrivals[4096];      // EXPERIMENT: arrivals per (XCC, SE, SH, CU); two workgroups per CU and launch -> the parity of the old value tells first from second
-__device__ unsigned g_pair_dbg[8];             // EXPERIMENT diagnostics: [0] workgroups, [1] of them in the second slot, [2] time-outs, [3] polls that had to wait, [4] wait iterations
-__device__ unsigned g_pair_progress[4096][2];  // EXPERIMENT: progress words of the two workgroup slots of every CU: (epoch << 12) | progress, progress = 2 k (patch k started), 2 k + 1 (past its midpoint), 0xFFF = finished
-template <int KIND, int NW>
-__global__ __launch_bounds__(NW * 64, (KIND == AFFNET_NET_HARDNET) ? NW / 4 : 4) void cnn32_trunk_persist_kernel(CnnArgs a, PyrSrc ps, int rows, int items) {
-    constexpr int CB = (KIND == AFFNET_NET_HARDNET) ? 32 : 16;
-    __shared__ __attribute__((aligned(16))) float lds[TrunkLds<CB>::TOTAL];
-    __shared__ unsigned s_second, s_key;
-    if (a.persist >= 5) {
-        if (threadIdx.x == 0) {
-            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u;     // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
-            s_key = (xcc << 8) | ((hw >> 8) & 255u);
-            if (a.persist == 5) s_second = atomicAdd(&g_cu_arrivals[s_key], 1u) & 1u;
-            else s_second = (__builtin_amdgcn_s_getreg((31 << 11) | 6) & 0xFFFu) != 0u;       // HW_REG_LDS_ALLOC: LDS base of this workgroup - 0 for the CU's first slot
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) { atomicAdd(&g_pair_dbg[0], 1u); if (s_second & 1u) atomicAdd(&g_pair_dbg[1], 1u); }
-    }
-    const bool late = a.persist >= 5 ? (s_second & 1u) != 0 : (a.persist == 2 ? ((int)blockIdx.x >= (int)gridDim.x / 2) : (a.persist == 3 ? (((int)blockIdx.x >> 3) & 1) != 0 : (a.persist == 4 ? ((int)blockIdx.x & 1) != 0 : false)));
-    if (late)
-        for (int d = 0; d < a.persist_delay; ++d) __builtin_amdgcn_s_sleep(127);
-    // persist == 6: the two workgroups of a CU take turns - the first slot's workgroup (leader) starts patch k once the follower is past the midpoint of its
-    // patch k - 1, the follower starts patch k once the leader is past the midpoint of ITS patch k: half a patch apart for the whole launch, so that one
-    // of the two is in an MFMA loop while the other runs input / conv0 / an epilogue.  (A start stagger alone does not hold: the workgroup that is
-    // behind gets the matrix pipe to itself whenever the leader leaves a loop and catches up - measured, delays of 0 .. 13 x 8128 cycles all the same.)
-    const bool paired = a.persist == 6;
-    unsigned* my = paired ? &g_pair_progress[s_key][late ? 1 : 0] : nullptr;
-    const unsigned* other = paired ? &g_pair_progress[s_key][late ? 0 : 1] : nullptr;
-    const unsigned base = (unsigned)a.pair_epoch << 12;
-    bool sync_on = paired;
-    int k = 0;
-    for (int i = blockIdx.x; i < items; i += gridDim.x, ++k) {
-        int bx = i % rows, by = i / rows, tid = threadIdx.x;
-        // opaque per iteration: nothing derived from the weight pointer or the thread index is loop invariant (held - and spilled - across the patch loop)
-        // (the weight pointer travels through the asm as an integer and comes back as a GLOBAL pointer: a laundered generic pointer turned every bias / tap
-        // load of the patch into a flat_load - 33 of them, counted against the LDS wait counter too - and cost 11 % per patch)
-        unsigned long long pkv = (unsigned long long)a.packed;
-#if AFFNET_PERSIST_LAUNDER
-        asm volatile("" : "+s"(bx), "+s"(by), "+v"(tid), "+s"(pkv));
-#endif
-        const float* pk = (const float*)(const __attribute__((address_space(1))) float*)pkv;
-        if (paired) {
-            const int need = late ? 2 * k + 1 : 2 * k - 1;           // follower: leader past the midpoint of patch k; leader: follower past the midpoint of patch k - 1
-            if (sync_on && need > 0 && threadIdx.x == 0) {
-                unsigned spins = 0;
-                for (;;) {
-                    const unsigned v = __hip_atomic_load(other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((v >> 12) == (unsigned)a.pair_epoch && (v & 0xFFFu) >= (unsigned)need) break;
-                    __builtin_amdgcn_s_sleep(2);
-                    if (++spins > 20000u) { s_second |= 2u; atomicAdd(&g_pair_dbg[2], 1u); break; }       // no partner on this CU (or it is gone): stop pairing, never hang
-                }
-                if (spins) { atomicAdd(&g_pair_dbg[3], 1u); atomicAdd(&g_pair_dbg[4], spins); }
-            }
-            if (threadIdx.x == 0) __hip_atomic_store(my, base | (unsigned)(2 * k), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            sync_on = sync_on && !(s_second & 2u);
-        }
-        trunk_patch<KIND, NW, false, 0>(a, ps, lds, bx, by, tid, pk, my, base | (unsigned)(2 * k + 1));
-        __syncthreads();                                // the next patch reuses the LDS buffers
-        if (paired && threadIdx.x == 0) __hip_atomic_store(my, base | (unsigned)(2 * k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (skipped rows never reach the midpoint)
-    }
-    if (paired && threadIdx.x == 0) __hip_atomic_store(my, base | 0xFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- AffNet / OriNet heads, second half: combine the eight per-wave partials of a patch ---------------------------------
@@ -1339,13 +1254,6 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
 #define TRUNK_LAUNCH(K) do { if (a.dbg_time || dbg_layer >= 0) hipLaunchKernelGGL((cnn32_trunk_kernel<K, 8, true>), grid, dim3(512), 0, st, a, ps); \
                              else hipLaunchKernelGGL((cnn32_trunk_kernel<K, 8, false>), grid, dim3(512), 0, st, a, ps); } while (0)
     a.s3_alt = ctx->split3_variant;
-    a.persist = 0; a.persist_delay = 0; a.pair_mid_at = 0; a.pair_epoch = 0;
-    static const int pair_mid_at = getenv("AFFNET_TRUNK_PAIR_MID") ? atoi(getenv("AFFNET_TRUNK_PAIR_MID")) : 0;
-    static unsigned pair_seq = 0;
-    static const int persist_mode = getenv("AFFNET_TRUNK_PERSIST") ? atoi(getenv("AFFNET_TRUNK_PERSIST")) : 0;
-    static const int persist_delay = getenv("AFFNET_TRUNK_DELAY") ? atoi(getenv("AFFNET_TRUNK_DELAY")) : 9;
-    static const int persist_kinds = getenv("AFFNET_TRUNK_PERSIST_KINDS") ? atoi(getenv("AFFNET_TRUNK_PERSIST_KINDS")) : 3;      // bit mask of net kinds (1 AffNet, 2 OriNet, 4 HardNet)
-    auto persist_grid = [&](int k) { return !((persist_kinds >> k) & 1) ? (1 << 30) : (k == AFFNET_NET_HARDNET ? 256 : 512); };
     const bool h2 = ctx->arith == AFFNET_ARITH_FP32_SPLIT2H;
     const bool split = ctx->arith == AFFNET_ARITH_FP32_SPLIT3 || h2;
     a.off = to_offsets(L, ctx->arith);                                   // the split copy of the active mode
@@ -1359,21 +1267,6 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
     else if (s3 && kind == AFFNET_NET_ORINET) SPLIT_LAUNCH(AFFNET_NET_ORINET, false);
     else if (s3) SPLIT_LAUNCH(AFFNET_NET_HARDNET, false);
 #undef SPLIT_LAUNCH
-    else if (persist_mode > 0 && !a.dbg_time && dbg_layer < 0 && (long long)row_count * B >= 16LL * persist_grid(kind)) {
-        // EXPERIMENT: persistent workgroups (exact arithmetic only), launches of >= 16 patches per CU slot
-        const int slots = persist_mode == 7 ? row_count * B : persist_grid(kind);      // 7: one patch per workgroup through the persistent kernel's code (isolates its code generation from persistence)
-        a.persist = persist_mode; a.persist_delay = persist_delay; a.pair_mid_at = pair_mid_at;
-        a.pair_epoch = (int)((++pair_seq * 2654435761u) >> 12);      // 20-bit launch tag of the progress words (experiment: process-wide counter)
-        if (getenv("AFFNET_TRUNK_PAIR_DBG") && (pair_seq % 8) == 0) {
-            unsigned d[8];
-            (void)hipDeviceSynchronize();
-            if (hipMemcpyFromSymbol(d, HIP_SYMBOL(g_pair_dbg), sizeof(d)) == hipSuccess)
-                fprintf(stderr, "pair dbg after %u launches: workgroups %u, second slot %u, time-outs %u, waits %u, wait iterations %u\n", pair_seq, d[0], d[1], d[2], d[3], d[4]);
-        }
-        if (kind == AFFNET_NET_AFFNET) hipLaunchKernelGGL((cnn32_trunk_persist_kernel<AFFNET_NET_AFFNET, 8>), dim3(slots), dim3(512), 0, st, a, ps, row_count, row_count * B);
-        else if (kind == AFFNET_NET_ORINET) hipLaunchKernelGGL((cnn32_trunk_persist_kernel<AFFNET_NET_ORINET, 8>), dim3(slots), dim3(512), 0, st, a, ps, row_count, row_count * B);
-        else hipLaunchKernelGGL((cnn32_trunk_persist_kernel<AFFNET_NET_HARDNET, 8>), dim3(slots), dim3(512), 0, st, a, ps, row_count, row_count * B);
-    }
     else if (kind == AFFNET_NET_AFFNET) TRUNK_LAUNCH(AFFNET_NET_AFFNET);
     else if (kind == AFFNET_NET_ORINET) TRUNK_LAUNCH(AFFNET_NET_ORINET);
     else TRUNK_LAUNCH(AFFNET_NET_HARDNET);
