@@ -955,10 +955,14 @@ __global__ __launch_bounds__(256) void affnet_finish_kernel(const float* __restr
 
 __global__ __launch_bounds__(256) void orinet_finish_kernel(const float* __restrict__ part, const float* __restrict__ hb,
                                                             const int32_t* __restrict__ count, int n_max, float* __restrict__ out, int row_begin,
-                                                            int row_end, float* __restrict__ rot_lafs) {
+                                                            int row_end, float* __restrict__ rot_lafs, DenormSel ds) {
     const int row = row_begin + blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int n = min(count ? min(count[blockIdx.y], n_max) : n_max, row_end);
-    if (row >= n) return;
+    if (row >= n) {
+        // fused denormalisation (denorm_level_select_kernel's convention): pixel frames past the row count are cleared
+        if (ds.out_px && row < n_max && lane < 6) ds.out_px[6 * ((size_t)blockIdx.y * n_max + row) + lane] = 0.f;
+        return;
+    }
     const size_t pidx = (size_t)blockIdx.y * n_max + row;
     const float* pp = part + pidx * HEAD_PART_ORI;
     float th = 0.f;
@@ -983,8 +987,12 @@ __global__ __launch_bounds__(256) void orinet_finish_kernel(const float* __restr
     if (rot_lafs) {                                                   // apply_rotation_kernel (laf_ops.hip), same fmaf order
         float* L = rot_lafs + 6 * pidx;
         const float l00 = L[0], l01 = L[1], l10 = L[3], l11 = L[4];
-        L[0] = fmaf(l01, -sn, l00 * cs); L[1] = fmaf(l01, cs, l00 * sn);
-        L[3] = fmaf(l11, -sn, l10 * cs); L[4] = fmaf(l11, cs, l10 * sn);
+        const float r0 = fmaf(l01, -sn, l00 * cs), r1 = fmaf(l01, cs, l00 * sn), r3 = fmaf(l11, -sn, l10 * cs), r4 = fmaf(l11, cs, l10 * sn);
+        L[0] = r0; L[1] = r1; L[3] = r3; L[4] = r4;
+        // the one-image latency path: denormalisation + pyramid-level choice of the row right here (was a launch of its own; same function, same values)
+        if (ds.out_px)
+            aff_denorm_level_row(r0, r1, L[2], r3, r4, L[5], ds.c_a, ds.c_x, ds.c_y, ds.ps, ds.lt, ds.ca, ds.cx, ds.cy, ds.out_px + 6 * pidx, ds.ids + 3 * pidx,
+                                 ds.lafs_norm + 6 * pidx);
     }
 }
 
@@ -1225,7 +1233,7 @@ void aff_fill_pyr_src(const affnet_ctx* ctx, PyrSrc* t) {
 static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const float* patches, const float* lafs, const int32_t* ids,
                       const int32_t* count, int n_max, float* out, float* scratch, int dbg_layer, float* dbg_out, hipStream_t st,
                       bool mark_head = false, int row_begin = 0, int row_count = -1, const int32_t* skip_cnt = nullptr, int skip_n = 0,
-                      const ShapeFuse* fuse = nullptr, int shape_op = 0, float* rot_lafs = nullptr) {
+                      const ShapeFuse* fuse = nullptr, int shape_op = 0, float* rot_lafs = nullptr, const DenormSel* denorm = nullptr) {
     if (kind < 0 || kind > 2) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: unknown net kind %d", kind);
     if (!packed || !out || n_max < 0 || (!patches && (!lafs || !ids))) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: null argument");
     if (!patches && !ctx->ws) return aff_fail(ctx, AFFNET_ERR_INVALID, "cnn32: sampling from the pyramid needs a bound workspace");
@@ -1280,8 +1288,11 @@ static int cnn_launch(affnet_ctx* ctx, int kind, const float* packed, const floa
             hipLaunchKernelGGL(affnet_finish_kernel, dim3(aff_cdiv(row_count, 256), B), dim3(256), 0, st, scratch, packed + L.head_b, count, n_max, out,
                                row_begin, row_begin + row_count, skip_cnt, skip_n, sf);
         } else {
+            DenormSel ds;
+            memset(&ds, 0, sizeof(ds));
+            if (denorm && rot_lafs) ds = *denorm;
             hipLaunchKernelGGL(orinet_finish_kernel, dim3(aff_cdiv(row_count, 4), B), dim3(256), 0, st, scratch, packed + L.head_b, count, n_max, out,
-                               row_begin, row_begin + row_count, rot_lafs);
+                               row_begin, row_begin + row_count, rot_lafs, ds);
         }
         AFF_LAUNCH_CHECK(ctx);
     }
@@ -1344,10 +1355,12 @@ int aff_affnet_filter_rows(affnet_ctx* ctx, const float* packed, const float* re
 }
 
 // OriNet with LAF <- LAF * R applied by the finish kernel (d_lafs rotated in place).
+// denorm != NULL: the finish kernel also denormalises the rotated frame, chooses its pyramid level and writes the re-normalised frame (aff_denorm_level_select's
+// work, one launch less per call).
 int aff_orinet_rotate(affnet_ctx* ctx, const float* packed, float* lafs, const int32_t* ids, const int32_t* count, int n_max, float* out, float* scratch,
-                      hipStream_t st) {
+                      hipStream_t st, const DenormSel* denorm) {
     return cnn_launch(ctx, AFFNET_NET_ORINET, packed, nullptr, lafs, ids, count, n_max, out, scratch, -1, nullptr, st, false, 0, -1, nullptr, 0, nullptr, 0,
-                      lafs);
+                      lafs, denorm);
 }
 
 int aff_hardnet_forward_pyr_marked(affnet_ctx* ctx, const float* packed, const float* lafs, const int32_t* ids, const int32_t* count,

@@ -368,7 +368,6 @@ extern "C" int affnet_scale_lafs(affnet_ctx* ctx, const float* d_in, float* d_ou
     return AFFNET_OK;
 }
 
-struct LevelTable { double sig[AFFNET_MAX_OCTAVES * AFFNET_MAX_LEVELS]; int n_oct, n_lvl; };
 
 __global__ void level_select_kernel(const float* __restrict__ lafs_px, const int32_t* __restrict__ d_count, int n_max, float ps,
                                     LevelTable lt, float ca, float cx, float cy, int32_t* __restrict__ ids, float* __restrict__ lafs_norm) {
@@ -408,24 +407,19 @@ __global__ void denorm_level_select_kernel(const float* __restrict__ in, float* 
     const float* L = in + 6 * (bi * n_max + i);
     float* P = out_px + 6 * (bi * n_max + i);
     if (i >= n) { P[0] = P[1] = P[2] = P[3] = P[4] = P[5] = 0.f; return; }
-    const float q0 = c_a * L[0], q1 = c_a * L[1], q2 = c_x * L[2], q3 = c_a * L[3], q4 = c_a * L[4], q5 = c_y * L[5];
-    P[0] = q0; P[1] = q1; P[2] = q2; P[3] = q3; P[4] = q4; P[5] = q5;
-    const float p1 = q0 * q4, p2 = q1 * q3;
-    const float sc = sqrtf(fabsf(p1 - p2) + 1e-12f);
-    const double need = (double)(sc / ps);
-    int best = 0;
-    double bd = INFINITY;
-    const int tot = lt.n_oct * lt.n_lvl;
-    for (int k = 0; k < tot; ++k) {
-        const double df = lt.sig[k] - need;
-        const double d = sqrt(df * df);               // scipy cdist 'euclidean' on 1-D points
-        if (d < bd) { bd = d; best = k; }
-    }
-    int32_t* I = ids + 3 * (bi * n_max + i);
-    I[0] = best / lt.n_lvl; I[1] = best % lt.n_lvl; I[2] = 0;
-    float* O = lafs_norm + 6 * (bi * n_max + i);
-    O[0] = ca * q0; O[1] = ca * q1; O[2] = cx * q2;
-    O[3] = ca * q3; O[4] = ca * q4; O[5] = cy * q5;
+    aff_denorm_level_row(L[0], L[1], L[2], L[3], L[4], L[5], c_a, c_x, c_y, ps, lt, ca, cx, cy, P, ids + 3 * (bi * n_max + i), lafs_norm + 6 * (bi * n_max + i));
+}
+
+// The constants of denorm_level_select_kernel for this context, for a kernel that fuses the step (OriNet's finish kernel, cnn32.hip).
+void aff_denorm_sel_fill(affnet_ctx* ctx, int ps, float* d_lafs_px, int32_t* d_ids, float* d_lafs_norm, DenormSel* ds) {
+    const affnet_config& c = ctx->cfg;
+    ds->lt.n_oct = c.n_octaves; ds->lt.n_lvl = c.levels_per_octave;
+    for (int o = 0; o < ds->lt.n_oct; ++o)
+        for (int l = 0; l < ds->lt.n_lvl; ++l) ds->lt.sig[o * ds->lt.n_lvl + l] = c.level_sigma_px[o][l];
+    const float fw = (float)c.width, fh = (float)c.height, m = fw < fh ? fw : fh;
+    ds->out_px = d_lafs_px; ds->ids = d_ids; ds->lafs_norm = d_lafs_norm;
+    ds->c_a = m; ds->c_x = fw; ds->c_y = fh; ds->ps = (float)ps;
+    ds->ca = 1.0f / m; ds->cx = (float)(1.0 / (double)fw); ds->cy = (float)(1.0 / (double)fh);
 }
 
 int aff_denorm_level_select(affnet_ctx* ctx, const float* d_lafs_norm_in, float* d_lafs_px, const int32_t* d_count, int n_max, int ps, int32_t* d_ids,

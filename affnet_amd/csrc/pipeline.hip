@@ -9,6 +9,7 @@
 // num_survived (SparseImgRepresenter.py:151) and round-trips LAF scales through scipy on the
 // host (LAF.py:466).  The reference's discarded extra patch extraction (:178-179) is dropped.
 #include "common.h"
+#include "shape_filter.h"
 
 void aff_prof_mark(affnet_ctx* ctx, int idx, hipStream_t st) {
     if (!ctx->prof_on || ctx->prof_calls >= PROF_RING) return;
@@ -68,7 +69,8 @@ int aff_cnn_forward_pyr_rows(affnet_ctx* ctx, int kind, const float* packed, con
 int aff_affnet_filter_rows(affnet_ctx* ctx, const float* packed, const float* resp, const float* lafs, const int32_t* ids, const int32_t* count,
                            float* out, float* scratch, int row_begin, int row_count, bool lazy, int shape_op, hipStream_t st);
 int aff_orinet_rotate(affnet_ctx* ctx, const float* packed, float* lafs, const int32_t* ids, const int32_t* count, int n_max, float* out, float* scratch,
-                      hipStream_t st);
+                      hipStream_t st, const DenormSel* denorm);
+void aff_denorm_sel_fill(affnet_ctx* ctx, int ps, float* d_lafs_px, int32_t* d_ids, float* d_lafs_norm, DenormSel* ds);
 int aff_denorm_level_select(affnet_ctx* ctx, const float* d_lafs_norm_in, float* d_lafs_px, const int32_t* d_count, int n_max, int ps, int32_t* d_ids,
                             float* d_lafs_norm, hipStream_t st);
 
@@ -232,10 +234,14 @@ extern "C" int affnet_describe_detected(affnet_ctx* ctx, const affnet_nets* nets
         { int crc = aff_copy2d_async(ctx, ctx->cnt + CNT_SHAPED, CNT_TOTAL * sizeof(int32_t), det_count, sizeof(int32_t), sizeof(int32_t), B, st); if (crc) return crc; }
     }
     aff_prof_mark(ctx, 4, st);
+    bool denorm_done = false;          // OriNet's finish kernel has denormalised the frames and chosen their levels (descriptor path)
     if (do_ori) {
-        if (nets->d_orinet) {       // LAF <- LAF * R inside OriNet's finish kernel
-            rc = aff_orinet_rotate(ctx, nets->d_orinet, ctx->st_lafs_shaped, d_ids, d_count, F, ctx->st_R, ctx->st_hard_scratch, st);
+        if (nets->d_orinet) {       // LAF <- LAF * R inside OriNet's finish kernel; with descriptors also denormalisation + level choice
+            DenormSel ds;
+            if (d_desc) aff_denorm_sel_fill(ctx, 32, d_lafs_px, ctx->st_lvl_ids, ctx->st_lafs_norm, &ds);
+            rc = aff_orinet_rotate(ctx, nets->d_orinet, ctx->st_lafs_shaped, d_ids, d_count, F, ctx->st_R, ctx->st_hard_scratch, st, d_desc ? &ds : nullptr);
             if (rc) return rc;
+            denorm_done = d_desc != nullptr;
         } else {
             rc = aff_handcrafted_launch(ctx, AFFNET_HC_ORIENTATION, nullptr, ctx->st_lafs_shaped, d_ids, d_count, F, nets->h_orientation_window,
                                         ctx->st_R, nullptr, st);
@@ -247,8 +253,10 @@ extern "C" int affnet_describe_detected(affnet_ctx* ctx, const affnet_nets* nets
     aff_prof_mark(ctx, 5, st);
     if (d_desc) {
         // denormalise + level choice in one launch; descriptor rows past the row count are cleared by hardnet_finish_kernel
-        rc = aff_denorm_level_select(ctx, ctx->st_lafs_shaped, d_lafs_px, d_count, F, 32, ctx->st_lvl_ids, ctx->st_lafs_norm, st);
-        if (rc) return rc;
+        if (!denorm_done) {
+            rc = aff_denorm_level_select(ctx, ctx->st_lafs_shaped, d_lafs_px, d_count, F, 32, ctx->st_lvl_ids, ctx->st_lafs_norm, st);
+            if (rc) return rc;
+        }
         aff_prof_mark(ctx, 6, st);
         rc = aff_hardnet_forward_pyr_marked(ctx, nets->d_hardnet, ctx->st_lafs_norm, ctx->st_lvl_ids, d_count, F, d_desc,
                                             ctx->st_hard_scratch, st);

@@ -35,3 +35,32 @@ __device__ __forceinline__ void aff_shape_filter_row(const float* __restrict__ r
     key[i] = resp[i] * (ok ? 1.0f : 0.0f);
     if (ok) atomicAdd(&cnt[CNT_SURVIVED], 1);
 }
+
+// Denormalisation (LAF.py:407-417) + pyramid-level choice (LAF.py:450-472, float64 |a - b| argmin like scipy's cdist on 1-D points) + re-normalised frame
+// of ONE row, shared by denorm_level_select_kernel (laf_ops.hip) and OriNet's finish kernel (cnn32.hip), which fuses it behind the rotation.
+struct LevelTable { double sig[AFFNET_MAX_OCTAVES * AFFNET_MAX_LEVELS]; int n_oct, n_lvl; };
+struct DenormSel {           // per-launch constants + outputs (pointers of image 0, rows of image b at b * n_max); out_px == NULL: not fused
+    float* out_px; int32_t* ids; float* lafs_norm;
+    float c_a, c_x, c_y, ps, ca, cx, cy;
+    LevelTable lt;
+};
+__device__ __forceinline__ void aff_denorm_level_row(float l0, float l1, float l2, float l3, float l4, float l5, float c_a, float c_x, float c_y, float ps,
+                                                     const LevelTable& lt, float ca, float cx, float cy, float* __restrict__ P, int32_t* __restrict__ I,
+                                                     float* __restrict__ O) {
+    const float q0 = c_a * l0, q1 = c_a * l1, q2 = c_x * l2, q3 = c_a * l3, q4 = c_a * l4, q5 = c_y * l5;
+    P[0] = q0; P[1] = q1; P[2] = q2; P[3] = q3; P[4] = q4; P[5] = q5;
+    const float p1 = q0 * q4, p2 = q1 * q3;
+    const float sc = sqrtf(fabsf(p1 - p2) + 1e-12f);
+    const double need = (double)(sc / ps);
+    int best = 0;
+    double bd = INFINITY;
+    const int tot = lt.n_oct * lt.n_lvl;
+    for (int k = 0; k < tot; ++k) {
+        const double df = lt.sig[k] - need;
+        const double d = sqrt(df * df);               // scipy cdist 'euclidean' on 1-D points
+        if (d < bd) { bd = d; best = k; }
+    }
+    I[0] = best / lt.n_lvl; I[1] = best % lt.n_lvl; I[2] = 0;
+    O[0] = ca * q0; O[1] = ca * q1; O[2] = cx * q2;
+    O[3] = ca * q3; O[4] = ca * q4; O[5] = cy * q5;
+}
