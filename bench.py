@@ -418,6 +418,9 @@ def compact_line(d):
         other.update(pick(oc, ("config2_graph_ms", "config2_eager_ms", "config2_graph_identical_to_eager", "config2_launches", "config5_kp_s", "error")))
         if isinstance(oc.get("config5_roofline"), dict):
             other["config5_frac"] = oc["config5_roofline"].get("frac")
+        if isinstance(oc.get("config5_golden"), dict):
+            other["config5_golden_pass"] = oc["config5_golden"].get("pass")
+            other["config5_golden_rows_outside_1e-3"] = oc["config5_golden"].get("rows_outside_1e-3")
         if isinstance(oc.get("config5_cpu_baseline"), dict):
             other["config5_cpu_kp_s"] = oc["config5_cpu_baseline"].get("value")
     for mode in SPLIT:
@@ -1191,6 +1194,20 @@ def other_configs(nets, dev, arith, gpu_sections, with_cpu=True):
                                "traffic": traffic.get("trunk_hbm_bytes_per_launch") if traffic else None,
                                "traffic_source": traffic.get("source") if traffic else None,
                                "scale_space": traffic.get("scale_space") if traffic else None}
+    # host-independent parity leg of configs[4]: image 0 of the batch against the unmodified reference's output (tests/golden/make_golden_config3.py 4k)
+    gpath = os.path.join(ROOT, "tests", "golden", "synth_%dx%d_s0_n%d.npz" % (h5, w5, n5))
+    if os.path.isfile(gpath):
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from _rowmatch import match_rows
+        g = np.load(gpath)
+        n0 = int(r["count"].view(-1)[0].item())
+        Lg, rg, Dg = r["LAFs"][0, :n0].cpu().numpy(), r["responses"][0, :n0].cpu().numpy(), r["descriptors"][0, :n0].cpu().numpy()
+        gi, wi = match_rows(rg, Lg, g["resp"], g["LAFs"])
+        eg = np.abs(Lg[gi] - g["LAFs"][wi]).reshape(len(gi), -1).max(axis=1)
+        dg = np.abs(Dg[gi] - g["desc"][wi].astype(np.float32)).max(axis=1)
+        out["config5_golden"] = {"rows": int(len(g["resp"])), "matched": int(len(gi)), "rows_outside_1e-3": int((eg >= 1e-3).sum()), "laf_max_px": float(eg.max()),
+                                 "desc_max": float(dg.max()), "pass": bool(len(gi) >= 0.995 * len(g["resp"]) and (eg < 1e-3).mean() >= 0.999 and eg.max() < 1e-2 and (dg[eg < 1e-3] < 1e-3).all()),
+                                 "bar": ">= 99.5 % of the reference's rows matched, >= 99.9 % of the matched LAF rows within 1e-3 px, none outside 1e-2 px, descriptors (golden stored as float16) within 1e-3"}
     del det, x, r
     torch.cuda.empty_cache()
     if with_cpu:

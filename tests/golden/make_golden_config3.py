@@ -5,6 +5,7 @@ first 32-image launch (round 3); seeds 0, 1, 2, 63 (round 6) = the images bench.
 line does not depend on how the GPU box's CPU rounds.  Run in the authoring container only:
 
     python tests/golden/make_golden_config3.py [seed ...]
+    python tests/golden/make_golden_config3.py 4k          # BASELINE configs[4]: one 3840x2160 image (seed 0), 8000 kp -> synth_2160x3840_s0_n8000.npz
 
 Rows are in the reference's output order (torch.topk order of the responses); tests match rows through the bit pattern of the
 response (responses are bit-identical between the reference and the HIP path and practically unique)."""
@@ -28,6 +29,15 @@ def main():
     A = ns.architectures.AffNetFast(PS=32); A.load_state_dict(rh.load_state_dict("AffNet.pth")); A.eval()
     O = ns.architectures.OriNetFast(PS=32); O.load_state_dict(rh.load_state_dict("OriNet.pth")); O.eval()
     Hn = ns.HardNet.HardNet(); Hn.load_state_dict(orc.synthetic_hardnet_state(0)); Hn.eval()
+    if sys.argv[1:] == ["4k"]:
+        x = orc.synthetic_image(2160, 3840, 0)
+        det = ns.SparseImgRepresenter.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=8000, border=5, num_Baum_iters=1, AffNet=A, OriNet=O)
+        with torch.no_grad(), rh.quiet():
+            L, r = det(x, do_ori=True)
+            D = Hn(det.extract_patches_from_pyr(L, PS=32))
+        np.savez_compressed(os.path.join(HERE, "synth_2160x3840_s0_n8000.npz"), seed=0, LAFs=L.numpy(), resp=r.numpy(), desc=D.numpy().astype(np.float16))
+        print("written: 4K seed 0", L.shape, D.shape, "(descriptors as float16: 2^-11 relative, compared at 1e-3)")
+        return
     for seed in ([int(a) for a in sys.argv[1:]] or SEEDS):
         x = orc.synthetic_image(768, 1024, seed)
         det = ns.SparseImgRepresenter.ScaleSpaceAffinePatchExtractor(mrSize=5.192, num_features=2000, border=5, num_Baum_iters=1, AffNet=A, OriNet=O)

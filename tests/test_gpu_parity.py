@@ -1313,7 +1313,7 @@ def test_c_host_program_drives_the_boundary_without_python(amd, nets, weights, g
 
 
 @pytest.mark.parametrize("arith", ARITH)
-def test_config5_4k_deep_pyramid(amd, nets, weights, arith):
+def test_config5_4k_deep_pyramid(amd, nets, weights, golden_dir, arith):
     """BASELINE.json configs[4]: 3840x2160, 8000 kp, 8 octaves.  Detector identities must equal the oracle's; LAFs and DESCRIPTORS
     within 1e-3; the batched path (bench.py --config5: 8 images per launch) bit-identical to single-image calls."""
     A, O, H = nets
@@ -1329,6 +1329,18 @@ def test_config5_4k_deep_pyramid(amd, nets, weights, arith):
     _assert_accounted(rec)
     assert rec["responses_equal"]
     assert rec["desc_rows_within_1e-3"] >= 0.995 and dd[dl < 1e-3].max() < 1e-3, rec
+    # host-independent leg (round 6): the UNMODIFIED reference's own output for this image on the authoring host (tests/golden/make_golden_config3.py 4k;
+    # descriptors stored as float16), rows matched through the response bit pattern.  At 4K a handful of frames of several hundred px with OriNet vectors of
+    # length 1e-2 are ill-conditioned beyond 1e-3 px in ANY fp32 evaluation: >= 99.9 % of the rows within 1e-3 px, none outside 1e-2.
+    g = np.load(os.path.join(golden_dir, "synth_2160x3840_s0_n8000.npz"))
+    Lg, rg, Dg = res["LAFs"].cpu().numpy(), res["responses"].cpu().numpy(), res["descriptors"].cpu().numpy()
+    g2, w2 = match_rows(rg, Lg, g["resp"], g["LAFs"])
+    eg = np.abs(Lg[g2] - g["LAFs"][w2]).reshape(len(g2), -1).max(axis=1)
+    dg = np.abs(Dg[g2] - g["desc"][w2].astype(np.float32)).max(axis=1)
+    record_parity("configs[4]: 3840x2160 seed 0 vs the reference's golden output" + ("" if arith == "fp32" else " [arith %s]" % arith), golden_rows=int(len(g["resp"])), matched=int(len(g2)),
+                  rows_outside_1e_3=int((eg >= 1e-3).sum()), laf_max_px=float(eg.max()), desc_max=float(dg.max()), desc_rows_outside_1e_3=int((dg >= 1e-3).sum()))
+    assert len(g2) >= 0.995 * 8000 and (eg < 1e-3).mean() >= 0.999 and eg.max() < 1e-2, (len(g2), int((eg >= 1e-3).sum()), eg.max())
+    assert (dg[eg < 1e-3] < 1e-3).all(), "descriptor of a geometrically matching row off by more than 1e-3 vs the golden output"
     # batched: 8 images per launch (seed 0 first and last so that one oracle run covers both positions)
     del det
     torch.cuda.empty_cache()
