@@ -173,6 +173,41 @@ def test_metric_configuration_1024x768_n2000(golden_dir, weights):
     _close(D.numpy(), g["desc"], 1e-4, "descriptors")
 
 
+@pytest.mark.parametrize("case", [("graf_img1", "graf_img1.png"), ("cat", "hesaffnet_cat.png"), ("fox1", "hesaffnet_fox1.png")], ids=["graf_img1", "cat", "fox1"])
+def test_threshold_mode_as_shipped_full_size(golden_dir, weights, case):
+    """hesaffnet.py as the reference ships it (th = -1 => num = -1, AffNetFast slot, no orientation) on its own images at their own sizes:
+    the oracle against the unmodified reference's output (tests/golden/make_golden_thmode.py; 7075 / 7376 / 8980 rows).  Rows are in
+    (octave, level, pixel) order on both sides; a borderline shape-filter decision may flip on another host, so the comparison goes through
+    the response bit pattern and tolerates a handful of missing rows."""
+    from _rowmatch import match_rows
+    tag, fname = case
+    g = np.load(os.path.join(golden_dir, "thmode_%s.npz" % tag))
+    x = load_gray(os.path.join(golden_dir, fname))
+    ex = orc.OracleExtractor(mrSize=5.192, num_features=2000, border=5, num_Baum_iters=1, th=-1, affnet_sd=weights["AffNet"])
+    L, r = ex(x)
+    assert abs(L.shape[0] - g["LAFs"].shape[0]) <= 0.002 * g["LAFs"].shape[0]
+    gi, wi = match_rows(r.numpy(), L.numpy(), g["resp"], g["LAFs"])
+    assert len(gi) >= 0.998 * g["LAFs"].shape[0]
+    _close(L.numpy()[gi], g["LAFs"][wi], 2e-4, "threshold-mode LAFs px")
+    ell = orc.lafs_to_ellipses(L.numpy())
+    rel = np.abs(ell[gi] - g["ells"][wi]) / np.abs(g["ells"][wi][:, 2:]).max(axis=1, keepdims=True)
+    assert np.abs(ell[gi, :2] - g["ells"][wi, :2]).max() < 2e-4 and rel[:, 2:].max() < 1e-4
+
+
+@pytest.mark.parametrize("seed", [63])
+def test_bench_seed_goldens(golden_dir, weights, seed):
+    """The host-independent leg of bench.py's parity statement rests on tests/golden/synth_768x1024_s{0,1,2,63}_n2000.npz (unmodified reference,
+    authoring host): the oracle reproduces one of them here (seed 63 = the last image of the bench's second launch; 31 is covered above)."""
+    from _rowmatch import match_rows
+    g = np.load(os.path.join(golden_dir, "synth_768x1024_s%d_n2000.npz" % seed))
+    assert int(g["seed"]) == seed
+    ex, (L, r, P, D) = _full(orc.synthetic_image(768, 1024, seed), 2000, weights)
+    gi, wi = match_rows(r.numpy(), L.numpy(), g["resp"], g["LAFs"])
+    assert len(gi) >= 0.995 * 2000
+    dl = np.abs(L.numpy()[gi] - g["LAFs"][wi]).reshape(len(gi), -1).max(axis=1)
+    assert (dl < 1e-3).mean() >= 0.999 and np.abs(D.numpy()[gi] - g["desc"][wi]).max() < 1e-4
+
+
 @pytest.mark.parametrize("case", ["hesaffnet_cat", "hesaffnet_fox1", "synth_481x641_s5"])
 def test_odd_sized_inputs(golden_dir, weights, case):
     """The oracle on odd-sized inputs the reference ships (examples/hesaffnet/img/cat.png 598 x 1000, fox1.png 1000 x 563) and a
