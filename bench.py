@@ -477,6 +477,11 @@ def emit(d):
             sys.stderr.write("bench.py: could not write %s: %r\n" % (path, e))
     sys.stderr.write("bench.py detail record (also in %s):\n%s\n" % (DETAIL_FILE, full))
     sys.stderr.flush()
+    try:                               # whatever C libraries have buffered for stdout (RCCL's version banner: seen AFTER the line in a file) goes out first
+        C.CDLL(None).fflush(None)
+    except Exception:                  # noqa: BLE001
+        pass
+    sys.stdout.flush()
     print(compact_line(d), flush=True)
 
 
@@ -693,6 +698,9 @@ def run(args, world):
             args.chunk = 8
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if rank != 0:                      # only rank 0 owns stdout (the ONE line): what the other ranks' libraries print there goes to stderr
+        sys.stdout.flush()
+        os.dup2(2, 1)
     import torch.distributed as dist
     DRY = args.dry_run
     one_device = bool(os.environ.get("AFFNET_BENCH_ONE_DEVICE"))
@@ -1127,9 +1135,13 @@ def run(args, world):
                     w.pop("ex", None); w.pop("ref", None)
         wall["total_since_process_start_s"] = round(time.time() - T_START, 1)
         out["wall_s"] = wall
-        emit(out)
+        final = out
+    else:
+        final = None
     if DIST:
         dist.destroy_process_group()
+    if final is not None:
+        emit(final)                    # LAST: after the process group is gone (RCCL writes a version banner to the C stdout, flushed at exit)
 
 
 def other_configs(nets, dev, arith, gpu_sections, with_cpu=True):
@@ -1434,6 +1446,8 @@ def dry_run(args, world, rank, dist, sharded, DIST, gather_dst, backend):
     flag = torch.tensor([1.0 if ok else 0.0])
     if DIST:
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if DIST:
+        dist.destroy_process_group()
     if rank == 0:
         emit({"dry_run": True, "metric": "keypoints/sec (detect+AffNet+OriNet+HardNet) per image, %d kp @%dx%d" % (NKP, W, H),
               "value": None, "unit": "keypoints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": None, "higher_is_better": True,
@@ -1444,8 +1458,6 @@ def dry_run(args, world, rank, dist, sharded, DIST, gather_dst, backend):
                            if got is not None else None, "gather_ms": None},
               "ms_per_step_per_rank": {"min": None, "max": None},
               "records_in_global_order": bool(flag.item() == 1.0)})
-    if DIST:
-        dist.destroy_process_group()
     if flag.item() != 1.0:
         sys.exit(3)
 

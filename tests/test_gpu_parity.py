@@ -1538,3 +1538,21 @@ def test_bench_n_rank_gather_with_real_kernels(ranks, gather):
     assert set(d["ms_per_step_per_rank"]) == {"min", "max"} and d["ms_per_step_per_rank"]["max"] >= d["ms_per_step_per_rank"]["min"] > 0
     full = json.load(open(os.path.join(root, d["detail"])))                      # the full record (rank 0 writes it next to bench.py)
     assert len(full["ms_per_step_per_rank"]["all"]) == ranks and full["gather_check"]["identical"] is True
+
+
+def test_bench_line_is_the_last_stdout_line_with_rccl():
+    """The driver parses the LAST stdout line.  RCCL writes a version banner ("RCCL version : ... Librccl path : ...") to the C stdout, which - buffered -
+    landed AFTER the JSON line when stdout is a file (round 6 evidence run).  bench.py destroys the process group first, flushes the C buffers and prints its
+    line last; ranks other than 0 send their stdout to stderr.  The 1-rank RCCL flavour of the N-rank path (AFFNET_BENCH_SELF_GATHER=1) on this box."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env.update({"AFFNET_BENCH_SELF_GATHER": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "1", "--batch", "4", "--chunk", "2", "--no-cpu-baseline",
+                        "--no-secondary", "--no-other-configs", "--no-split3", "--verify-gather", "all"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    last = p.stdout.rstrip("\n").splitlines()[-1]
+    d = json.loads(last)                      # fails on a banner line
+    assert len(last) < 4096 and d["n_gpus"] == 1 and d["value"] > 0 and d["exchange"]["mode"] == "gather_rank0" and d["gather_check"]["identical"] is True
