@@ -1,7 +1,7 @@
 """Parity of RECORDED MI355X outputs (tests/golden/gpu_rows/*.npz, written on the GPU by tests/dump_rows_gpu.py / bench.py) against the CPU
 oracle run live on this host - no GPU needed.  The same bars as the GPU tests: keys matched exactly, responses of matched rows bit-equal,
 >= 99.5 % of the LAF rows within 1e-3 px, descriptors within 1e-3, every unmatched key and every row outside 1e-3 px accounted for by the
-float64 referee (oracle/fp64_referee.py).  On the authoring host these files reproduce profiles/r05_s1_offline_parity_*_authoring_host.json."""
+float64 referee (oracle/fp64_referee.py).  On the authoring host these files reproduce profiles/archive/r05_s1_offline_parity_*_authoring_host.json."""
 import glob
 import os
 import re
