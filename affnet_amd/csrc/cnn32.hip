@@ -978,21 +978,22 @@ __global__ __launch_bounds__(256) void orinet_finish_kernel(const float* __restr
     float t0 = 0.f, t1 = 0.f;
 #pragma unroll
     for (int q = 0; q < 9; ++q) { t0 += __shfl(th, q, 64); t1 += __shfl(th, 9 + q, 64); }
-    if (lane != 0) return;
+    if (lane != 0 && !(rot_lafs && ds.out_px)) return;                // (the fused level search below uses the whole wave: every lane carries the same row values)
     const float yv = t0 / 9.0f, xv = t1 / 9.0f;                       // AdaptiveAvgPool2d(1)
     const float ang = atan2f(yv + 1e-8f, xv + 1e-8f);                 // architectures.py:78
     const float sn = sinf(ang), cs = cosf(ang);
     float* o = out + 4 * pidx;
-    o[0] = cs; o[1] = sn; o[2] = -sn; o[3] = cs;
+    if (lane == 0) { o[0] = cs; o[1] = sn; o[2] = -sn; o[3] = cs; }
     if (rot_lafs) {                                                   // apply_rotation_kernel (laf_ops.hip), same fmaf order
         float* L = rot_lafs + 6 * pidx;
-        const float l00 = L[0], l01 = L[1], l10 = L[3], l11 = L[4];
+        const float l00 = L[0], l01 = L[1], l10 = L[3], l11 = L[4], lx = L[2], ly = L[5];
         const float r0 = fmaf(l01, -sn, l00 * cs), r1 = fmaf(l01, cs, l00 * sn), r3 = fmaf(l11, -sn, l10 * cs), r4 = fmaf(l11, cs, l10 * sn);
-        L[0] = r0; L[1] = r1; L[3] = r3; L[4] = r4;
-        // the one-image latency path: denormalisation + pyramid-level choice of the row right here (was a launch of its own; same function, same values)
+        // the one-image latency path: denormalisation + pyramid-level choice of the row right here (was a launch of its own; same values, the level search
+        // spread over the wave).  Every lane has read the frame BEFORE lane 0 overwrites it.
         if (ds.out_px)
-            aff_denorm_level_row(r0, r1, L[2], r3, r4, L[5], ds.c_a, ds.c_x, ds.c_y, ds.ps, ds.lt, ds.ca, ds.cx, ds.cy, ds.out_px + 6 * pidx, ds.ids + 3 * pidx,
-                                 ds.lafs_norm + 6 * pidx);
+            aff_denorm_level_row_wave(lane, r0, r1, lx, r3, r4, ly, ds.c_a, ds.c_x, ds.c_y, ds.ps, ds.lt, ds.ca, ds.cx, ds.cy, ds.out_px + 6 * pidx, ds.ids + 3 * pidx,
+                                      ds.lafs_norm + 6 * pidx);
+        if (lane == 0) { L[0] = r0; L[1] = r1; L[3] = r3; L[4] = r4; }
     }
 }
 

@@ -64,3 +64,34 @@ __device__ __forceinline__ void aff_denorm_level_row(float l0, float l1, float l
     O[0] = ca * q0; O[1] = ca * q1; O[2] = cx * q2;
     O[3] = ca * q3; O[4] = ca * q4; O[5] = cy * q5;
 }
+
+// The same row with the level search spread over the lanes of a wavefront (OriNet's finish kernel owns one wave per row: a single lane walking the 30 - 48
+// float64 distances made that kernel 4 x longer at 64 000 rows per launch).  EVERY lane calls it with the same row values; lane k evaluates level k's distance
+// with the expression of the sequential loop, the minimum is reduced with ties going to the LOWER index - what the loop's strict `<` selects - and lane 0 writes.
+__device__ __forceinline__ void aff_denorm_level_row_wave(int lane, float l0, float l1, float l2, float l3, float l4, float l5, float c_a, float c_x, float c_y, float ps,
+                                                          const LevelTable& lt, float ca, float cx, float cy, float* __restrict__ P, int32_t* __restrict__ I,
+                                                          float* __restrict__ O) {
+    const float q0 = c_a * l0, q1 = c_a * l1, q2 = c_x * l2, q3 = c_a * l3, q4 = c_a * l4, q5 = c_y * l5;
+    const float p1 = q0 * q4, p2 = q1 * q3;
+    const float sc = sqrtf(fabsf(p1 - p2) + 1e-12f);
+    const double need = (double)(sc / ps);
+    const int tot = lt.n_oct * lt.n_lvl;
+    double bd = INFINITY;
+    int best = 0x7fffffff;
+    for (int k = lane; k < tot; k += 64) {           // tot <= 128: at most two levels per lane, ascending
+        const double df = lt.sig[k] - need;
+        const double d = sqrt(df * df);
+        if (d < bd) { bd = d; best = k; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const double od = __shfl_xor(bd, off, 64);
+        const int ok = __shfl_xor(best, off, 64);
+        if (od < bd || (od == bd && ok < best)) { bd = od; best = ok; }
+    }
+    if (lane != 0) return;
+    P[0] = q0; P[1] = q1; P[2] = q2; P[3] = q3; P[4] = q4; P[5] = q5;
+    I[0] = best / lt.n_lvl; I[1] = best % lt.n_lvl; I[2] = 0;
+    O[0] = ca * q0; O[1] = ca * q1; O[2] = cx * q2;
+    O[3] = ca * q3; O[4] = ca * q4; O[5] = cy * q5;
+}

@@ -431,7 +431,7 @@ def test_roofline_table_regenerates_from_the_tracked_evidence():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sets = sorted(f[:-len("_kernel_stats.csv")] for f in glob.glob(os.path.join(root, "profiles", "r*_s*_kernel_stats.csv"))
                   if "split3" not in f and "split2h" not in f and "config" not in f and "onepass" not in f)
-    sets = [s for s in sets if os.path.exists(s + "_traffic.json") and os.path.exists(s + "_bench_default.json")]
+    sets = [s for s in sets if os.path.exists(s + "_traffic.json") and (os.path.exists(s + "_bench_default.json") or os.path.exists(s + "_bench_driver_detail.json"))]
     assert sets, "no full evidence set in profiles/"
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "roofline_table.py"), sets[-1]], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr[-400:]

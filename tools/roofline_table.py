@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Regenerates the bandwidth / FLOP-rate table of DESIGN.md section 4 from tracked files:
-    python tools/roofline_table.py profiles/r02_s2          (prefix of *_kernel_stats.csv, *_traffic.json, *_bench_default.json)
+    python tools/roofline_table.py profiles/r02_s2          (prefix of *_kernel_stats.csv, *_traffic.json, *_bench_default.json or, since round 6, *_bench_driver_detail.json)
 Per kernel: launches per 32-image call, mean duration (rocprofv3 --kernel-trace --stats), HBM bytes per launch from the
 FETCH_SIZE / WRITE_SIZE passes scaled by the calibration measured for the kernel's access width (tools/fetch_calib.py), the
 resulting GB/s and its fraction of 8 TB/s; for the CNN kernels the algorithmic FLOP rate against the 157.3 TFLOP/s fp32 MFMA peak.
@@ -45,7 +45,10 @@ def main(prefix):
     for r in csv.DictReader(open(prefix + "_kernel_stats.csv")):
         stats[r["Name"].split("(")[0]] = (int(r["Calls"]), float(r["AverageNs"]))
     traffic = json.load(open(prefix + "_traffic.json"))["kernels"]
-    bench = json.loads(open(prefix + "_bench_default.json").readline())
+    import os
+    # rounds 1 - 5: the full record was the bench line itself (*_bench_default.json); since round 6 the line is compact and the record a side file
+    bfile = prefix + "_bench_default.json" if os.path.exists(prefix + "_bench_default.json") else prefix + "_bench_driver_detail.json"
+    bench = json.loads(open(bfile).readline())
     aff_eval = bench.get("roofline", {}).get("affnet_patches_evaluated_per_image")
     if aff_eval:
         FLOP["cnn32_trunk_kernel<0"] = aff_eval * 19193856.0
