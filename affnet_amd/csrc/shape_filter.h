@@ -90,6 +90,7 @@ __device__ __forceinline__ void aff_denorm_level_row_wave(int lane, float l0, fl
         if (od < bd || (od == bd && ok < best)) { bd = od; best = ok; }
     }
     if (lane != 0) return;
+    if (best == 0x7fffffff) best = 0;                // a NaN frame: no distance compares below infinity - the sequential loop stays at level 0
     P[0] = q0; P[1] = q1; P[2] = q2; P[3] = q3; P[4] = q4; P[5] = q5;
     I[0] = best / lt.n_lvl; I[1] = best % lt.n_lvl; I[2] = 0;
     O[0] = ca * q0; O[1] = ca * q1; O[2] = cx * q2;
