@@ -447,7 +447,8 @@ int affnet_graph_launch(affnet_ctx* ctx, void* stream);
 /* Stage timing with HIP events recorded on the caller's stream around the stages of
  * affnet_extract_features (no host synchronisation while enabled; a ring of 256 calls).
  * Stages: 0 pyramid, 1 detector, 2 AffNet trunk(+sampling), 3 shape filter/select, 4 OriNet(+rotation),
- * 5 denormalise + level select, 6 HardNet trunk (+sampling), 7 HardNet head GEMM. */
+ * 5 denormalise + level select (with a native OriNet and descriptors this work is done by OriNet's finish kernel, i.e. inside
+ * stage 4, and stage 5 is empty), 6 HardNet trunk (+sampling), 7 HardNet head GEMM. */
 #define AFFNET_PROFILE_STAGES 8
 int affnet_profile_enable(affnet_ctx* ctx, int on);
 /* After the caller synchronised the stream(s): sums the elapsed milliseconds per stage over the
