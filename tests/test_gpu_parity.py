@@ -384,7 +384,8 @@ def _check_full(amd, nets, x, n, weights, want=None, min_match=0.995, name=None,
         record_parity(name + " vs the reference's golden output", golden_rows=int(len(want["resp"])), matched=int(len(g2)),
                       golden_rows_with_tied_responses=tie_groups(want["resp"]), laf_max_px=float(eg.max()), laf_rows_within_1e_3=float((eg < 1e-3).mean()),
                       desc_max=float(np.abs(D[g2] - want["desc"][w2]).max()))
-        assert len(g2) >= min_match * len(want["resp"]) and (eg < 1e-3).mean() >= 0.995 and eg.max() < 1e-2
+        # host-independent leg: EVERY matched row within 1e-3 px of the unmodified reference's own output (all callers are <= 1024 x 768; measured worst 6.9e-4 px)
+        assert len(g2) >= min_match * len(want["resp"]) and (eg < 1e-3).all(), "%d of %d golden rows outside 1e-3 px (worst %.3g)" % ((eg >= 1e-3).sum(), len(g2), eg.max())
         assert np.percentile(np.abs(D[g2] - want["desc"][w2]), 99.5) < 1e-3
     return det, res
 
